@@ -1,0 +1,163 @@
+/*
+ * vrc_hip.h -- C ABI of libvrc_hip.so, the MI355X (gfx950) device layer of the volume
+ * raycaster.  It replaces, entry point for entry point, the reference's CUDA device layer
+ * renderers/cudaRaycaster/cuda/ (classes cuda::Renderer, cuda::TexturePool, cuda::ColorMap,
+ * cuda::ClipPlanes, cuda::PixelBufferObject), which the host plugin classes
+ * CudaRaycastRenderer / CudaTexturePool / CudaTextureObject call.  Everything here is
+ * plain C: opaque handles, PODs, pointers and sizes.  No torch, no C++ types.
+ *
+ * Reference citations are path:line relative to the reference root.
+ *
+ * Return convention: 0 = VRC_OK, otherwise a VRC_E* code; vrc_last_error() returns the
+ * thread-local message (the reference throws std::runtime_error from checkCudaErrors,
+ * cuda/cuda.h:39-53; the C++ shim rethrows the same exception types).
+ *
+ * Threading (mirrors SURVEY 8b): vrc_pool_* are thread-safe (the reference guards its free
+ * list with a mutex, cuda/TexturePool.cu:179-185, and calls copyToSlot from 3 threads);
+ * vrc_update/pre_render/render/post_render are single-threaded per context.  Unlike the
+ * reference (quirk Q9) every upload is ordered before the next vrc_render by an event.
+ */
+#ifndef VRC_HIP_H
+#define VRC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRC_OK 0
+#define VRC_EINVAL 1     /* bad argument */
+#define VRC_EHIP 2       /* a HIP runtime call failed (message has hipGetErrorString) */
+#define VRC_EFULL 3      /* no free slot in the pool: slot = (-1,-1,-1), TexturePool.cu:180-181 */
+#define VRC_ENOMEM 4     /* allocation failed */
+#define VRC_EUNSUPPORTED 5 /* unsupported data type / channel count, TexturePool.cu:66-67 */
+
+typedef struct vrc_ctx vrc_ctx;   /* replaces cuda::Renderer (cuda/Renderer.cuh:69-112) */
+typedef struct vrc_pool vrc_pool; /* replaces cuda::TexturePool (cuda/TexturePool.cuh:42-103) */
+
+/* cuda/Renderer.cuh:35-41 -- 12 floats, 48 bytes, same field order */
+typedef struct
+{
+    float textureMin[3];  /* normalized atlas origin of the brick interior */
+    float textureSize[3]; /* normalized atlas size of the brick interior */
+    float aabbMin[3];     /* world box min */
+    float aabbSize[3];    /* world box size */
+} vrc_node_data;
+
+/* cuda/Renderer.cuh:46-56, same field order.  Matrices are column-major float[16]. */
+typedef struct
+{
+    float eyePosition[3];
+    uint32_t glViewport[4]; /* x, y, w, h; the kernel maps pixel (px,py) of the buffer */
+    float invProjMatrix[16];
+    float modelViewMatrix[16]; /* carried for ABI shape; unused by the kernel (quirk Q3) */
+    float invViewMatrix[16];
+    float aabbMin[3];
+    float aabbMax[3];
+    float nearPlane;
+} vrc_view_data;
+
+/* cuda/Renderer.cuh:59-66, same field order */
+typedef struct
+{
+    uint32_t samplesPerRay;
+    uint32_t samplesPerPixel;  /* unused by the kernel (quirk Q3) */
+    uint32_t maxSamplesPerRay; /* opacity-correction reference, 32 in the reference */
+    uint32_t datatype;         /* unused by the kernel (quirk Q2) */
+    float dataSourceRange[2];
+} vrc_render_data;
+
+/* per-render statistics (not in the reference; feeds bench.py's Msamples/s and roofline) */
+typedef struct
+{
+    float kernel_ms;        /* HIP-event time of the last raycast kernel on the ctx stream */
+    uint64_t samples;       /* samples composited by the last vrc_render (0 if counting is off) */
+    uint32_t kernel_variant; /* which kernel ran: VRC_KERNEL_* */
+    uint32_t grid_dims[3];  /* brick-grid dims used by the DDA kernel (0 if not used) */
+} vrc_stats;
+
+/* ---- options (vrc_set_option) ---------------------------------------------------------- */
+#define VRC_OPT_KERNEL 1          /* VRC_KERNEL_AUTO (default) | _REFERENCE_ORDER | _GRID_DDA */
+#define VRC_OPT_FILTER 2          /* 0 nearest (reference parity, default) | 1 trilinear (extension) */
+#define VRC_OPT_TF_FRAC_BITS 3    /* 8 (default, CUDA 1.8 fixed-point lerp weight) | 0 exact float */
+#define VRC_OPT_COUNT_SAMPLES 4   /* 0 (default) | 1: count composited samples (slower kernel) */
+
+#define VRC_KERNEL_AUTO 0
+#define VRC_KERNEL_REFERENCE_ORDER 1 /* O(nodes) loop per ray in host order, cuda/Renderer.cu:172-227 */
+#define VRC_KERNEL_GRID_DDA 2        /* 3-D DDA over the brick grid; needs a grid-aligned node set */
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* cuda::Renderer::Renderer() (cuda/Renderer.cu:234-238); device is explicit (fixes Q11) */
+int vrc_ctx_create( int device, vrc_ctx** out );
+void vrc_ctx_destroy( vrc_ctx* ctx );
+/* launch on a caller-owned hipStream_t (pass the handle as void*); NULL = the ctx's own stream */
+int vrc_ctx_set_stream( vrc_ctx* ctx, void* hip_stream );
+int vrc_set_option( vrc_ctx* ctx, int option, int64_t value );
+int vrc_get_option( vrc_ctx* ctx, int option, int64_t* value );
+
+/* ---- texture pool (brick atlas) ----------------------------------------------------------- */
+/* cuda::TexturePool::TexturePool (cuda/TexturePool.cu:101-173).  max_block is the slot size
+ * in voxels (block + 2*overlap), max_bytes the atlas budget.  Slot grid and free-list order
+ * follow TexturePool.cu:128-144 with VRC_MAX_TEXTURE_3D standing in for maxTexture3D. */
+#define VRC_MAX_TEXTURE_3D 4096
+int vrc_pool_create( vrc_ctx* ctx, size_t bytes_per_voxel, int is_signed, int is_float,
+                     size_t n_components, const uint32_t max_block[3], size_t max_bytes,
+                     vrc_pool** out );
+void vrc_pool_destroy( vrc_pool* pool );
+/* cuda::TexturePool::copyToSlot (cuda/TexturePool.cu:175-203): host brick of size[] voxels,
+ * tightly packed, x fastest.  Writes the normalized slot origin; on a full pool returns
+ * VRC_EFULL and writes (-1,-1,-1).  The host pointer is only borrowed for the call. */
+int vrc_pool_copy_to_slot( vrc_pool* pool, const void* host_brick, const uint32_t size[3],
+                           float slot_out[3] );
+/* same, but the brick already lives in device memory (row-major, tightly packed) */
+int vrc_pool_copy_to_slot_device( vrc_pool* pool, const void* device_brick,
+                                  const uint32_t size[3], float slot_out[3] );
+/* cuda::TexturePool::releaseSlot (cuda/TexturePool.cu:210-214) */
+int vrc_pool_release_slot( vrc_pool* pool, const float slot[3] );
+/* getSlotMemSize / getTextureSize / getTextureMem (cuda/TexturePool.cuh:80-95) + free count */
+int vrc_pool_info( const vrc_pool* pool, size_t* slot_bytes, uint32_t atlas_dim[3],
+                   size_t* atlas_bytes, uint32_t slots[3], uint32_t* free_slots );
+/* block until every pending upload of the pool has landed in HBM */
+int vrc_pool_synchronize( vrc_pool* pool );
+/* debug/test: read back the voxel at logical atlas coordinate (x,y,z) region into host memory,
+ * row-major; used by the parity tests to check the atlas layout transform */
+int vrc_pool_read_region( vrc_pool* pool, const uint32_t origin[3], const uint32_t size[3],
+                          void* host_out );
+
+/* ---- renderer ----------------------------------------------------------------------------- */
+/* cuda::Renderer::update (cuda/Renderer.cu:245-250): 256 RGBA float texels as
+ * lexis ColorMap::sampleColors<float>(256,0,256,0) yields them (cuda/ColorMap.cu:56-65), and
+ * up to 6 clip planes (nx,ny,nz,d) (cuda/ClipPlanes.cu:32-46).  n_planes == 0 clears the
+ * planes (the reference keeps stale ones, an obvious slip). */
+int vrc_update( vrc_ctx* ctx, const float tf_rgba[256 * 4], const float* planes, uint32_t n_planes );
+/* cuda::Renderer::preRender (cuda/Renderer.cu:252-257) + PixelBufferObject::resize/mapBuffer
+ * (cuda/PixelBufferObject.cu:43-81): (re)allocate W x H float4 and clear it to 0.
+ * W = glViewport[2], H = glViewport[3] (the reference's w-x / h-y is quirk Q10). */
+int vrc_pre_render( vrc_ctx* ctx, const vrc_view_data* view );
+/* render into caller-owned device memory instead (the reference renders into a GL-owned PBO):
+ * width*height float4, cleared by vrc_pre_render like the internal one.  NULL returns to the
+ * internal buffer. */
+int vrc_set_framebuffer( vrc_ctx* ctx, void* device_rgba, uint32_t width, uint32_t height );
+int vrc_get_framebuffer( vrc_ctx* ctx, void** device_rgba, uint32_t* width, uint32_t* height );
+/* cuda::Renderer::render (cuda/Renderer.cu:274-297): node table H2D + one rayCast pass that
+ * accumulates into the pixel buffer.  nodes are in the host's front-to-back order. */
+int vrc_render( vrc_ctx* ctx, const vrc_view_data* view, const vrc_node_data* nodes,
+                uint32_t n_nodes, const vrc_render_data* render, vrc_pool* pool );
+/* cuda::Renderer::postRender (cuda/Renderer.cu:299-326): the reference unmaps the PBO and
+ * glDrawPixels it; here the frame is complete on the stream and, if host_rgba is non-NULL,
+ * copied to W*H*4 floats of host memory (synchronous). */
+int vrc_post_render( vrc_ctx* ctx, float* host_rgba );
+int vrc_synchronize( vrc_ctx* ctx );
+int vrc_get_stats( vrc_ctx* ctx, vrc_stats* out );
+
+const char* vrc_last_error( void );
+/* ABI version of this header */
+#define VRC_ABI_VERSION 1
+int vrc_abi_version( void );
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRC_HIP_H */

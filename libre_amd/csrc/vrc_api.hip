@@ -1,0 +1,856 @@
+/*
+ * vrc_api.hip -- implementation of the C ABI declared in include/vrc_hip.h.
+ *
+ * Host-side logic of the device layer: context + stream, brick atlas (slot grid, free list,
+ * pinned staging ring, upload stream + event ordering), classified-table cache, node table
+ * and brick-grid construction, kernel selection, timing.  Replaces the host halves of
+ * cuda::Renderer::Impl (cuda/Renderer.cu:232-333) and cuda::TexturePool (cuda/TexturePool.cu).
+ */
+#include "../../include/vrc_hip.h"
+#include "vrc_internal.h"
+#include "vrc_tables.h"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace
+{
+thread_local std::string g_lastError;
+
+int fail( int code, const std::string& msg )
+{
+    g_lastError = msg;
+    return code;
+}
+
+#define VRC_HIP_CHECK( expr )                                                              \
+    do                                                                                     \
+    {                                                                                      \
+        const hipError_t _e = ( expr );                                                    \
+        if( _e != hipSuccess )                                                             \
+            return fail( VRC_EHIP, std::string( #expr ) + ": " + hipGetErrorString( _e ) ); \
+    } while( 0 )
+
+constexpr int kStagingSlots = 4;
+} // namespace
+
+struct vrc_pool
+{
+    vrc_ctx* ctx = nullptr;
+    uint32_t elemBytes = 1;
+    uint32_t maxBlock[3] = { 0, 0, 0 };
+    uint32_t slotDim[3] = { 0, 0, 0 }; /* maxBlock rounded up to the micro-block size */
+    uint32_t slots[3] = { 1, 1, 1 };
+    uint32_t atlasDim[3] = { 0, 0, 0 };
+    uint32_t nbx = 0, nby = 0, nbz = 0;
+    size_t slotBytes = 0, atlasBytes = 0;
+    void* dAtlas = nullptr;
+
+    std::mutex mutex; /* free list + staging ring index + upload event */
+    std::vector< std::array< float, 3 > > freeList;
+
+    hipStream_t uploadStream = nullptr;
+    hipEvent_t lastUpload = nullptr;
+    bool hasUpload = false;
+
+    struct Staging
+    {
+        std::mutex mutex;
+        void* pinned = nullptr;
+        void* device = nullptr;
+        hipEvent_t done = nullptr;
+        bool used = false;
+    };
+    Staging staging[kStagingSlots];
+    uint32_t nextStaging = 0;
+};
+
+struct vrc_ctx
+{
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+
+    /* cuda::ColorMap + cuda::ClipPlanes state */
+    float* dTf = nullptr;
+    uint64_t tfVersion = 0;
+    float planes[6][4];
+    uint32_t nPlanes = 0;
+
+    /* classified table */
+    vrc_f4* dLut = nullptr;
+    bool lutValid = false;
+    uint64_t lutTfVersion = 0;
+    vrc_lut_params lutParams = { 0, 0, 0, 0 };
+
+    /* pixel buffer (cuda::PixelBufferObject) */
+    vrc_f4* fbOwn = nullptr;
+    size_t fbOwnPixels = 0;
+    vrc_f4* fbExt = nullptr;
+    uint32_t fbW = 0, fbH = 0;
+
+    /* node table + brick grid */
+    vrc_dev_node* dNodes = nullptr;
+    size_t dNodesCap = 0;
+    int32_t* dGrid = nullptr;
+    size_t dGridCap = 0;
+    void* hStage = nullptr; /* pinned staging for nodes + grid */
+    size_t hStageCap = 0;
+    std::vector< vrc_node_data > cachedNodes;
+    const vrc_pool* cachedPool = nullptr;
+    bool cachedGridOk = false;
+    bool cachedClamp = false;
+    vrc_frame cachedGridFrame; /* only grid* fields are meaningful */
+
+    unsigned long long* dCounter = nullptr;
+    unsigned long long* hCounter = nullptr; /* pinned */
+
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    bool timed = false;
+
+    int64_t optKernel = VRC_KERNEL_AUTO;
+    int64_t optFilter = 0;
+    int64_t optTfFracBits = 8;
+    int64_t optCount = 0;
+
+    vrc_stats stats = {};
+};
+
+extern "C" {
+
+const char* vrc_last_error( void ) { return g_lastError.c_str(); }
+int vrc_abi_version( void ) { return VRC_ABI_VERSION; }
+
+/* ---------------------------------------------------------------------------------------- */
+int vrc_ctx_create( int device, vrc_ctx** out )
+{
+    if( !out )
+        return fail( VRC_EINVAL, "vrc_ctx_create: out is NULL" );
+    *out = nullptr;
+    int count = 0;
+    VRC_HIP_CHECK( hipGetDeviceCount( &count ) );
+    if( device < 0 || device >= count )
+        return fail( VRC_EINVAL, "vrc_ctx_create: no such device" );
+    VRC_HIP_CHECK( hipSetDevice( device ) );
+    vrc_ctx* c = new vrc_ctx();
+    c->device = device;
+    std::memset( c->planes, 0, sizeof( c->planes ) );
+    hipError_t e = hipStreamCreateWithFlags( &c->ownStream, hipStreamNonBlocking );
+    if( e == hipSuccess ) e = hipMalloc( &c->dTf, 256 * 4 * sizeof( float ) );
+    if( e == hipSuccess ) e = hipMalloc( &c->dLut, 256 * sizeof( vrc_f4 ) );
+    if( e == hipSuccess ) e = hipMalloc( &c->dCounter, sizeof( unsigned long long ) );
+    if( e == hipSuccess ) e = hipHostMalloc( &c->hCounter, sizeof( unsigned long long ) );
+    if( e == hipSuccess ) e = hipEventCreate( &c->evStart );
+    if( e == hipSuccess ) e = hipEventCreate( &c->evStop );
+    if( e != hipSuccess )
+    {
+        const std::string msg = std::string( "vrc_ctx_create: " ) + hipGetErrorString( e );
+        vrc_ctx_destroy( c );
+        return fail( VRC_EHIP, msg );
+    }
+    c->stream = c->ownStream;
+    *c->hCounter = 0;
+    /* default transfer function: linear grey ramp (the reference uploads lexis' default
+     * colour map in cuda::ColorMap::ColorMap, cuda/ColorMap.cu:32; that map lives in the
+     * un-vendored Lexis library, so the default here is documented and explicit) */
+    float tf[256 * 4];
+    for( int i = 0; i < 256; ++i )
+        tf[i * 4 + 0] = tf[i * 4 + 1] = tf[i * 4 + 2] = tf[i * 4 + 3] = (float)i / 255.0f;
+    e = hipMemcpy( c->dTf, tf, sizeof( tf ), hipMemcpyHostToDevice );
+    if( e != hipSuccess )
+    {
+        const std::string msg = std::string( "vrc_ctx_create: " ) + hipGetErrorString( e );
+        vrc_ctx_destroy( c );
+        return fail( VRC_EHIP, msg );
+    }
+    c->tfVersion = 1;
+    *out = c;
+    return VRC_OK;
+}
+
+void vrc_ctx_destroy( vrc_ctx* c )
+{
+    if( !c )
+        return;
+    (void)hipSetDevice( c->device );
+    if( c->stream ) (void)hipStreamSynchronize( c->stream );
+    if( c->dTf ) (void)hipFree( c->dTf );
+    if( c->dLut ) (void)hipFree( c->dLut );
+    if( c->fbOwn ) (void)hipFree( c->fbOwn );
+    if( c->dNodes ) (void)hipFree( c->dNodes );
+    if( c->dGrid ) (void)hipFree( c->dGrid );
+    if( c->hStage ) (void)hipHostFree( c->hStage );
+    if( c->dCounter ) (void)hipFree( c->dCounter );
+    if( c->hCounter ) (void)hipHostFree( c->hCounter );
+    if( c->evStart ) (void)hipEventDestroy( c->evStart );
+    if( c->evStop ) (void)hipEventDestroy( c->evStop );
+    if( c->ownStream ) (void)hipStreamDestroy( c->ownStream );
+    delete c;
+}
+
+int vrc_ctx_set_stream( vrc_ctx* c, void* s )
+{
+    if( !c )
+        return fail( VRC_EINVAL, "vrc_ctx_set_stream: ctx is NULL" );
+    VRC_HIP_CHECK( hipSetDevice( c->device ) );
+    VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
+    c->stream = s ? (hipStream_t)s : c->ownStream;
+    return VRC_OK;
+}
+
+int vrc_set_option( vrc_ctx* c, int option, int64_t value )
+{
+    if( !c )
+        return fail( VRC_EINVAL, "vrc_set_option: ctx is NULL" );
+    switch( option )
+    {
+    case VRC_OPT_KERNEL:
+        if( value < VRC_KERNEL_AUTO || value > VRC_KERNEL_GRID_DDA )
+            return fail( VRC_EINVAL, "vrc_set_option: bad kernel variant" );
+        c->optKernel = value;
+        return VRC_OK;
+    case VRC_OPT_FILTER:
+        if( value != 0 )
+            return fail( VRC_EUNSUPPORTED,
+                         "vrc_set_option: only nearest filtering (0) is implemented" );
+        c->optFilter = value;
+        return VRC_OK;
+    case VRC_OPT_TF_FRAC_BITS:
+        if( value < 0 || value > 16 )
+            return fail( VRC_EINVAL, "vrc_set_option: tf frac bits out of range" );
+        c->optTfFracBits = value;
+        return VRC_OK;
+    case VRC_OPT_COUNT_SAMPLES: c->optCount = value ? 1 : 0; return VRC_OK;
+    default: return fail( VRC_EINVAL, "vrc_set_option: unknown option" );
+    }
+}
+
+int vrc_get_option( vrc_ctx* c, int option, int64_t* value )
+{
+    if( !c || !value )
+        return fail( VRC_EINVAL, "vrc_get_option: NULL argument" );
+    switch( option )
+    {
+    case VRC_OPT_KERNEL: *value = c->optKernel; return VRC_OK;
+    case VRC_OPT_FILTER: *value = c->optFilter; return VRC_OK;
+    case VRC_OPT_TF_FRAC_BITS: *value = c->optTfFracBits; return VRC_OK;
+    case VRC_OPT_COUNT_SAMPLES: *value = c->optCount; return VRC_OK;
+    default: return fail( VRC_EINVAL, "vrc_get_option: unknown option" );
+    }
+}
+
+/* ---------------------------------------------------------------------------------------- */
+int vrc_pool_create( vrc_ctx* c, size_t bytesPerVoxel, int isSigned, int isFloat,
+                     size_t nComponents, const uint32_t maxBlock[3], size_t maxBytes,
+                     vrc_pool** out )
+{
+    (void)isSigned;
+    if( !c || !out || !maxBlock )
+        return fail( VRC_EINVAL, "vrc_pool_create: NULL argument" );
+    *out = nullptr;
+    /* cuda/TexturePool.cu:66-67 */
+    if( nComponents == 0 || nComponents > 4 )
+        return fail( VRC_EUNSUPPORTED, "Channel number cannot be 0 or larger than 4" );
+    /* the reference kernel only ever fetches unsigned char (Renderer.cu:211, quirk Q2);
+     * this layer renders 1-byte single-channel volumes and says so for the rest */
+    if( bytesPerVoxel != 1 || nComponents != 1 || isFloat )
+        return fail( VRC_EUNSUPPORTED,
+                     "vrc_pool_create: only 1-byte single-channel volumes are implemented" );
+    if( maxBlock[0] == 0 || maxBlock[1] == 0 || maxBlock[2] == 0 )
+        return fail( VRC_EINVAL, "vrc_pool_create: zero block size" );
+    VRC_HIP_CHECK( hipSetDevice( c->device ) );
+
+    vrc_pool* p = new vrc_pool();
+    p->ctx = c;
+    p->elemBytes = (uint32_t)( bytesPerVoxel * nComponents );
+    for( int a = 0; a < 3; ++a )
+    {
+        p->maxBlock[a] = maxBlock[a];
+        p->slotDim[a] = ( maxBlock[a] + VRC_MB - 1 ) / VRC_MB * VRC_MB;
+        if( p->slotDim[a] > VRC_MAX_TEXTURE_3D )
+        {
+            delete p;
+            return fail( VRC_EINVAL, "vrc_pool_create: block larger than VRC_MAX_TEXTURE_3D" );
+        }
+    }
+    p->slotBytes = (size_t)p->slotDim[0] * p->slotDim[1] * p->slotDim[2] * p->elemBytes;
+
+    /* cuda/TexturePool.cu:119-135, with 64-bit arithmetic (fixes quirk Q12) */
+    size_t freeMem = 0, totalMem = 0;
+    hipError_t e = hipMemGetInfo( &freeMem, &totalMem );
+    if( e != hipSuccess )
+    {
+        delete p;
+        return fail( VRC_EHIP, std::string( "hipMemGetInfo: " ) + hipGetErrorString( e ) );
+    }
+    const size_t maxMemory = std::min( freeMem, maxBytes );
+    const uint64_t maxBlocks64 = maxMemory / p->slotBytes;
+    const uint32_t maxBlocks = (uint32_t)std::min< uint64_t >( maxBlocks64, 0xFFFFFFFFull );
+    p->slots[0] = std::min( VRC_MAX_TEXTURE_3D / p->slotDim[0], std::max( maxBlocks, 1u ) );
+    p->slots[1] = std::min( VRC_MAX_TEXTURE_3D / p->slotDim[1],
+                            std::max( maxBlocks / p->slots[0], 1u ) );
+    p->slots[2] = std::min( VRC_MAX_TEXTURE_3D / p->slotDim[2],
+                            std::max( maxBlocks / ( p->slots[0] * p->slots[1] ), 1u ) );
+    for( int a = 0; a < 3; ++a )
+        p->atlasDim[a] = p->slots[a] * p->slotDim[a];
+    p->nbx = p->atlasDim[0] / VRC_MB;
+    p->nby = p->atlasDim[1] / VRC_MB;
+    p->nbz = p->atlasDim[2] / VRC_MB;
+    p->atlasBytes = (size_t)p->atlasDim[0] * p->atlasDim[1] * p->atlasDim[2] * p->elemBytes;
+    if( p->atlasBytes / p->elemBytes >= 0xFFFFFFFFull )
+    {
+        delete p;
+        return fail( VRC_EINVAL, "vrc_pool_create: atlas exceeds 2^32 voxels" );
+    }
+
+    /* cuda/TexturePool.cu:137-144: i,j,k descending, k innermost; slots are popped from the back */
+    for( int i = (int)p->slots[0] - 1; i >= 0; --i )
+        for( int j = (int)p->slots[1] - 1; j >= 0; --j )
+            for( int k = (int)p->slots[2] - 1; k >= 0; --k )
+                p->freeList.push_back( { (float)i / (float)p->slots[0],
+                                         (float)j / (float)p->slots[1],
+                                         (float)k / (float)p->slots[2] } );
+
+    e = hipMalloc( &p->dAtlas, p->atlasBytes );
+    if( e == hipSuccess ) e = hipMemset( p->dAtlas, 0, p->atlasBytes );
+    if( e == hipSuccess ) e = hipStreamCreateWithFlags( &p->uploadStream, hipStreamNonBlocking );
+    if( e == hipSuccess ) e = hipEventCreateWithFlags( &p->lastUpload, hipEventDisableTiming );
+    for( int s = 0; s < kStagingSlots && e == hipSuccess; ++s )
+    {
+        e = hipHostMalloc( &p->staging[s].pinned, p->slotBytes );
+        if( e == hipSuccess ) e = hipMalloc( &p->staging[s].device, p->slotBytes );
+        if( e == hipSuccess )
+            e = hipEventCreateWithFlags( &p->staging[s].done, hipEventDisableTiming );
+    }
+    if( e != hipSuccess )
+    {
+        const std::string msg = std::string( "vrc_pool_create: " ) + hipGetErrorString( e );
+        vrc_pool_destroy( p );
+        return fail( e == hipErrorOutOfMemory ? VRC_ENOMEM : VRC_EHIP, msg );
+    }
+    *out = p;
+    return VRC_OK;
+}
+
+void vrc_pool_destroy( vrc_pool* p )
+{
+    if( !p )
+        return;
+    (void)hipSetDevice( p->ctx->device );
+    if( p->uploadStream ) (void)hipStreamSynchronize( p->uploadStream );
+    if( p->ctx->cachedPool == p )
+    {
+        (void)hipStreamSynchronize( p->ctx->stream );
+        p->ctx->cachedPool = nullptr;
+        p->ctx->cachedNodes.clear();
+    }
+    for( int s = 0; s < kStagingSlots; ++s )
+    {
+        if( p->staging[s].pinned ) (void)hipHostFree( p->staging[s].pinned );
+        if( p->staging[s].device ) (void)hipFree( p->staging[s].device );
+        if( p->staging[s].done ) (void)hipEventDestroy( p->staging[s].done );
+    }
+    if( p->lastUpload ) (void)hipEventDestroy( p->lastUpload );
+    if( p->uploadStream ) (void)hipStreamDestroy( p->uploadStream );
+    if( p->dAtlas ) (void)hipFree( p->dAtlas );
+    delete p;
+}
+
+static int pool_take_slot( vrc_pool* p, float slot[3] )
+{
+    std::lock_guard< std::mutex > lock( p->mutex );
+    if( p->freeList.empty() )
+    {
+        slot[0] = slot[1] = slot[2] = -1.0f; /* INVALID_SLOT_POSITION, TexturePool.cu:98 */
+        return fail( VRC_EFULL, "vrc_pool_copy_to_slot: no free slot" );
+    }
+    const auto s = p->freeList.back();
+    p->freeList.pop_back();
+    slot[0] = s[0];
+    slot[1] = s[1];
+    slot[2] = s[2];
+    return VRC_OK;
+}
+
+static void pool_slot_voxel( const vrc_pool* p, const float slot[3], uint32_t o[3] )
+{
+    /* cuda/TexturePool.cu:193-197 */
+    for( int a = 0; a < 3; ++a )
+        o[a] = (uint32_t)std::lround( slot[a] * (float)p->atlasDim[a] );
+}
+
+static int pool_check_size( const vrc_pool* p, const uint32_t size[3] )
+{
+    for( int a = 0; a < 3; ++a )
+        if( size[a] == 0 || size[a] > p->slotDim[a] )
+            return fail( VRC_EINVAL, "vrc_pool_copy_to_slot: brick does not fit a slot" );
+    return VRC_OK;
+}
+
+static int pool_upload( vrc_pool* p, const void* src, bool srcIsDevice, const uint32_t size[3],
+                        float slotOut[3] )
+{
+    if( !p || !src || !size || !slotOut )
+        return fail( VRC_EINVAL, "vrc_pool_copy_to_slot: NULL argument" );
+    slotOut[0] = slotOut[1] = slotOut[2] = -1.0f;
+    int rc = pool_check_size( p, size );
+    if( rc != VRC_OK )
+        return rc;
+    VRC_HIP_CHECK( hipSetDevice( p->ctx->device ) );
+    float slot[3];
+    rc = pool_take_slot( p, slot );
+    if( rc != VRC_OK )
+        return rc;
+    uint32_t o[3];
+    pool_slot_voxel( p, slot, o );
+    const size_t bytes = (size_t)size[0] * size[1] * size[2] * p->elemBytes;
+
+    uint32_t si;
+    {
+        std::lock_guard< std::mutex > lock( p->mutex );
+        si = p->nextStaging++ % kStagingSlots;
+    }
+    vrc_pool::Staging& st = p->staging[si];
+    hipError_t e = hipSuccess;
+    {
+        std::lock_guard< std::mutex > slock( st.mutex );
+        if( st.used )
+            e = hipEventSynchronize( st.done ); /* staging buffers free again */
+        const void* devSrc = src;
+        if( e == hipSuccess && !srcIsDevice )
+        {
+            std::memcpy( st.pinned, src, bytes ); /* the host pointer is only borrowed */
+            e = hipMemcpyAsync( st.device, st.pinned, bytes, hipMemcpyHostToDevice,
+                                p->uploadStream );
+            devSrc = st.device;
+        }
+        if( e == hipSuccess )
+            e = vrc_launch_repack_brick( devSrc, p->dAtlas, p->elemBytes, size, o, p->nbx, p->nby,
+                                         p->uploadStream );
+        if( e == hipSuccess )
+            e = hipEventRecord( st.done, p->uploadStream );
+        st.used = true;
+        if( e == hipSuccess )
+        {
+            std::lock_guard< std::mutex > lock( p->mutex );
+            e = hipEventRecord( p->lastUpload, p->uploadStream );
+            p->hasUpload = true;
+        }
+    }
+    if( e != hipSuccess )
+    {
+        vrc_pool_release_slot( p, slot );
+        return fail( VRC_EHIP, std::string( "vrc_pool_copy_to_slot: " ) + hipGetErrorString( e ) );
+    }
+    if( srcIsDevice )
+    {
+        /* the caller's device buffer must stay valid until the repack has run */
+        e = hipStreamSynchronize( p->uploadStream );
+        if( e != hipSuccess )
+            return fail( VRC_EHIP, std::string( "vrc_pool_copy_to_slot_device: " ) +
+                                       hipGetErrorString( e ) );
+    }
+    slotOut[0] = slot[0];
+    slotOut[1] = slot[1];
+    slotOut[2] = slot[2];
+    return VRC_OK;
+}
+
+int vrc_pool_copy_to_slot( vrc_pool* p, const void* hostBrick, const uint32_t size[3],
+                           float slotOut[3] )
+{
+    return pool_upload( p, hostBrick, false, size, slotOut );
+}
+
+int vrc_pool_copy_to_slot_device( vrc_pool* p, const void* deviceBrick, const uint32_t size[3],
+                                  float slotOut[3] )
+{
+    return pool_upload( p, deviceBrick, true, size, slotOut );
+}
+
+int vrc_pool_release_slot( vrc_pool* p, const float slot[3] )
+{
+    if( !p || !slot )
+        return fail( VRC_EINVAL, "vrc_pool_release_slot: NULL argument" );
+    if( slot[0] < 0.f || slot[1] < 0.f || slot[2] < 0.f )
+        return fail( VRC_EINVAL, "vrc_pool_release_slot: invalid slot" );
+    std::lock_guard< std::mutex > lock( p->mutex );
+    p->freeList.push_back( { slot[0], slot[1], slot[2] } );
+    return VRC_OK;
+}
+
+int vrc_pool_info( const vrc_pool* p, size_t* slotBytes, uint32_t atlasDim[3], size_t* atlasBytes,
+                   uint32_t slots[3], uint32_t* freeSlots )
+{
+    if( !p )
+        return fail( VRC_EINVAL, "vrc_pool_info: pool is NULL" );
+    if( slotBytes ) *slotBytes = p->slotBytes;
+    if( atlasBytes ) *atlasBytes = p->atlasBytes;
+    for( int a = 0; a < 3; ++a )
+    {
+        if( atlasDim ) atlasDim[a] = p->atlasDim[a];
+        if( slots ) slots[a] = p->slots[a];
+    }
+    if( freeSlots )
+    {
+        std::lock_guard< std::mutex > lock( const_cast< vrc_pool* >( p )->mutex );
+        *freeSlots = (uint32_t)p->freeList.size();
+    }
+    return VRC_OK;
+}
+
+int vrc_pool_synchronize( vrc_pool* p )
+{
+    if( !p )
+        return fail( VRC_EINVAL, "vrc_pool_synchronize: pool is NULL" );
+    VRC_HIP_CHECK( hipSetDevice( p->ctx->device ) );
+    VRC_HIP_CHECK( hipStreamSynchronize( p->uploadStream ) );
+    return VRC_OK;
+}
+
+int vrc_pool_read_region( vrc_pool* p, const uint32_t origin[3], const uint32_t size[3],
+                          void* hostOut )
+{
+    if( !p || !origin || !size || !hostOut )
+        return fail( VRC_EINVAL, "vrc_pool_read_region: NULL argument" );
+    for( int a = 0; a < 3; ++a )
+        if( (uint64_t)origin[a] + size[a] > p->atlasDim[a] )
+            return fail( VRC_EINVAL, "vrc_pool_read_region: region outside the atlas" );
+    VRC_HIP_CHECK( hipSetDevice( p->ctx->device ) );
+    const size_t bytes = (size_t)size[0] * size[1] * size[2] * p->elemBytes;
+    if( bytes == 0 )
+        return VRC_OK;
+    void* tmp = nullptr;
+    VRC_HIP_CHECK( hipMalloc( &tmp, bytes ) );
+    hipError_t e = hipStreamSynchronize( p->uploadStream );
+    if( e == hipSuccess )
+        e = vrc_launch_read_region( p->dAtlas, tmp, p->elemBytes, origin, size, p->nbx, p->nby,
+                                    p->uploadStream );
+    if( e == hipSuccess ) e = hipStreamSynchronize( p->uploadStream );
+    if( e == hipSuccess ) e = hipMemcpy( hostOut, tmp, bytes, hipMemcpyDeviceToHost );
+    (void)hipFree( tmp );
+    if( e != hipSuccess )
+        return fail( VRC_EHIP, std::string( "vrc_pool_read_region: " ) + hipGetErrorString( e ) );
+    return VRC_OK;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+int vrc_update( vrc_ctx* c, const float tf[256 * 4], const float* planes, uint32_t nPlanes )
+{
+    if( !c )
+        return fail( VRC_EINVAL, "vrc_update: ctx is NULL" );
+    if( nPlanes > 6 )
+        return fail( VRC_EINVAL, "vrc_update: more than 6 clip planes" );
+    if( nPlanes > 0 && !planes )
+        return fail( VRC_EINVAL, "vrc_update: planes is NULL" );
+    VRC_HIP_CHECK( hipSetDevice( c->device ) );
+    if( tf )
+    {
+        /* 4 KiB, as cudaMemcpyToArray in cuda/ColorMap.cu:61-64; pageable source, so the
+         * call returns once the bytes are staged */
+        VRC_HIP_CHECK( hipMemcpyAsync( c->dTf, tf, 256 * 4 * sizeof( float ),
+                                       hipMemcpyHostToDevice, c->stream ) );
+        VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
+        ++c->tfVersion;
+    }
+    c->nPlanes = nPlanes;
+    for( uint32_t i = 0; i < nPlanes; ++i )
+        for( int k = 0; k < 4; ++k )
+            c->planes[i][k] = planes[i * 4 + k];
+    return VRC_OK;
+}
+
+static vrc_f4* ctx_fb( vrc_ctx* c ) { return c->fbExt ? c->fbExt : c->fbOwn; }
+
+int vrc_pre_render( vrc_ctx* c, const vrc_view_data* view )
+{
+    if( !c || !view )
+        return fail( VRC_EINVAL, "vrc_pre_render: NULL argument" );
+    const uint32_t w = view->glViewport[2], h = view->glViewport[3];
+    if( w == 0 || h == 0 )
+        return fail( VRC_EINVAL, "vrc_pre_render: empty viewport" );
+    VRC_HIP_CHECK( hipSetDevice( c->device ) );
+    if( c->fbExt )
+    {
+        if( w != c->fbW || h != c->fbH )
+            return fail( VRC_EINVAL, "vrc_pre_render: viewport differs from the external framebuffer" );
+    }
+    else
+    {
+        const size_t pixels = (size_t)w * h;
+        if( pixels > c->fbOwnPixels )
+        {
+            VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
+            if( c->fbOwn ) VRC_HIP_CHECK( hipFree( c->fbOwn ) );
+            c->fbOwn = nullptr;
+            c->fbOwnPixels = 0;
+            VRC_HIP_CHECK( hipMalloc( &c->fbOwn, pixels * sizeof( vrc_f4 ) ) );
+            c->fbOwnPixels = pixels;
+        }
+        c->fbW = w;
+        c->fbH = h;
+    }
+    /* PixelBufferObject::mapBuffer clears the mapped buffer (cuda/PixelBufferObject.cu:80) */
+    VRC_HIP_CHECK( hipMemsetAsync( ctx_fb( c ), 0, (size_t)w * h * sizeof( vrc_f4 ), c->stream ) );
+    return VRC_OK;
+}
+
+int vrc_set_framebuffer( vrc_ctx* c, void* deviceRgba, uint32_t width, uint32_t height )
+{
+    if( !c )
+        return fail( VRC_EINVAL, "vrc_set_framebuffer: ctx is NULL" );
+    if( deviceRgba && ( width == 0 || height == 0 ) )
+        return fail( VRC_EINVAL, "vrc_set_framebuffer: empty framebuffer" );
+    if( deviceRgba && ( (uintptr_t)deviceRgba % 16u ) != 0 )
+        return fail( VRC_EINVAL, "vrc_set_framebuffer: pointer must be 16-byte aligned" );
+    c->fbExt = (vrc_f4*)deviceRgba;
+    if( deviceRgba )
+    {
+        c->fbW = width;
+        c->fbH = height;
+    }
+    else
+    {
+        c->fbW = c->fbH = 0;
+        if( c->fbOwn )
+        {
+            (void)hipSetDevice( c->device );
+            (void)hipStreamSynchronize( c->stream );
+            (void)hipFree( c->fbOwn );
+            c->fbOwn = nullptr;
+            c->fbOwnPixels = 0;
+        }
+    }
+    return VRC_OK;
+}
+
+int vrc_get_framebuffer( vrc_ctx* c, void** deviceRgba, uint32_t* width, uint32_t* height )
+{
+    if( !c )
+        return fail( VRC_EINVAL, "vrc_get_framebuffer: ctx is NULL" );
+    if( deviceRgba ) *deviceRgba = ctx_fb( c );
+    if( width ) *width = c->fbW;
+    if( height ) *height = c->fbH;
+    return VRC_OK;
+}
+
+/* node table + brick grid: vrc_tables.h */
+static int ensure_capacity( vrc_ctx* c, size_t nNodes, size_t nGrid )
+{
+    if( nNodes > c->dNodesCap )
+    {
+        VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
+        if( c->dNodes ) VRC_HIP_CHECK( hipFree( c->dNodes ) );
+        c->dNodes = nullptr;
+        c->dNodesCap = 0;
+        const size_t cap = std::max< size_t >( nNodes, 1024 ); /* sized to n (fixes Q8) */
+        VRC_HIP_CHECK( hipMalloc( &c->dNodes, cap * sizeof( vrc_dev_node ) ) );
+        c->dNodesCap = cap;
+    }
+    if( nGrid > c->dGridCap )
+    {
+        VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
+        if( c->dGrid ) VRC_HIP_CHECK( hipFree( c->dGrid ) );
+        c->dGrid = nullptr;
+        c->dGridCap = 0;
+        const size_t cap = std::max< size_t >( nGrid, 4096 );
+        VRC_HIP_CHECK( hipMalloc( &c->dGrid, cap * sizeof( int32_t ) ) );
+        c->dGridCap = cap;
+    }
+    const size_t stageBytes = nNodes * sizeof( vrc_dev_node ) + nGrid * sizeof( int32_t );
+    if( stageBytes > c->hStageCap )
+    {
+        VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
+        if( c->hStage ) VRC_HIP_CHECK( hipHostFree( c->hStage ) );
+        c->hStage = nullptr;
+        c->hStageCap = 0;
+        const size_t cap = std::max< size_t >( stageBytes, 1 << 20 );
+        VRC_HIP_CHECK( hipHostMalloc( &c->hStage, cap ) );
+        c->hStageCap = cap;
+    }
+    return VRC_OK;
+}
+
+int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* nodes, uint32_t nNodes,
+                const vrc_render_data* render, vrc_pool* pool )
+{
+    if( !c || !view || !render || !pool )
+        return fail( VRC_EINVAL, "vrc_render: NULL argument" );
+    if( nNodes > 0 && !nodes )
+        return fail( VRC_EINVAL, "vrc_render: nodes is NULL" );
+    if( pool->ctx != c )
+        return fail( VRC_EINVAL, "vrc_render: pool belongs to another context" );
+    if( !ctx_fb( c ) || c->fbW == 0 )
+        return fail( VRC_EINVAL, "vrc_render: vrc_pre_render has not been called" );
+    if( view->glViewport[2] != c->fbW || view->glViewport[3] != c->fbH )
+        return fail( VRC_EINVAL, "vrc_render: viewport differs from the pixel buffer" );
+    if( render->samplesPerRay == 0 )
+        return fail( VRC_EINVAL, "vrc_render: samplesPerRay is 0" );
+    if( render->dataSourceRange[1] == render->dataSourceRange[0] )
+        return fail( VRC_EINVAL, "vrc_render: empty data source range" );
+    if( nNodes == 0 ) /* CudaRaycastRenderer.cpp:157-158 */
+        return VRC_OK;
+    VRC_HIP_CHECK( hipSetDevice( c->device ) );
+
+    /* classified table, rebuilt only when one of its inputs changed */
+    vrc_lut_params lp;
+    lp.rangeMin = render->dataSourceRange[0];
+    lp.rangeMax = render->dataSourceRange[1];
+    lp.alphaCorrection = (float)render->maxSamplesPerRay / (float)render->samplesPerRay;
+    lp.fracBits = (int)c->optTfFracBits;
+    if( !c->lutValid || c->lutTfVersion != c->tfVersion ||
+        std::memcmp( &lp, &c->lutParams, sizeof( lp ) ) != 0 )
+    {
+        VRC_HIP_CHECK( vrc_launch_build_lut( c->dTf, c->dLut, lp, c->stream ) );
+        c->lutParams = lp;
+        c->lutTfVersion = c->tfVersion;
+        c->lutValid = true;
+    }
+
+    /* node table + grid, re-derived and re-uploaded only when the node list changed
+     * (the reference re-uploads synchronously every pass, Renderer.cu:259-267) */
+    const bool sameNodes = c->cachedPool == pool && c->cachedNodes.size() == nNodes &&
+                           std::memcmp( c->cachedNodes.data(), nodes,
+                                        nNodes * sizeof( vrc_node_data ) ) == 0;
+    if( !sameNodes )
+    {
+        vrc_host_tables t;
+        vrc_atlas_geom geom;
+        for( int a = 0; a < 3; ++a )
+        {
+            geom.atlasDim[a] = pool->atlasDim[a];
+            geom.slotDim[a] = pool->slotDim[a];
+        }
+        geom.nbx = pool->nbx;
+        geom.nby = pool->nby;
+        vrc_build_tables( geom, nodes, nNodes, t );
+        const int rc = ensure_capacity( c, t.nodes.size(), t.grid.size() );
+        if( rc != VRC_OK )
+            return rc;
+        VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) ); /* staging buffer reuse */
+        uint8_t* h = (uint8_t*)c->hStage;
+        const size_t nb = t.nodes.size() * sizeof( vrc_dev_node );
+        const size_t gb = t.grid.size() * sizeof( int32_t );
+        std::memcpy( h, t.nodes.data(), nb );
+        VRC_HIP_CHECK( hipMemcpyAsync( c->dNodes, h, nb, hipMemcpyHostToDevice, c->stream ) );
+        if( gb )
+        {
+            std::memcpy( h + nb, t.grid.data(), gb );
+            VRC_HIP_CHECK(
+                hipMemcpyAsync( c->dGrid, h + nb, gb, hipMemcpyHostToDevice, c->stream ) );
+        }
+        c->cachedNodes.assign( nodes, nodes + nNodes );
+        c->cachedPool = pool;
+        c->cachedGridOk = t.gridOk;
+        c->cachedClamp = t.clamp;
+        c->cachedGridFrame = t.g;
+    }
+
+    bool useDda = c->cachedGridOk;
+    if( c->optKernel == VRC_KERNEL_REFERENCE_ORDER )
+        useDda = false;
+    else if( c->optKernel == VRC_KERNEL_GRID_DDA && !c->cachedGridOk )
+        return fail( VRC_EINVAL, "vrc_render: node set is not grid-aligned; GRID_DDA unavailable" );
+
+    vrc_raycast_args a;
+    std::memset( &a, 0, sizeof( a ) );
+    vrc_frame& f = a.frame;
+    {
+        vrc_atlas_geom geom;
+        for( int i = 0; i < 3; ++i )
+        {
+            geom.atlasDim[i] = pool->atlasDim[i];
+            geom.slotDim[i] = pool->slotDim[i];
+        }
+        geom.nbx = pool->nbx;
+        geom.nby = pool->nby;
+        vrc_fill_frame( f, *view, *render, geom, c->cachedGridFrame, c->planes, c->nPlanes, nNodes,
+                        c->fbW, c->fbH, 0.0f, 0.0f );
+    }
+
+    a.nodes = c->dNodes;
+    a.gridTable = useDda ? c->dGrid : nullptr;
+    a.atlas = pool->dAtlas;
+    a.lut = c->dLut;
+    a.pixelBuffer = ctx_fb( c );
+    a.sampleCounter = c->optCount ? c->dCounter : nullptr;
+    a.clamp = c->cachedClamp;
+    a.gridDda = useDda;
+
+    /* order the march after every brick upload issued so far (fixes quirk Q9) */
+    {
+        std::lock_guard< std::mutex > lock( pool->mutex );
+        if( pool->hasUpload )
+            VRC_HIP_CHECK( hipStreamWaitEvent( c->stream, pool->lastUpload, 0 ) );
+    }
+    if( c->optCount )
+        VRC_HIP_CHECK( hipMemsetAsync( c->dCounter, 0, sizeof( unsigned long long ), c->stream ) );
+    VRC_HIP_CHECK( hipEventRecord( c->evStart, c->stream ) );
+    VRC_HIP_CHECK( vrc_launch_raycast( a, c->stream ) );
+    VRC_HIP_CHECK( hipEventRecord( c->evStop, c->stream ) );
+    if( c->optCount )
+        VRC_HIP_CHECK( hipMemcpyAsync( c->hCounter, c->dCounter, sizeof( unsigned long long ),
+                                       hipMemcpyDeviceToHost, c->stream ) );
+    c->timed = true;
+    c->stats.kernel_variant = useDda ? VRC_KERNEL_GRID_DDA : VRC_KERNEL_REFERENCE_ORDER;
+    for( int i = 0; i < 3; ++i )
+        c->stats.grid_dims[i] = useDda ? (uint32_t)f.gridDim[i] : 0u;
+    return VRC_OK;
+}
+
+int vrc_post_render( vrc_ctx* c, float* hostRgba )
+{
+    if( !c )
+        return fail( VRC_EINVAL, "vrc_post_render: ctx is NULL" );
+    VRC_HIP_CHECK( hipSetDevice( c->device ) );
+    if( hostRgba )
+    {
+        if( !ctx_fb( c ) || c->fbW == 0 )
+            return fail( VRC_EINVAL, "vrc_post_render: no pixel buffer" );
+        VRC_HIP_CHECK( hipMemcpyAsync( hostRgba, ctx_fb( c ),
+                                       (size_t)c->fbW * c->fbH * sizeof( vrc_f4 ),
+                                       hipMemcpyDeviceToHost, c->stream ) );
+        VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
+    }
+    return VRC_OK;
+}
+
+int vrc_synchronize( vrc_ctx* c )
+{
+    if( !c )
+        return fail( VRC_EINVAL, "vrc_synchronize: ctx is NULL" );
+    VRC_HIP_CHECK( hipSetDevice( c->device ) );
+    VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
+    return VRC_OK;
+}
+
+int vrc_get_stats( vrc_ctx* c, vrc_stats* out )
+{
+    if( !c || !out )
+        return fail( VRC_EINVAL, "vrc_get_stats: NULL argument" );
+    VRC_HIP_CHECK( hipSetDevice( c->device ) );
+    if( c->timed )
+    {
+        VRC_HIP_CHECK( hipEventSynchronize( c->evStop ) );
+        float ms = 0.f;
+        VRC_HIP_CHECK( hipEventElapsedTime( &ms, c->evStart, c->evStop ) );
+        c->stats.kernel_ms = ms;
+        if( c->optCount )
+        {
+            VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
+            c->stats.samples = *c->hCounter;
+        }
+        else
+            c->stats.samples = 0;
+    }
+    *out = c->stats;
+    return VRC_OK;
+}
+
+} /* extern "C" */

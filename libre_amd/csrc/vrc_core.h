@@ -1,0 +1,492 @@
+/*
+ * vrc_core.h -- per-ray arithmetic of the raycaster, shared by the gfx950 kernels
+ * (vrc_kernels.hip) and by a host-compiled unit harness (tests/cpu_harness.cpp, g++,
+ * used only to exercise this logic under sanitizers where no GPU exists; it is never
+ * loaded by the product).
+ *
+ * What the arithmetic must reproduce is the reference kernel
+ * renderers/cudaRaycaster/cuda/Renderer.cu:95-230 (cited per function).  How it is
+ * organised is new: a brick-grid DDA instead of the O(nodes) loop, a per-frame 256-entry
+ * "classified sample" table instead of a per-sample TF fetch + pow, and an atlas stored as
+ * 8x8x8-voxel micro-blocks.
+ */
+#ifndef VRC_CORE_H
+#define VRC_CORE_H
+
+#include <stdint.h>
+
+#if defined( __HIPCC__ )
+#define VRC_HD __host__ __device__ __forceinline__
+#else
+#include <math.h>
+#define VRC_HD inline
+#endif
+
+#define VRC_EARLY_EXIT 0.999f     /* Renderer.cu:34 */
+#define VRC_EPSILON 0.0000000001f /* Renderer.cu:35 */
+
+/* atlas micro-block: 8x8x8 voxels, x fastest inside the block */
+#define VRC_MB 8u
+#define VRC_MB_SHIFT 3u
+#define VRC_MB_VOXELS 512u
+
+struct vrc_f3
+{
+    float x, y, z;
+};
+struct vrc_f4
+{
+    float x, y, z, w;
+};
+
+/* Kernel-side copy of vrc_node_data plus what the sampler needs per brick. 64 bytes. */
+struct vrc_dev_node
+{
+    float aabbMin[3];
+    float aabbSize[3];
+    float voxPerWorld[3]; /* texSize*atlasDim/aabbSize: atlas voxels per world unit */
+    float localOrigin[3]; /* atlas-voxel coordinate of aabbMin, relative to the slot origin */
+    uint32_t slotBlock;   /* micro-block index of the slot origin */
+    uint32_t slotVoxel[3]; /* atlas voxel coordinate of the slot origin (multiple of 8) */
+};
+
+/* Frame constants, derived on the host exactly as Renderer.cu:159-170 does per thread. */
+struct vrc_frame
+{
+    float eye[3];
+    float vpX, vpY, vpW, vpH;      /* glViewport as floats */
+    float pixelOffX, pixelOffY;    /* sort-first tile offset added to the buffer-local pixel */
+    float invProj[16];
+    float invView[16];
+    float aabbMin[3], aabbMax[3];
+    float nearPlane;
+    float stepSize;
+    uint32_t width, height;        /* pixel buffer */
+    uint32_t nPlanes;
+    float planes[6][4];
+    uint32_t nodeCount;
+    /* atlas */
+    uint32_t nbx, nby;             /* micro-blocks per atlas row / column */
+    uint32_t slotDim[3];           /* padded slot size in voxels */
+    /* brick grid for the DDA kernel */
+    float gridMin[3];
+    float cellSize[3];
+    float invCellSize[3];
+    int32_t gridDim[3];
+};
+
+/* physical element index of logical atlas voxel (x,y,z) */
+VRC_HD uint32_t vrc_swizzle( uint32_t x, uint32_t y, uint32_t z, uint32_t nbx, uint32_t nby )
+{
+    const uint32_t blk = ( ( z >> VRC_MB_SHIFT ) * nby + ( y >> VRC_MB_SHIFT ) ) * nbx +
+                         ( x >> VRC_MB_SHIFT );
+    const uint32_t inner = ( ( z & 7u ) << 6 ) | ( ( y & 7u ) << 3 ) | ( x & 7u );
+    return blk * VRC_MB_VOXELS + inner;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Classified-sample table entry for u8 density d: what Renderer.cu:215-218 computes from a
+ * sample of that density: tf = tex1D(tfTex, d*mult+add) (cuda/ColorMap.cu:40-45: 256 texels,
+ * linear, normalized, clamp; the lerp weight is kept in fracBits fractional bits, 8 on CUDA
+ * hardware, 0 = exact float); alpha' = 1 - pow(1 - min(tf.a, 255/256), alphaCorrection)
+ * (Renderer.cu:88-89); entry = (tf.rgb*alpha', alpha').  A pure function of d within a frame.
+ * ---------------------------------------------------------------------------------------- */
+struct vrc_lut_params
+{
+    float rangeMin, rangeMax; /* RenderData.dataSourceRange, Renderer.cu:162-164 */
+    float alphaCorrection;    /* maxSamplesPerRay / samplesPerRay, Renderer.cu:167-168 */
+    int fracBits;
+};
+
+VRC_HD vrc_f4 vrc_lut_entry( const float* tf, uint32_t d, vrc_lut_params p )
+{
+#if defined( __clang__ )
+#pragma clang fp contract( off )
+#endif
+    const float multiplyer = 1.0f / ( p.rangeMax - p.rangeMin );
+    const float addedValue = -p.rangeMin / ( p.rangeMax - p.rangeMin );
+    const float u = (float)d * multiplyer + addedValue;
+    const float xB = u * 256.0f - 0.5f;
+    const float fl = floorf( xB );
+    float a = xB - fl;
+    if( p.fracBits > 0 )
+    {
+        const float q = (float)( 1 << p.fracBits );
+        a = floorf( a * q + 0.5f ) / q;
+    }
+    int i0 = (int)fl, i1 = (int)fl + 1;
+    i0 = i0 < 0 ? 0 : ( i0 > 255 ? 255 : i0 );
+    i1 = i1 < 0 ? 0 : ( i1 > 255 ? 255 : i1 );
+    float c[4];
+    for( int k = 0; k < 4; ++k )
+        c[k] = ( 1.0f - a ) * tf[i0 * 4 + k] + a * tf[i1 * 4 + k];
+    const float corr = 1.0f - fminf( c[3], 1.0f - 1.0f / 256.0f );
+    const float alpha = 1.0f - powf( corr, p.alphaCorrection );
+    vrc_f4 e;
+    e.x = c[0] * alpha;
+    e.y = c[1] * alpha;
+    e.z = c[2] * alpha;
+    e.w = alpha;
+    return e;
+}
+
+/* cuda/math.cuh:1457-1464 (column-major 4x4 times vec4) */
+VRC_HD vrc_f4 vrc_mul44( const float* m, vrc_f4 v )
+{
+    vrc_f4 r;
+    r.x = m[0] * v.x + m[4] * v.y + m[8] * v.z + m[12] * v.w;
+    r.y = m[1] * v.x + m[5] * v.y + m[9] * v.z + m[13] * v.w;
+    r.z = m[2] * v.x + m[6] * v.y + m[10] * v.z + m[14] * v.w;
+    r.w = m[3] * v.x + m[7] * v.y + m[11] * v.z + m[15] * v.w;
+    return r;
+}
+
+VRC_HD float vrc_dot( vrc_f3 a, vrc_f3 b ) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+/* cuda/math.cuh:1310-1314 */
+VRC_HD vrc_f3 vrc_normalize( vrc_f3 v )
+{
+    const float invLen = 1.0f / sqrtf( vrc_dot( v, v ) );
+    vrc_f3 r = { v.x * invLen, v.y * invLen, v.z * invLen };
+    return r;
+}
+
+/* Renderer.cu:56-80; invR is hoisted (the reference recomputes the same value per call) */
+VRC_HD bool vrc_intersect_box( vrc_f3 origin, vrc_f3 invR, vrc_f3 boxMin, vrc_f3 boxMax,
+                               float* tnear, float* tfar )
+{
+    const float tbx = invR.x * ( boxMin.x - origin.x ), ttx = invR.x * ( boxMax.x - origin.x );
+    const float tby = invR.y * ( boxMin.y - origin.y ), tty = invR.y * ( boxMax.y - origin.y );
+    const float tbz = invR.z * ( boxMin.z - origin.z ), ttz = invR.z * ( boxMax.z - origin.z );
+    const float tminx = fminf( ttx, tbx ), tmaxx = fmaxf( ttx, tbx );
+    const float tminy = fminf( tty, tby ), tmaxy = fmaxf( tty, tby );
+    const float tminz = fminf( ttz, tbz ), tmaxz = fmaxf( ttz, tbz );
+    const float largestTmin = fmaxf( fmaxf( tminx, tminy ), tminz );
+    const float smallestTmax = fminf( fminf( tmaxx, tmaxy ), tmaxz );
+    *tnear = largestTmin;
+    *tfar = smallestTmax;
+    return smallestTmax > largestTmin;
+}
+
+struct vrc_ray
+{
+    vrc_f3 origin, dir, invDir;
+    float tNearGlobal, tFarGlobal, tNearPlane;
+    bool hit;
+};
+
+/* Renderer.cu:106-149 + :159-160: pixel -> world ray, global box, clip planes, near plane */
+VRC_HD vrc_ray vrc_setup_ray( const vrc_frame& f, uint32_t px, uint32_t py )
+{
+    vrc_ray r;
+    /* Renderer.cu:40-51 */
+    const float wx = (float)px + f.pixelOffX, wy = (float)py + f.pixelOffY;
+    const float nx = 2.0f * ( wx - f.vpX - ( f.vpW / 2.0f ) ) / f.vpW;
+    const float ny = 2.0f * ( wy - f.vpY - ( f.vpH / 2.0f ) ) / f.vpH;
+    const vrc_f4 ndc = { nx, ny, 1.0f, 1.0f };
+    const vrc_f4 e = vrc_mul44( f.invProj, ndc );
+    const vrc_f4 eyeSpace = { e.x / e.w, e.y / e.w, e.z / e.w, e.w / e.w };
+    const vrc_f4 world = vrc_mul44( f.invView, eyeSpace );
+    r.origin.x = f.eye[0];
+    r.origin.y = f.eye[1];
+    r.origin.z = f.eye[2];
+    const vrc_f3 d0 = { world.x - r.origin.x, world.y - r.origin.y, world.z - r.origin.z };
+    r.dir = vrc_normalize( d0 );
+    if( r.dir.x == 0.0f ) r.dir.x = VRC_EPSILON;
+    if( r.dir.y == 0.0f ) r.dir.y = VRC_EPSILON;
+    if( r.dir.z == 0.0f ) r.dir.z = VRC_EPSILON;
+    r.invDir.x = 1.0f / r.dir.x;
+    r.invDir.y = 1.0f / r.dir.y;
+    r.invDir.z = 1.0f / r.dir.z;
+
+    const vrc_f3 gmin = { f.aabbMin[0], f.aabbMin[1], f.aabbMin[2] };
+    const vrc_f3 gmax = { f.aabbMax[0], f.aabbMax[1], f.aabbMax[2] };
+    r.hit = vrc_intersect_box( r.origin, r.invDir, gmin, gmax, &r.tNearGlobal, &r.tFarGlobal );
+
+    /* Renderer.cu:132-146 */
+    for( uint32_t i = 0; i < f.nPlanes; ++i )
+    {
+        const vrc_f3 n = { f.planes[i][0], f.planes[i][1], f.planes[i][2] };
+        float rn = vrc_dot( r.dir, n );
+        if( rn == 0.0f )
+            rn = VRC_EPSILON;
+        const float t = -( vrc_dot( n, r.origin ) + f.planes[i][3] ) / rn;
+        if( rn > 0.0f )
+            r.tNearGlobal = fmaxf( r.tNearGlobal, t );
+        else
+            r.tFarGlobal = fminf( r.tFarGlobal, t );
+    }
+    if( r.tNearGlobal > r.tFarGlobal )
+        r.hit = false;
+
+    /* Renderer.cu:159-160 */
+    const vrc_f3 e3 = { eyeSpace.x, eyeSpace.y, eyeSpace.z };
+    const vrc_f3 ne = vrc_normalize( e3 );
+    r.tNearPlane = -f.nearPlane / ne.z;
+    return r;
+}
+
+/* One brick segment of one ray, Renderer.cu:179-201: returns false if the brick is skipped.
+ * stop: set when the reference would leave the node loop (tNear > tFarGlobal). */
+struct vrc_segment
+{
+    vrc_f3 pos;   /* rayStart */
+    vrc_f3 step;  /* normalize(stop-start)*stepSize */
+    float dist;
+};
+
+VRC_HD bool vrc_brick_segment( const vrc_ray& r, const vrc_dev_node& n, float stepSize,
+                               vrc_segment* s, bool* stop )
+{
+    const vrc_f3 boxMin = { n.aabbMin[0], n.aabbMin[1], n.aabbMin[2] };
+    const vrc_f3 boxMax = { boxMin.x + n.aabbSize[0], boxMin.y + n.aabbSize[1],
+                            boxMin.z + n.aabbSize[2] };
+    float tNear = 0.0f, tFar = 0.0f;
+    *stop = false;
+    if( !vrc_intersect_box( r.origin, r.invDir, boxMin, boxMax, &tNear, &tFar ) )
+        return false;
+    if( tNear > r.tFarGlobal )
+    {
+        *stop = true;
+        return false;
+    }
+    if( tFar < r.tNearGlobal )
+        return false;
+    tNear = fmaxf( fmaxf( r.tNearPlane, tNear ), r.tNearGlobal );
+    tFar = fminf( tFar, r.tFarGlobal );
+    if( tNear > tFar )
+        return false;
+
+    const vrc_f3 rayStart = { r.origin.x + r.dir.x * tNear, r.origin.y + r.dir.y * tNear,
+                              r.origin.z + r.dir.z * tNear };
+    const vrc_f3 rayStop = { r.origin.x + r.dir.x * tFar, r.origin.y + r.dir.y * tFar,
+                             r.origin.z + r.dir.z * tFar };
+    const vrc_f3 diff = { rayStop.x - rayStart.x, rayStop.y - rayStart.y,
+                          rayStop.z - rayStart.z };
+    const float d2 = vrc_dot( diff, diff );
+    const float invLen = 1.0f / sqrtf( d2 );
+    s->pos = rayStart;
+    s->step.x = diff.x * invLen * stepSize;
+    s->step.y = diff.y * invLen * stepSize;
+    s->step.z = diff.z * invLen * stepSize;
+    s->dist = sqrtf( d2 );
+    return true;
+}
+
+/* brick-local voxel of a world position (nearest, Renderer.cu:210-214 + point sampling of
+ * cuda/TexturePool.cu:163-170), as the physical element index in the atlas.
+ * Evaluated brick-locally so the float grid is finer than the reference's normalized
+ * atlas coordinate; voxel choice can differ only for samples within ~1e-4 voxel of a
+ * voxel face ("nearest-voxel flips"). */
+template < bool CLAMP >
+VRC_HD uint32_t vrc_voxel_index( const vrc_dev_node& n, const vrc_frame& f, vrc_f3 pos )
+{
+    const float lx = ( pos.x - n.aabbMin[0] ) * n.voxPerWorld[0] + n.localOrigin[0];
+    const float ly = ( pos.y - n.aabbMin[1] ) * n.voxPerWorld[1] + n.localOrigin[1];
+    const float lz = ( pos.z - n.aabbMin[2] ) * n.voxPerWorld[2] + n.localOrigin[2];
+    int ix = (int)floorf( lx ), iy = (int)floorf( ly ), iz = (int)floorf( lz );
+    if( CLAMP )
+    {
+        ix = ix < 0 ? 0 : ( ix > (int)f.slotDim[0] - 1 ? (int)f.slotDim[0] - 1 : ix );
+        iy = iy < 0 ? 0 : ( iy > (int)f.slotDim[1] - 1 ? (int)f.slotDim[1] - 1 : iy );
+        iz = iz < 0 ? 0 : ( iz > (int)f.slotDim[2] - 1 ? (int)f.slotDim[2] - 1 : iz );
+    }
+    const uint32_t ux = (uint32_t)ix, uy = (uint32_t)iy, uz = (uint32_t)iz;
+    const uint32_t blk = n.slotBlock + ( ( uz >> VRC_MB_SHIFT ) * f.nby + ( uy >> VRC_MB_SHIFT ) ) * f.nbx +
+                         ( ux >> VRC_MB_SHIFT );
+    const uint32_t inner = ( ( uz & 7u ) << 6 ) | ( ( uy & 7u ) << 3 ) | ( ux & 7u );
+    return blk * VRC_MB_VOXELS + inner;
+}
+
+/* Renderer.cu:83-93 with the classified table: e = (rgb*alpha', alpha') for the density */
+VRC_HD void vrc_composite( vrc_f4& c, const vrc_f4& e )
+{
+    const float t = 1.0f - c.w;
+    c.x = c.x + e.x * t;
+    c.y = c.y + e.y * t;
+    c.z = c.z + e.z * t;
+    c.w = c.w + e.w * t;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * March one brick segment (Renderer.cu:206-223).  Samples are taken in groups of four so
+ * that four atlas fetches are in flight per lane; each sample is composited only if the
+ * reference loop would have reached it (travel > 0 and no early exit yet), so the result
+ * is the reference's sample sequence exactly.
+ * Returns true when the early-ray-termination threshold was crossed (Renderer.cu:219-226).
+ * ---------------------------------------------------------------------------------------- */
+template < bool CLAMP, bool COUNT, typename ATLAS_T >
+VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_segment s,
+                               const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
+                               vrc_f4& color, uint32_t& nSamples )
+{
+    const float stepSize = f.stepSize;
+    float travel = s.dist;
+    vrc_f3 pos = s.pos;
+    bool done = false;
+    while( travel > 0.0f && !done )
+    {
+        uint32_t idx[4];
+        bool valid[4];
+#pragma unroll
+        for( int k = 0; k < 4; ++k )
+        {
+            valid[k] = travel > 0.0f;
+            /* positions past the end of the segment are computed but never fetched */
+            idx[k] = vrc_voxel_index< CLAMP >( n, f, pos );
+            pos.x += s.step.x;
+            pos.y += s.step.y;
+            pos.z += s.step.z;
+            travel -= stepSize;
+        }
+        uint32_t d[4];
+#pragma unroll
+        for( int k = 0; k < 4; ++k )
+            d[k] = valid[k] ? (uint32_t)atlas[idx[k]] : 0u;
+#pragma unroll
+        for( int k = 0; k < 4; ++k )
+        {
+            if( valid[k] && !done )
+            {
+                vrc_composite( color, lut[d[k]] );
+                if( COUNT )
+                    ++nSamples;
+                done = color.w > VRC_EARLY_EXIT;
+            }
+        }
+    }
+    return done;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Reference-order pixel: the O(nodeCount) loop of Renderer.cu:172-227, nodes in host order.
+ * ---------------------------------------------------------------------------------------- */
+template < bool CLAMP, bool COUNT, typename ATLAS_T >
+VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
+                                       const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
+                                       vrc_f4* __restrict__ pixelBuffer, uint32_t px, uint32_t py,
+                                       uint32_t& nSamples )
+{
+    const vrc_ray r = vrc_setup_ray( f, px, py );
+    if( !r.hit )
+        return; /* Renderer.cu:129-130, :148-149: pixel left untouched */
+    const uint32_t pixelPos = py * f.width + px;
+    vrc_f4 color = pixelBuffer[pixelPos];
+    if( color.w > VRC_EARLY_EXIT ) /* Renderer.cu:152-155 */
+        return;
+    for( uint32_t i = 0; i < f.nodeCount; ++i )
+    {
+        const vrc_dev_node n = nodes[i];
+        vrc_segment s;
+        bool stop;
+        if( !vrc_brick_segment( r, n, f.stepSize, &s, &stop ) )
+        {
+            if( stop )
+                break;
+            continue;
+        }
+        if( vrc_march_segment< CLAMP, COUNT, ATLAS_T >( f, n, s, atlas, lut, color, nSamples ) )
+            break;
+    }
+    pixelBuffer[pixelPos] = color; /* Renderer.cu:229 */
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Grid-DDA pixel: same per-brick arithmetic, but the bricks a ray meets are enumerated by a
+ * 3-D DDA over the brick grid (cell -> node index table) instead of testing every node.
+ * For a regular single-LOD grid the along-ray order equals the reference's host order for
+ * every pair of bricks that share a ray ("brick order").
+ * ---------------------------------------------------------------------------------------- */
+template < bool CLAMP, bool COUNT, typename ATLAS_T >
+VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
+                                const int32_t* __restrict__ gridTable,
+                                const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
+                                vrc_f4* __restrict__ pixelBuffer, uint32_t px, uint32_t py,
+                                uint32_t& nSamples )
+{
+    const vrc_ray r = vrc_setup_ray( f, px, py );
+    if( !r.hit )
+        return;
+    const uint32_t pixelPos = py * f.width + px;
+    vrc_f4 color = pixelBuffer[pixelPos];
+    if( color.w > VRC_EARLY_EXIT )
+        return;
+
+    /* ray interval inside the brick grid */
+    const vrc_f3 gmin = { f.gridMin[0], f.gridMin[1], f.gridMin[2] };
+    const vrc_f3 gmax = { f.gridMin[0] + f.cellSize[0] * (float)f.gridDim[0],
+                          f.gridMin[1] + f.cellSize[1] * (float)f.gridDim[1],
+                          f.gridMin[2] + f.cellSize[2] * (float)f.gridDim[2] };
+    float t0, t1;
+    bool any = vrc_intersect_box( r.origin, r.invDir, gmin, gmax, &t0, &t1 );
+    t0 = fmaxf( fmaxf( t0, r.tNearGlobal ), fmaxf( r.tNearPlane, 0.0f ) );
+    t1 = fminf( t1, r.tFarGlobal );
+    if( any && t0 <= t1 )
+    {
+        const float o[3] = { r.origin.x, r.origin.y, r.origin.z };
+        const float d[3] = { r.dir.x, r.dir.y, r.dir.z };
+        const float id[3] = { r.invDir.x, r.invDir.y, r.invDir.z };
+        int cell[3], stepDir[3];
+        float tMax[3], tDelta[3];
+#pragma unroll
+        for( int a = 0; a < 3; ++a )
+        {
+            const float p = o[a] + d[a] * t0;
+            int c = (int)floorf( ( p - f.gridMin[a] ) * f.invCellSize[a] );
+            c = c < 0 ? 0 : ( c > f.gridDim[a] - 1 ? f.gridDim[a] - 1 : c );
+            cell[a] = c;
+            const bool pos = d[a] > 0.0f;
+            stepDir[a] = pos ? 1 : -1;
+            const float boundary = f.gridMin[a] + f.cellSize[a] * (float)( pos ? c + 1 : c );
+            tMax[a] = ( boundary - o[a] ) * id[a];
+            tDelta[a] = f.cellSize[a] * fabsf( id[a] );
+        }
+        int32_t lastNode = -1;
+        const int maxSteps = f.gridDim[0] + f.gridDim[1] + f.gridDim[2] + 3;
+        for( int it = 0; it < maxSteps; ++it )
+        {
+            const int32_t node =
+                gridTable[( cell[2] * f.gridDim[1] + cell[1] ) * f.gridDim[0] + cell[0]];
+            if( node >= 0 && node != lastNode )
+            {
+                lastNode = node;
+                const vrc_dev_node n = nodes[node];
+                vrc_segment s;
+                bool stop;
+                if( vrc_brick_segment( r, n, f.stepSize, &s, &stop ) )
+                {
+                    if( vrc_march_segment< CLAMP, COUNT, ATLAS_T >( f, n, s, atlas, lut, color,
+                                                                    nSamples ) )
+                        break;
+                }
+                else if( stop )
+                    break;
+            }
+            /* advance to the next cell along the ray */
+            const float tNext = fminf( fminf( tMax[0], tMax[1] ), tMax[2] );
+            if( tNext > t1 )
+                break;
+            if( tMax[0] <= tMax[1] && tMax[0] <= tMax[2] )
+            {
+                cell[0] += stepDir[0];
+                tMax[0] += tDelta[0];
+                if( cell[0] < 0 || cell[0] >= f.gridDim[0] ) break;
+            }
+            else if( tMax[1] <= tMax[2] )
+            {
+                cell[1] += stepDir[1];
+                tMax[1] += tDelta[1];
+                if( cell[1] < 0 || cell[1] >= f.gridDim[1] ) break;
+            }
+            else
+            {
+                cell[2] += stepDir[2];
+                tMax[2] += tDelta[2];
+                if( cell[2] < 0 || cell[2] >= f.gridDim[2] ) break;
+            }
+        }
+    }
+    pixelBuffer[pixelPos] = color;
+}
+
+#endif /* VRC_CORE_H */

@@ -1,0 +1,190 @@
+/*
+ * vrc_tables.h -- host-side derivation of the kernel's node table and brick grid from the
+ * reference-shaped NodeData list (cuda/Renderer.cuh:35-41).  Header-only so that the C ABI
+ * (vrc_api.hip) and the CPU unit harness (tests/cpu_harness) run the very same code.
+ */
+#ifndef VRC_TABLES_H
+#define VRC_TABLES_H
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "../../include/vrc_hip.h"
+#include "vrc_core.h"
+
+struct vrc_atlas_geom
+{
+    uint32_t atlasDim[3];
+    uint32_t slotDim[3];
+    uint32_t nbx, nby;
+};
+
+struct vrc_host_tables
+{
+    std::vector< vrc_dev_node > nodes;
+    std::vector< int32_t > grid;
+    bool gridOk = false;
+    bool clamp = false;
+    vrc_frame g; /* grid fields only */
+};
+
+inline bool vrc_near_int( double v, double tol, long* out )
+{
+    const double r = std::floor( v + 0.5 );
+    *out = (long)r;
+    return std::fabs( v - r ) <= tol;
+}
+
+inline void vrc_build_tables( const vrc_atlas_geom& p, const vrc_node_data* in, uint32_t n,
+                              vrc_host_tables& t )
+{
+    t.nodes.resize( n );
+    t.clamp = false;
+    for( uint32_t i = 0; i < n; ++i )
+    {
+        const vrc_node_data& s = in[i];
+        vrc_dev_node& d = t.nodes[i];
+        for( int a = 0; a < 3; ++a )
+        {
+            d.aabbMin[a] = s.aabbMin[a];
+            d.aabbSize[a] = s.aabbSize[a];
+            const double dim = (double)p.atlasDim[a];
+            const double texMinVox = (double)s.textureMin[a] * dim;
+            const double texSizeVox = (double)s.textureSize[a] * dim;
+            d.voxPerWorld[a] = (float)( texSizeVox / (double)s.aabbSize[a] );
+            long tv = (long)std::floor( texMinVox + 0.5 );
+            if( tv < 0 ) tv = 0;
+            if( tv > (long)p.atlasDim[a] - 1 ) tv = (long)p.atlasDim[a] - 1;
+            const uint32_t slotIdx = (uint32_t)tv / p.slotDim[a];
+            d.slotVoxel[a] = slotIdx * p.slotDim[a];
+            d.localOrigin[a] = (float)( texMinVox - (double)d.slotVoxel[a] );
+            /* samples may land one voxel outside the interior on either side; if that can
+             * leave the slot (overlap 0), the kernel clamps inside the slot */
+            if( d.localOrigin[a] < 1.0f ||
+                d.localOrigin[a] + (float)texSizeVox > (float)p.slotDim[a] - 1.0f )
+                t.clamp = true;
+        }
+        d.slotBlock = ( ( d.slotVoxel[2] / VRC_MB ) * p.nby + ( d.slotVoxel[1] / VRC_MB ) ) * p.nbx +
+                      ( d.slotVoxel[0] / VRC_MB );
+    }
+
+    /* brick grid: cells of the finest brick size covering the union of the node boxes */
+    t.gridOk = false;
+    t.grid.clear();
+    for( int a = 0; a < 3; ++a )
+    {
+        t.g.gridMin[a] = 0.f;
+        t.g.cellSize[a] = 1.f;
+        t.g.invCellSize[a] = 1.f;
+        t.g.gridDim[a] = 0;
+    }
+    if( n == 0 )
+        return;
+    double cell[3], gmin[3], gmax[3];
+    for( int a = 0; a < 3; ++a )
+    {
+        cell[a] = in[0].aabbSize[a];
+        gmin[a] = in[0].aabbMin[a];
+        gmax[a] = (double)in[0].aabbMin[a] + in[0].aabbSize[a];
+    }
+    for( uint32_t i = 1; i < n; ++i )
+        for( int a = 0; a < 3; ++a )
+        {
+            cell[a] = std::min( cell[a], (double)in[i].aabbSize[a] );
+            gmin[a] = std::min( gmin[a], (double)in[i].aabbMin[a] );
+            gmax[a] = std::max( gmax[a], (double)in[i].aabbMin[a] + in[i].aabbSize[a] );
+        }
+    long dim[3];
+    for( int a = 0; a < 3; ++a )
+    {
+        if( !( cell[a] > 0.0 ) )
+            return;
+        if( !vrc_near_int( ( gmax[a] - gmin[a] ) / cell[a], 1e-3, &dim[a] ) || dim[a] < 1 ||
+            dim[a] > 4096 )
+            return;
+    }
+    if( (double)dim[0] * dim[1] * dim[2] > 64.0 * 1024 * 1024 )
+        return;
+    t.grid.assign( (size_t)dim[0] * dim[1] * dim[2], -1 );
+    for( uint32_t i = 0; i < n; ++i )
+    {
+        long i0[3], cnt[3];
+        for( int a = 0; a < 3; ++a )
+        {
+            if( !vrc_near_int( ( (double)in[i].aabbMin[a] - gmin[a] ) / cell[a], 1e-3, &i0[a] ) ||
+                !vrc_near_int( (double)in[i].aabbSize[a] / cell[a], 1e-3, &cnt[a] ) || cnt[a] < 1 ||
+                i0[a] < 0 || i0[a] + cnt[a] > dim[a] )
+            {
+                t.grid.clear();
+                return;
+            }
+        }
+        for( long z = i0[2]; z < i0[2] + cnt[2]; ++z )
+            for( long y = i0[1]; y < i0[1] + cnt[1]; ++y )
+                for( long x = i0[0]; x < i0[0] + cnt[0]; ++x )
+                {
+                    int32_t& c = t.grid[( (size_t)z * dim[1] + y ) * dim[0] + x];
+                    if( c != -1 )
+                    {
+                        /* overlapping nodes: not a partition, use the generic kernel */
+                        t.grid.clear();
+                        return;
+                    }
+                    c = (int32_t)i;
+                }
+    }
+    for( int a = 0; a < 3; ++a )
+    {
+        t.g.gridMin[a] = (float)gmin[a];
+        t.g.cellSize[a] = (float)cell[a];
+        t.g.invCellSize[a] = (float)( 1.0 / cell[a] );
+        t.g.gridDim[a] = (int32_t)dim[a];
+    }
+    t.gridOk = true;
+}
+
+/* Frame constants from the reference-shaped PODs (Renderer.cu:159-170 derives the same
+ * values per thread).  Grid fields come from vrc_build_tables. */
+inline void vrc_fill_frame( vrc_frame& f, const vrc_view_data& view, const vrc_render_data& render,
+                            const vrc_atlas_geom& geom, const vrc_frame& gridFrame,
+                            const float planes[6][4], uint32_t nPlanes, uint32_t nNodes,
+                            uint32_t fbW, uint32_t fbH, float pixelOffX, float pixelOffY )
+{
+    for( int i = 0; i < 3; ++i )
+    {
+        f.eye[i] = view.eyePosition[i];
+        f.aabbMin[i] = view.aabbMin[i];
+        f.aabbMax[i] = view.aabbMax[i];
+        f.slotDim[i] = geom.slotDim[i];
+        f.gridMin[i] = gridFrame.gridMin[i];
+        f.cellSize[i] = gridFrame.cellSize[i];
+        f.invCellSize[i] = gridFrame.invCellSize[i];
+        f.gridDim[i] = gridFrame.gridDim[i];
+    }
+    f.vpX = (float)view.glViewport[0];
+    f.vpY = (float)view.glViewport[1];
+    f.vpW = (float)view.glViewport[2];
+    f.vpH = (float)view.glViewport[3];
+    f.pixelOffX = pixelOffX;
+    f.pixelOffY = pixelOffY;
+    for( int i = 0; i < 16; ++i )
+    {
+        f.invProj[i] = view.invProjMatrix[i];
+        f.invView[i] = view.invViewMatrix[i];
+    }
+    f.nearPlane = view.nearPlane;
+    /* Renderer.cu:170: 1.0 / float(spr) evaluated in double, stored to float */
+    f.stepSize = (float)( 1.0 / (double)(float)render.samplesPerRay );
+    f.width = fbW;
+    f.height = fbH;
+    f.nPlanes = nPlanes;
+    for( int i = 0; i < 6; ++i )
+        for( int k = 0; k < 4; ++k )
+            f.planes[i][k] = planes[i][k];
+    f.nodeCount = nNodes;
+    f.nbx = geom.nbx;
+    f.nby = geom.nby;
+}
+
+#endif

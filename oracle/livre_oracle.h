@@ -1,0 +1,164 @@
+/*
+ * livre_oracle.h -- CPU ORACLE for the Libre cudaRaycaster hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check in
+ * __graft_entry__.py and the cpu_baseline leg of bench.py may load it.  The product
+ * path (libre_amd/csrc + libre_amd/host) never links, loads or calls anything here.
+ *
+ * It is a plain-C, IEEE-float32 restatement of the reference's algorithm, written from
+ * the reference's sources (cited per function as path:line relative to the reference
+ * root).  No reference source text is copied.
+ *
+ * PARITY PINNING: the reference holds NO golden frame, rendering test or known-answer
+ * pixel for the raycast itself, so the pixel path of this oracle
+ * is "parity unpinned" by the reference.  The adjacent host-side pieces ARE pinned by
+ * the reference's own unit tests (tests/lib/lodSelection.cpp, tests/lib/cache.cpp,
+ * tests/data/dataSource.cpp, tests/core/volumeInformation.cpp, tests/core/clipPlanes.cpp,
+ * tests/eq/settings/cameraSettings.cpp); those known answers are checked in
+ * tests/test_oracle_kat.py.
+ */
+#ifndef LIVRE_ORACLE_H
+#define LIVRE_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* renderers/cudaRaycaster/cuda/Renderer.cuh:35-41 */
+typedef struct
+{
+    float textureMin[3];
+    float textureSize[3];
+    float aabbMin[3];
+    float aabbSize[3];
+} orc_node_data;
+
+/* renderers/cudaRaycaster/cuda/Renderer.cuh:46-56 */
+typedef struct
+{
+    float eyePosition[3];
+    uint32_t glViewport[4];
+    float invProjMatrix[16];   /* column-major, cuda/math.cuh:1457-1464 */
+    float modelViewMatrix[16]; /* passed, unused by the kernel */
+    float invViewMatrix[16];
+    float aabbMin[3];
+    float aabbMax[3];
+    float nearPlane;
+} orc_view_data;
+
+/* renderers/cudaRaycaster/cuda/Renderer.cuh:59-66 */
+typedef struct
+{
+    uint32_t samplesPerRay;
+    uint32_t samplesPerPixel; /* unused by the kernel */
+    uint32_t maxSamplesPerRay;
+    uint32_t datatype; /* unused by the kernel */
+    float dataSourceRange[2];
+} orc_render_data;
+
+/* livre/core/data/VolumeInformation.h:43-112 (the fields the path reads) */
+typedef struct
+{
+    uint32_t voxels[3];
+    uint32_t maximumBlockSize[3];
+    uint32_t overlap[3];
+    float worldSize[3];
+    float worldSpacePerVoxel;
+    uint32_t depth;          /* RootNode::getDepth */
+    uint32_t rootBlocks[3];  /* RootNode::getBlockSize(0) */
+} orc_volume_info;
+
+/* livre/core/data/LODNode.h:35-124 (the fields the path reads) */
+typedef struct
+{
+    uint64_t nodeId;
+    uint32_t blockSize[3];
+    uint32_t voxelBoxMin[3];
+    uint32_t voxelBoxMax[3];
+    float worldBoxMin[3];
+    float worldBoxMax[3];
+} orc_lod_node;
+
+/* options of the integrator that the reference fixes in hardware state */
+typedef struct
+{
+    int tfFracBits;  /* 8 = CUDA linear-filter weights (1.8 fixed point); 0 = exact float */
+    int filter;      /* 0 = nearest (reference, cuda/TexturePool.cu:167); 1 = trilinear (extension) */
+    int nThreads;    /* row-parallel worker threads (>=1) */
+    uint32_t rowBegin, rowEnd, rowStride; /* rows [rowBegin,rowEnd) step rowStride are rendered */
+} orc_options;
+
+/* ---- NodeId: livre/core/data/NodeId.h:38-49, livre/core/types.h:191-195, mathTypes.h:82 */
+uint64_t orc_nodeid_pack( uint32_t level, uint32_t x, uint32_t y, uint32_t z, uint32_t timeStep );
+void orc_nodeid_unpack( uint64_t id, uint32_t out[5] ); /* level,x,y,z,t */
+uint64_t orc_nodeid_parent( uint64_t id );               /* NodeId.cpp:61-68 */
+void orc_nodeid_children( uint64_t id, uint64_t out[8] ); /* NodeId.cpp:92-113 */
+
+/* ---- livre/core/data/DataSourcePlugin.cpp:83-109 */
+void orc_fill_regular_volume_info( orc_volume_info* info );
+/* ---- datasources/memory/MemoryDataSource.cpp:74-131 (mem://#x,y,z,block) */
+void orc_mem_volume_info( uint32_t vx, uint32_t vy, uint32_t vz, uint32_t block, orc_volume_info* info );
+/* ---- livre/core/data/DataSourcePlugin.cpp:55-81 + LODNode.cpp:62-66 */
+void orc_lod_node_from_id( const orc_volume_info* info, uint64_t nodeId, orc_lod_node* out );
+/* ---- datasources/memory/MemoryDataSource.cpp:48-72 (uint8, sparsity 1) */
+uint8_t orc_mem_brick_value_u8( uint64_t nodeId );
+void orc_mem_brick_fill_u8( const orc_volume_info* info, uint64_t nodeId, uint8_t* dst );
+
+/* ---- cuda/TexturePool.cu:122-144: slot grid for a memory budget.
+ * maxTexture3D stands in for cudaDeviceProp::maxTexture3D, slotBytes for _cudaBlockSize. */
+void orc_pool_slots( const uint32_t maxBlock[3], size_t slotBytes, size_t maxBytes,
+                     const uint32_t maxTexture3D[3], uint32_t slotsOut[3] );
+/* free-list order: cuda/TexturePool.cu:137-144, pop from the back (:183-184).
+ * Writes the k-th slot handed out (k = 0 first) as the normalized origin. */
+void orc_pool_kth_slot( const uint32_t slots[3], uint32_t k, float slotOut[3] );
+/* cuda/TexturePool.cu:193-197: destination voxel origin of a slot in the atlas */
+void orc_pool_slot_voxel_origin( const uint32_t slots[3], const uint32_t maxBlock[3],
+                                 const float slot[3], uint32_t originOut[3] );
+/* copy one brick (size voxels, tightly packed, 1 byte/voxel) into a row-major u8 atlas */
+void orc_pool_copy_to_slot_u8( uint8_t* atlas, const uint32_t atlasDim[3],
+                               const uint32_t origin[3], const uint8_t* src,
+                               const uint32_t size[3] );
+/* ---- CudaTextureObject.cpp:61-84 */
+void orc_texture_object( const orc_volume_info* info, const orc_lod_node* node,
+                         const float slot[3], const uint32_t atlasDim[3],
+                         float texPosOut[3], float texSizeOut[3] );
+/* ---- CudaRaycastRenderer.cpp:41-61 (DistanceOperator): |MV * centre| */
+float orc_node_distance( const float mv[16], const orc_lod_node* node );
+/* ---- CudaRaycastRenderer.cpp:155-180: sort + NodeData fill. ids are permuted in place. */
+void orc_sort_nodes_front_to_back( const orc_volume_info* info, const float mv[16],
+                                   uint64_t* ids, uint32_t n );
+/* ---- CudaRaycastRenderer.cpp:113-129 */
+uint32_t orc_computed_samples_per_ray( const orc_volume_info* info, const uint64_t* ids,
+                                       uint32_t n, uint32_t samplesPerRayFlag );
+
+/* ---- camera: livre/core/settings/CameraSettings.cpp:35-103, Frustum.cpp:27-43 */
+void orc_mat4_identity( float m[16] );
+void orc_mat4_mul( const float a[16], const float b[16], float out[16] );
+int orc_mat4_inverse( const float m[16], float out[16] );
+void orc_look_at( const float eye[3], const float center[3], const float up[3], float out[16] );
+void orc_spin_model( float mv[16], float x, float y );
+void orc_perspective_frustum( float l, float r, float b, float t, float n, float f, float out[16] );
+void orc_make_view_data( const float mv[16], const float proj[16], const uint32_t viewport[4],
+                    const orc_volume_info* info, orc_view_data* out );
+
+/* ---- the integrator: cuda/Renderer.cu:95-230.  pixelBuffer is read-modify-write
+ * (multipass), W*H float4.  Returns the number of samples composited. */
+uint64_t orc_raycast( const uint8_t* atlas, const uint32_t atlasDim[3], float* pixelBuffer,
+                      uint32_t width, uint32_t height, const float* clipPlanes /* n*4 */,
+                      uint32_t nPlanes, const float* tf /* 256*4 */,
+                      const orc_view_data* view, uint32_t nodeCount,
+                      const orc_node_data* nodes, const orc_render_data* render,
+                      const orc_options* opt );
+
+/* one transfer-function fetch exactly as the integrator does it (cuda/ColorMap.cu:40-45) */
+void orc_tf_fetch( const float* tf, float u, int fracBits, float out[4] );
+/* one compositing step (cuda/Renderer.cu:83-93) */
+void orc_composite( const float src[4], float dst[4], float alphaCorrection );
+
+#ifdef __cplusplus
+}
+#endif
+#endif

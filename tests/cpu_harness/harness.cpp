@@ -1,0 +1,95 @@
+/*
+ * harness.cpp -- host build (g++) of the per-ray logic in libre_amd/csrc/vrc_core.h and the
+ * table builder in vrc_tables.h, for CPU-side unit tests (optionally under ASan/UBSan) in a
+ * container without a GPU.  TEST INFRASTRUCTURE ONLY: nothing in the product loads this; the
+ * product path is the gfx950 kernel in vrc_kernels.hip, which includes the same headers.
+ */
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../libre_amd/csrc/vrc_tables.h"
+
+extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3],
+                               const uint32_t slotDim[3], float* pixelBuffer, uint32_t W,
+                               uint32_t H, const float* planes, uint32_t nPlanes, const float* tf,
+                               const vrc_view_data* view, uint32_t nNodes,
+                               const vrc_node_data* nodes, const vrc_render_data* render,
+                               int fracBits, int kernel, int pixelOffX, int pixelOffY,
+                               uint64_t* samplesOut, int* gridOkOut )
+{
+    vrc_atlas_geom geom;
+    for( int a = 0; a < 3; ++a )
+    {
+        if( atlasDim[a] % 8u || slotDim[a] % 8u )
+            return 1;
+        geom.atlasDim[a] = atlasDim[a];
+        geom.slotDim[a] = slotDim[a];
+    }
+    geom.nbx = atlasDim[0] / 8u;
+    geom.nby = atlasDim[1] / 8u;
+
+    /* micro-blocked copy of the atlas, as the upload kernel lays it out */
+    std::vector< uint8_t > atlas( (size_t)atlasDim[0] * atlasDim[1] * atlasDim[2] );
+    for( uint32_t z = 0; z < atlasDim[2]; ++z )
+        for( uint32_t y = 0; y < atlasDim[1]; ++y )
+            for( uint32_t x = 0; x < atlasDim[0]; ++x )
+                atlas[vrc_swizzle( x, y, z, geom.nbx, geom.nby )] =
+                    atlasRowMajor[( (size_t)z * atlasDim[1] + y ) * atlasDim[0] + x];
+
+    vrc_lut_params lp;
+    lp.rangeMin = render->dataSourceRange[0];
+    lp.rangeMax = render->dataSourceRange[1];
+    lp.alphaCorrection = (float)render->maxSamplesPerRay / (float)render->samplesPerRay;
+    lp.fracBits = fracBits;
+    std::vector< vrc_f4 > lut( 256 );
+    for( uint32_t d = 0; d < 256; ++d )
+        lut[d] = vrc_lut_entry( tf, d, lp );
+
+    vrc_host_tables t;
+    vrc_build_tables( geom, nodes, nNodes, t );
+    if( gridOkOut )
+        *gridOkOut = t.gridOk ? 1 : 0;
+    float pl[6][4];
+    std::memset( pl, 0, sizeof( pl ) );
+    for( uint32_t i = 0; i < nPlanes && i < 6; ++i )
+        for( int k = 0; k < 4; ++k )
+            pl[i][k] = planes[i * 4 + k];
+    vrc_frame f;
+    std::memset( &f, 0, sizeof( f ) );
+    vrc_fill_frame( f, *view, *render, geom, t.g, pl, nPlanes, nNodes, W, H, (float)pixelOffX,
+                    (float)pixelOffY );
+
+    const bool dda = kernel == 2;
+    if( dda && !t.gridOk )
+        return 2;
+    uint64_t total = 0;
+    vrc_f4* pb = reinterpret_cast< vrc_f4* >( pixelBuffer );
+    for( uint32_t py = 0; py < H; ++py )
+        for( uint32_t px = 0; px < W; ++px )
+        {
+            uint32_t n = 0;
+            if( dda )
+            {
+                if( t.clamp )
+                    vrc_pixel_grid_dda< true, true, uint8_t >( f, t.nodes.data(), t.grid.data(),
+                                                               atlas.data(), lut.data(), pb, px, py, n );
+                else
+                    vrc_pixel_grid_dda< false, true, uint8_t >( f, t.nodes.data(), t.grid.data(),
+                                                                atlas.data(), lut.data(), pb, px, py, n );
+            }
+            else
+            {
+                if( t.clamp )
+                    vrc_pixel_reference_order< true, true, uint8_t >( f, t.nodes.data(), atlas.data(),
+                                                                      lut.data(), pb, px, py, n );
+                else
+                    vrc_pixel_reference_order< false, true, uint8_t >( f, t.nodes.data(), atlas.data(),
+                                                                       lut.data(), pb, px, py, n );
+            }
+            total += n;
+        }
+    if( samplesOut )
+        *samplesOut = total;
+    return 0;
+}

@@ -1,0 +1,386 @@
+"""ctypes binding of the CPU oracle (oracle/livre_oracle.c) + scene builders for the tests.
+
+TEST INFRASTRUCTURE.  Everything here goes through the oracle's restatement of the
+reference's host-side derivation (NodeId, LODNode, texture pool slots, texture objects,
+sorting, view data), so the parity tests feed the HIP path and the oracle the same inputs.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "liblivre_oracle.so")
+HARNESS_DIR = os.path.join(ROOT, "tests", "cpu_harness")
+HARNESS_SO = os.path.join(HARNESS_DIR, "libharness.so")
+
+u32x3 = C.c_uint32 * 3
+f32x3 = C.c_float * 3
+f32x16 = C.c_float * 16
+
+
+class NodeData(C.Structure):  # cuda/Renderer.cuh:35-41
+    _fields_ = [("textureMin", f32x3), ("textureSize", f32x3),
+                ("aabbMin", f32x3), ("aabbSize", f32x3)]
+
+
+class ViewData(C.Structure):  # cuda/Renderer.cuh:46-56
+    _fields_ = [("eyePosition", f32x3), ("glViewport", C.c_uint32 * 4),
+                ("invProjMatrix", f32x16), ("modelViewMatrix", f32x16),
+                ("invViewMatrix", f32x16), ("aabbMin", f32x3), ("aabbMax", f32x3),
+                ("nearPlane", C.c_float)]
+
+
+class RenderData(C.Structure):  # cuda/Renderer.cuh:59-66
+    _fields_ = [("samplesPerRay", C.c_uint32), ("samplesPerPixel", C.c_uint32),
+                ("maxSamplesPerRay", C.c_uint32), ("datatype", C.c_uint32),
+                ("dataSourceRange", C.c_float * 2)]
+
+
+class VolumeInfo(C.Structure):
+    _fields_ = [("voxels", u32x3), ("maximumBlockSize", u32x3), ("overlap", u32x3),
+                ("worldSize", f32x3), ("worldSpacePerVoxel", C.c_float),
+                ("depth", C.c_uint32), ("rootBlocks", u32x3)]
+
+
+class LODNode(C.Structure):
+    _fields_ = [("nodeId", C.c_uint64), ("blockSize", u32x3), ("voxelBoxMin", u32x3),
+                ("voxelBoxMax", u32x3), ("worldBoxMin", f32x3), ("worldBoxMax", f32x3)]
+
+
+class Options(C.Structure):
+    _fields_ = [("tfFracBits", C.c_int), ("filter", C.c_int), ("nThreads", C.c_int),
+                ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32), ("rowStride", C.c_uint32)]
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+    return ORACLE_SO
+
+
+def build_harness(sanitize=False):
+    out = HARNESS_SO if not sanitize else os.path.join(HARNESS_DIR, "libharness_asan.so")
+    src = os.path.join(HARNESS_DIR, "harness.cpp")
+    deps = [src] + [os.path.join(ROOT, "libre_amd", "csrc", f) for f in ("vrc_core.h", "vrc_tables.h")]
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-Wno-unknown-pragmas", "-o", out, src]
+    if sanitize:
+        cmd[1:1] = ["-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+    subprocess.check_call(cmd)
+    return out
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build_oracle())
+    L.orc_nodeid_pack.restype = C.c_uint64
+    L.orc_nodeid_pack.argtypes = [C.c_uint32] * 5
+    L.orc_nodeid_unpack.argtypes = [C.c_uint64, C.POINTER(C.c_uint32)]
+    L.orc_nodeid_parent.restype = C.c_uint64
+    L.orc_nodeid_parent.argtypes = [C.c_uint64]
+    L.orc_nodeid_children.argtypes = [C.c_uint64, C.POINTER(C.c_uint64)]
+    L.orc_fill_regular_volume_info.argtypes = [C.POINTER(VolumeInfo)]
+    L.orc_mem_volume_info.argtypes = [C.c_uint32] * 4 + [C.POINTER(VolumeInfo)]
+    L.orc_lod_node_from_id.argtypes = [C.POINTER(VolumeInfo), C.c_uint64, C.POINTER(LODNode)]
+    L.orc_mem_brick_value_u8.restype = C.c_uint8
+    L.orc_mem_brick_value_u8.argtypes = [C.c_uint64]
+    L.orc_mem_brick_fill_u8.argtypes = [C.POINTER(VolumeInfo), C.c_uint64, C.c_void_p]
+    L.orc_pool_slots.argtypes = [u32x3, C.c_size_t, C.c_size_t, u32x3, u32x3]
+    L.orc_pool_kth_slot.argtypes = [u32x3, C.c_uint32, f32x3]
+    L.orc_pool_slot_voxel_origin.argtypes = [u32x3, u32x3, f32x3, u32x3]
+    L.orc_pool_copy_to_slot_u8.argtypes = [C.c_void_p, u32x3, u32x3, C.c_void_p, u32x3]
+    L.orc_texture_object.argtypes = [C.POINTER(VolumeInfo), C.POINTER(LODNode), f32x3, u32x3,
+                                     f32x3, f32x3]
+    L.orc_node_distance.restype = C.c_float
+    L.orc_node_distance.argtypes = [f32x16, C.POINTER(LODNode)]
+    L.orc_sort_nodes_front_to_back.argtypes = [C.POINTER(VolumeInfo), f32x16,
+                                               C.POINTER(C.c_uint64), C.c_uint32]
+    L.orc_computed_samples_per_ray.restype = C.c_uint32
+    L.orc_computed_samples_per_ray.argtypes = [C.POINTER(VolumeInfo), C.POINTER(C.c_uint64),
+                                               C.c_uint32, C.c_uint32]
+    L.orc_mat4_identity.argtypes = [f32x16]
+    L.orc_mat4_mul.argtypes = [f32x16, f32x16, f32x16]
+    L.orc_mat4_inverse.restype = C.c_int
+    L.orc_mat4_inverse.argtypes = [f32x16, f32x16]
+    L.orc_look_at.argtypes = [f32x3, f32x3, f32x3, f32x16]
+    L.orc_spin_model.argtypes = [f32x16, C.c_float, C.c_float]
+    L.orc_perspective_frustum.argtypes = [C.c_float] * 6 + [f32x16]
+    L.orc_make_view_data.argtypes = [f32x16, f32x16, C.c_uint32 * 4, C.POINTER(VolumeInfo),
+                                     C.POINTER(ViewData)]
+    L.orc_raycast.restype = C.c_uint64
+    L.orc_raycast.argtypes = [C.c_void_p, u32x3, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                              C.c_uint32, C.c_void_p, C.POINTER(ViewData), C.c_uint32,
+                              C.POINTER(NodeData), C.POINTER(RenderData), C.POINTER(Options)]
+    L.orc_tf_fetch.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_float * 4]
+    L.orc_composite.argtypes = [C.c_float * 4, C.c_float * 4, C.c_float]
+    _lib = L
+    return L
+
+
+_harness = {}
+
+
+def harness(sanitize=False):
+    if sanitize in _harness:
+        return _harness[sanitize]
+    H = C.CDLL(build_harness(sanitize))
+    H.harness_render.restype = C.c_int
+    H.harness_render.argtypes = [C.c_void_p, u32x3, u32x3, C.c_void_p, C.c_uint32, C.c_uint32,
+                                 C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(ViewData),
+                                 C.c_uint32, C.POINTER(NodeData), C.POINTER(RenderData), C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64),
+                                 C.POINTER(C.c_int)]
+    _harness[sanitize] = H
+    return H
+
+
+# ---------------------------------------------------------------------------------------------
+def mat16(a):
+    return f32x16(*[float(v) for v in a])
+
+
+def pack(level, x, y, z, t=0):
+    return int(lib().orc_nodeid_pack(level, x, y, z, t))
+
+
+def unpack(i):
+    out = (C.c_uint32 * 5)()
+    lib().orc_nodeid_unpack(i, out)
+    return tuple(out)
+
+
+def mem_volume_info(vx, vy, vz, block):
+    vi = VolumeInfo()
+    lib().orc_mem_volume_info(vx, vy, vz, block, C.byref(vi))
+    return vi
+
+
+def lod_node(vi, node_id):
+    n = LODNode()
+    lib().orc_lod_node_from_id(C.byref(vi), node_id, C.byref(n))
+    return n
+
+
+def leaf_ids(vi):
+    """All NodeIds of the finest level (what --min-lod = --max-lod = depth-1 selects when the
+    whole volume is inside the frustum)."""
+    level = vi.depth - 1
+    dims = [vi.rootBlocks[a] << level for a in range(3)]
+    ids = []
+    for x in range(dims[0]):
+        for y in range(dims[1]):
+            for z in range(dims[2]):
+                ids.append(pack(level, x, y, z, 0))
+    return ids
+
+
+def linear_ramp_tf(alpha_scale=0.05):
+    """BASELINE.md TF: rgba[i] = (i/255, i/255, i/255, alpha*i/255)."""
+    i = np.arange(256, dtype=np.float32) / np.float32(255.0)
+    tf = np.stack([i, i, i, np.float32(alpha_scale) * i], axis=1).astype(np.float32)
+    return np.ascontiguousarray(tf)
+
+
+def default_proj():
+    """near 0.1, far 15, l/r/b/t = -/+0.05 (livre/eq/Channel.cpp:61-62 +
+    tests/lib/lodSelection.cpp:38-41)."""
+    m = f32x16()
+    lib().orc_perspective_frustum(-0.05, 0.05, -0.05, 0.05, 0.1, 15.0, m)
+    return m
+
+
+def tile_proj(x0, y0, w, h, W, H):
+    """Off-axis sub-frustum of pixel tile (x0,y0,w,h) of a W x H frame (the per-channel
+    frustum Equalizer hands to livre/eq/Channel.cpp:151-157)."""
+    l, r, b, t = -0.05, 0.05, -0.05, 0.05
+    tl = l + (r - l) * x0 / W
+    tr = l + (r - l) * (x0 + w) / W
+    tb = b + (t - b) * y0 / H
+    tt = b + (t - b) * (y0 + h) / H
+    m = f32x16()
+    lib().orc_perspective_frustum(tl, tr, tb, tt, 0.1, 15.0, m)
+    return m
+
+
+def default_mv(spin=(0.0, 0.0), eye=(0.0, 0.0, 1.5)):
+    """lookAt(eye (0,0,1.5) -> origin, up +y) (ApplicationParameters.cpp:54-55), optionally
+    spun (CameraSettings.cpp:35-59)."""
+    m = f32x16()
+    lib().orc_look_at(f32x3(*eye), f32x3(0, 0, 0), f32x3(0, 1, 0), m)
+    if spin[0] != 0.0 or spin[1] != 0.0:
+        lib().orc_spin_model(m, spin[0], spin[1])
+    return m
+
+
+def hash_volume(vx, vy, vz, seed=0x5EED):
+    """'Volume N' of SURVEY 8d: v = hash32(x + vx*(y + vy*z) + seed) >> 24, then a 3-tap box
+    filter per axis.  Deterministic, build-defined (not a reference input)."""
+    idx = np.arange(vx * vy * vz, dtype=np.uint64).reshape(vz, vy, vx)
+    h = (idx + np.uint64(seed)) & np.uint64(0xFFFFFFFF)
+    h = h.astype(np.uint32)
+    h ^= h >> np.uint32(16)
+    h *= np.uint32(0x7FEB352D)
+    h ^= h >> np.uint32(15)
+    h *= np.uint32(0x846CA68B)
+    h ^= h >> np.uint32(16)
+    v = (h >> np.uint32(24)).astype(np.float32)
+    for ax in range(3):
+        v = (np.roll(v, 1, axis=ax) + v + np.roll(v, -1, axis=ax)) / 3.0
+    return np.clip(np.floor(v), 0, 255).astype(np.uint8)
+
+
+def brick_from_volume(vol, vi, node):
+    """Cut brick + overlap out of a full-resolution volume (z,y,x order), clamping at the
+    volume border (what a bricking data source does)."""
+    ov = [vi.overlap[a] for a in range(3)]
+    lo = [int(node.voxelBoxMin[a]) - ov[a] for a in range(3)]
+    hi = [int(node.voxelBoxMax[a]) + ov[a] for a in range(3)]
+    ix = [np.clip(np.arange(lo[a], hi[a]), 0, vol.shape[2 - a] - 1) for a in range(3)]
+    return np.ascontiguousarray(vol[np.ix_(ix[2], ix[1], ix[0])])
+
+
+class Scene:
+    pass
+
+
+def build_scene(voxels=(64, 64, 64), block=16, viewport=(64, 64), spr=0, alpha=0.05,
+                spin=(0.0, 0.0), volume="mem", max_slots=None, planes=None, ids=None,
+                tile=None, eye=(0.0, 0.0, 1.5), max_tex3d=4096, pad8=True):
+    """Everything the integrator needs, derived through the oracle's restatement of the
+    reference host code.  `pad8`: slot = maxBlock rounded up to 8 (the HIP atlas layout)."""
+    L = lib()
+    s = Scene()
+    vi = mem_volume_info(voxels[0], voxels[1], voxels[2], block)
+    s.vi = vi
+    s.ids = list(ids) if ids is not None else leaf_ids(vi)
+    n = len(s.ids)
+
+    mb = [vi.maximumBlockSize[a] for a in range(3)]
+    slot_dim = [(m + 7) // 8 * 8 for m in mb] if pad8 else mb
+    s.slot_dim = slot_dim
+    slot_bytes = slot_dim[0] * slot_dim[1] * slot_dim[2]
+    want = max_slots if max_slots is not None else n
+    # smallest budget whose slot grid (TexturePool.cu:128-135) holds `want` bricks
+    slots = u32x3()
+    blocks = want
+    while True:
+        L.orc_pool_slots(u32x3(*slot_dim), slot_bytes, blocks * slot_bytes,
+                         u32x3(max_tex3d, max_tex3d, max_tex3d), slots)
+        if slots[0] * slots[1] * slots[2] >= want:
+            break
+        blocks += 1
+    s.pool_bytes = blocks * slot_bytes
+    s.slots = [slots[a] for a in range(3)]
+    s.atlas_dim = [s.slots[a] * slot_dim[a] for a in range(3)]
+    s.atlas = np.zeros((s.atlas_dim[2], s.atlas_dim[1], s.atlas_dim[0]), dtype=np.uint8)
+
+    vol = None
+    if volume == "hash":
+        vol = hash_volume(*voxels)
+    s.bricks = {}
+    s.slot_of = {}
+    s.lod = {}
+    size = u32x3(*mb)
+    for k, nid in enumerate(s.ids):
+        node = lod_node(vi, nid)
+        s.lod[nid] = node
+        if vol is None:
+            brick = np.full((mb[2], mb[1], mb[0]), L.orc_mem_brick_value_u8(nid), dtype=np.uint8)
+        else:
+            brick = brick_from_volume(vol, vi, node)
+        s.bricks[nid] = brick
+        slot = f32x3()
+        L.orc_pool_kth_slot(slots, k, slot)
+        origin = u32x3()
+        L.orc_pool_slot_voxel_origin(slots, u32x3(*slot_dim), slot, origin)
+        L.orc_pool_copy_to_slot_u8(s.atlas.ctypes.data, u32x3(*s.atlas_dim), origin,
+                                   brick.ctypes.data, size)
+        s.slot_of[nid] = (slot[0], slot[1], slot[2])
+
+    W, H = viewport
+    s.W, s.H = W, H
+    s.mv = default_mv(spin, eye)
+    if tile is None:
+        s.proj = default_proj()
+        vp = (C.c_uint32 * 4)(0, 0, W, H)
+    else:
+        x0, y0, w, h, FW, FH = tile
+        s.proj = tile_proj(x0, y0, w, h, FW, FH)
+        vp = (C.c_uint32 * 4)(0, 0, w, h)
+        s.W, s.H = w, h
+    s.view = ViewData()
+    L.orc_make_view_data(s.mv, s.proj, vp, C.byref(vi), C.byref(s.view))
+
+    ids_arr = (C.c_uint64 * n)(*s.ids)
+    L.orc_sort_nodes_front_to_back(C.byref(vi), s.mv, ids_arr, n)
+    s.sorted_ids = list(ids_arr)
+    s.nodes = (NodeData * n)()
+    for k, nid in enumerate(s.sorted_ids):
+        node = s.lod[nid]
+        tp, ts = f32x3(), f32x3()
+        L.orc_texture_object(C.byref(vi), C.byref(node), f32x3(*s.slot_of[nid]),
+                             u32x3(*s.atlas_dim), tp, ts)
+        nd = s.nodes[k]
+        for a in range(3):
+            nd.textureMin[a] = tp[a]
+            nd.textureSize[a] = ts[a]
+            nd.aabbMin[a] = node.worldBoxMin[a]
+            nd.aabbSize[a] = node.worldBoxMax[a] - node.worldBoxMin[a]
+    s.n_nodes = n
+    spr_eff = L.orc_computed_samples_per_ray(C.byref(vi), ids_arr, n, spr)
+    s.render = RenderData(spr_eff, 1, 32, 0, (C.c_float * 2)(0.0, 255.0))
+    s.tf = linear_ramp_tf(alpha)
+    if planes is None:
+        s.planes = np.zeros((0, 4), dtype=np.float32)
+    else:
+        s.planes = np.ascontiguousarray(np.asarray(planes, dtype=np.float32).reshape(-1, 4))
+    return s
+
+
+def oracle_render(s, frac_bits=8, threads=8, rows=None, fb=None, filter_mode=0):
+    """Run the oracle integrator on a scene. Returns (rgba[H,W,4], samples)."""
+    L = lib()
+    if fb is None:
+        fb = np.zeros((s.H, s.W, 4), dtype=np.float32)
+    opt = Options(frac_bits, filter_mode, threads, 0, s.H, 1)
+    if rows is not None:
+        opt.rowBegin, opt.rowEnd, opt.rowStride = rows
+    n = L.orc_raycast(s.atlas.ctypes.data, u32x3(*s.atlas_dim), fb.ctypes.data, s.W, s.H,
+                      s.planes.ctypes.data if len(s.planes) else None, len(s.planes),
+                      s.tf.ctypes.data, C.byref(s.view), s.n_nodes, s.nodes, C.byref(s.render),
+                      C.byref(opt))
+    return fb, int(n)
+
+
+def harness_render(s, kernel=2, frac_bits=8, fb=None, sanitize=False, pixel_off=(0, 0)):
+    """Run the host build of the HIP kernel's per-ray code (vrc_core.h)."""
+    H = harness(sanitize)
+    if fb is None:
+        fb = np.zeros((s.H, s.W, 4), dtype=np.float32)
+    samples = C.c_uint64(0)
+    grid_ok = C.c_int(0)
+    rc = H.harness_render(s.atlas.ctypes.data, u32x3(*s.atlas_dim), u32x3(*s.slot_dim),
+                          fb.ctypes.data, s.W, s.H,
+                          s.planes.ctypes.data if len(s.planes) else None, len(s.planes),
+                          s.tf.ctypes.data, C.byref(s.view), s.n_nodes, s.nodes,
+                          C.byref(s.render), frac_bits, kernel, pixel_off[0], pixel_off[1],
+                          C.byref(samples), C.byref(grid_ok))
+    if rc != 0:
+        raise RuntimeError("harness_render failed: %d" % rc)
+    return fb, int(samples.value), bool(grid_ok.value)
+
+
+def compare(a, b):
+    """(max-abs, mean-abs, fraction of pixels with any channel over 2e-3)."""
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    over = (d.max(axis=-1) > 2e-3).mean()
+    return float(d.max()), float(d.mean()), float(over)

@@ -1,0 +1,62 @@
+"""The C-ABI library builds for gfx950, loads, and exports every symbol include/vrc_hip.h
+declares.  No compute call is made (no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vrc_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    from libre_amd import vrc
+    L = vrc.load_library()
+    declared = _declared("vrc_hip.h")
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(L, name), "libvrc_hip.so does not export %s" % name
+    assert sorted(vrc.EXPORTS) == declared
+    assert L.vrc_abi_version() == 1
+
+
+def test_library_is_gfx950_code_object(built):
+    from libre_amd import vrc
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o",
+                          "--input=" + vrc.LIB_PATH], capture_output=True, text=True)
+    blob = open(vrc.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"vrc_k_raycast" in blob
+    del out
+
+
+def test_pod_layouts_match_reference_shapes(built):
+    from libre_amd import vrc
+    # cuda/Renderer.cuh:35-66: NodeData = 12 floats; RenderData = 4 uint + 2 float
+    assert C.sizeof(vrc.NodeData) == 48
+    assert C.sizeof(vrc.RenderData) == 24
+    assert C.sizeof(vrc.ViewData) == (3 + 4 + 16 * 3 + 3 + 3 + 1) * 4
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from libre_amd import vrc
+    with pytest.raises(FileNotFoundError):
+        vrc.load_library(str(tmp_path / "nope.so"))
+
+
+def test_no_oracle_in_product_tree():
+    # the product never references the oracle or the CPU harness
+    for d in ("libre_amd", "include"):
+        for root, _, files in os.walk(os.path.join(ROOT, d)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                    txt = open(os.path.join(root, f), errors="replace").read()
+                    assert "livre_oracle" not in txt and "orc_raycast" not in txt, os.path.join(root, f)
+                    assert "libharness" not in txt, os.path.join(root, f)

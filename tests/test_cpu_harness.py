@@ -1,0 +1,156 @@
+"""CPU-side checks of the HIP kernel's per-ray code (libre_amd/csrc/vrc_core.h +
+vrc_tables.h compiled by g++ in tests/cpu_harness) against the oracle.  No GPU needed; the
+same headers are what hipcc compiles into the gfx950 kernel."""
+import numpy as np
+import pytest
+
+import orc
+import scenes
+
+
+@pytest.mark.parametrize("name", sorted(scenes.SCENES))
+def test_reference_order_matches_oracle(name):
+    s = scenes.get(name)
+    want, n_want = orc.oracle_render(s, threads=4)
+    got, n_got, _ = orc.harness_render(s, kernel=1)
+    scenes.assert_parity(got, want, name)
+    # same bricks, same per-brick loop: the sample count is identical
+    assert n_got == n_want
+
+
+@pytest.mark.parametrize("name", sorted(scenes.SCENES))
+def test_grid_dda_matches_oracle(name):
+    s = scenes.get(name)
+    want, n_want = orc.oracle_render(s, threads=4)
+    got, n_got, grid_ok = orc.harness_render(s, kernel=2)
+    assert grid_ok
+    scenes.assert_parity(got, want, name)
+    # the DDA may step over brick slivers: at most one sample per such crossing
+    assert abs(n_got - n_want) <= 2e-4 * n_want + 8
+
+
+def test_reference_order_is_bit_exact_on_constant_bricks():
+    # with constant bricks voxel flips cannot matter and there is no FMA on the host build:
+    # the restructured arithmetic (hoisted 1/dir, classified table) is bit-identical
+    s = scenes.get("mem64_spin")
+    want, _ = orc.oracle_render(s, threads=4)
+    got, _, _ = orc.harness_render(s, kernel=1)
+    assert (got == want).all()
+
+
+def test_exact_tf_weights_option():
+    s = scenes.get("hash64_spin")
+    want, _ = orc.oracle_render(s, threads=4, frac_bits=0)
+    got, _, _ = orc.harness_render(s, kernel=2, frac_bits=0)
+    scenes.assert_parity(got, want)
+
+
+def test_nucleon_single_brick_overlap0():
+    s = scenes.nucleon_scene()
+    want, n_want = orc.oracle_render(s, threads=4)
+    assert want[..., 3].max() > 0.05
+    for k in (1, 2):
+        got, n_got, _ = orc.harness_render(s, kernel=k)
+        scenes.assert_parity(got, want, "nucleon k%d" % k)
+        assert n_got == n_want
+
+
+def test_multipass_accumulates():
+    # CudaRaycastPipeline.cpp:149-185: passes of front-to-back node ranges accumulate through
+    # the persistent pixel buffer (Renderer.cu:151-157, 229)
+    s = scenes.get("hash64_spin")
+    want, _ = orc.oracle_render(s, threads=4)
+    half = s.n_nodes // 2
+    fb = np.zeros((s.H, s.W, 4), dtype=np.float32)
+    full_nodes, n = s.nodes, s.n_nodes
+    try:
+        s.nodes = (orc.NodeData * half)(*full_nodes[:half])
+        s.n_nodes = half
+        fb, _, _ = orc.harness_render(s, kernel=2, fb=fb)
+        s.nodes = (orc.NodeData * (n - half))(*full_nodes[half:])
+        s.n_nodes = n - half
+        fb, _, _ = orc.harness_render(s, kernel=2, fb=fb)
+    finally:
+        s.nodes, s.n_nodes = full_nodes, n
+    scenes.assert_parity(fb, want, "multipass")
+
+
+def test_partial_node_set_uses_grid_with_holes():
+    # async mode renders whatever is resident: drop a third of the bricks
+    s = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(40, 40), volume="hash", spin=(0.5, 0.35))
+    keep = [nid for i, nid in enumerate(s.ids) if i % 3 != 0]
+    s2 = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(40, 40), volume="hash",
+                         spin=(0.5, 0.35), ids=keep)
+    want, n_want = orc.oracle_render(s2, threads=4)
+    got, n_got, grid_ok = orc.harness_render(s2, kernel=2)
+    assert grid_ok
+    scenes.assert_parity(got, want, "holes")
+
+
+def test_mixed_lod_node_set():
+    # a coarse brick next to fine bricks (the LOD cut mixes levels): the grid is built at the
+    # finest cell size and a coarse node covers 2x2x2 cells
+    vi = orc.mem_volume_info(64, 64, 64, 16)
+    assert vi.depth == 3
+    coarse = orc.pack(1, 0, 0, 0)
+    fine = [i for i in orc.leaf_ids(vi) if orc.lib().orc_nodeid_parent(i) != coarse]
+    ids = [coarse] + fine
+    s = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(40, 40), spin=(0.4, 0.3), ids=ids)
+    want, _ = orc.oracle_render(s, threads=4)
+    ref, _, _ = orc.harness_render(s, kernel=1)
+    scenes.assert_parity(ref, want, "mixed ref-order")
+    got, _, grid_ok = orc.harness_render(s, kernel=2)
+    assert grid_ok
+    scenes.assert_parity(got, want, "mixed dda")
+
+
+def test_sort_first_tile_equals_crop():
+    # a tile rendered with the pixel offset + full-frame matrices equals the crop
+    # of the full frame, bit for bit (same ray arithmetic)
+    s = scenes.get("hash64_spin")
+    full, _, _ = orc.harness_render(s, kernel=2)
+    x0, y0, w, h = 8, 16, 24, 32
+    W, H = s.W, s.H
+    try:
+        s.W, s.H = w, h
+        tile, _, _ = orc.harness_render(s, kernel=2, pixel_off=(x0, y0))
+    finally:
+        s.W, s.H = W, H
+    # the viewport in ViewData stays the full frame; only the buffer is the tile
+    assert (tile == full[y0:y0 + h, x0:x0 + w]).all()
+
+
+def test_sort_first_tile_with_subfrustum_matches_oracle():
+    # the Equalizer way (livre/eq/Channel.cpp:151-157): origin-0 viewport + off-axis frustum
+    kw = dict(scenes.SCENES["hash64_spin"])
+    kw["viewport"] = (48, 48)
+    full = orc.build_scene(**kw)
+    want_full, _ = orc.oracle_render(full, threads=4)
+    t = orc.build_scene(tile=(12, 24, 24, 12, 48, 48), **kw)
+    want, _ = orc.oracle_render(t, threads=4)
+    got, _, _ = orc.harness_render(t, kernel=2)
+    scenes.assert_parity(got, want, "tile")
+    # and the sub-frustum tile is the crop of the full frame up to float rounding of the matrices
+    mx, mean, _ = orc.compare(want, want_full[24:36, 12:36])
+    assert mx < 5e-3 and mean < 1e-4
+
+
+def test_sanitized_build_runs_clean():
+    # ASan + UBSan on the host build of the per-ray code (the GPU pool cannot run sanitizers)
+    s = scenes.get("hash_clip")
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import orc, scenes
+        s = scenes.get("hash_clip")
+        a, n, _ = orc.harness_render(s, kernel=2, sanitize=True)
+        b, m, _ = orc.harness_render(s, kernel=1, sanitize=True)
+        s = scenes.nucleon_scene(viewport=(24, 24))
+        orc.harness_render(s, kernel=2, sanitize=True)
+        print("OK", n, m)
+    """ % os.path.dirname(os.path.abspath(__file__)))
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr

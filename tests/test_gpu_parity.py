@@ -1,0 +1,235 @@
+"""Parity tests proper: the gfx950 path driven through the C ABI (ctypes) against the CPU
+oracle and the committed golden frames.  Run on the GPU box with `pytest -m gpu`."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frames.npz")
+
+
+@pytest.fixture(scope="module")
+def vrc():
+    from libre_amd import vrc as v
+    v.load_library()  # fails loudly when the HIP extension is missing
+    return v
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLDEN)
+
+
+def _gpu(s):
+    from gpu_run import GpuScene
+    return GpuScene(s)
+
+
+def test_oracle_still_matches_golden(golden):
+    for name in sorted(scenes.SCENES):
+        fb, n = orc.oracle_render(scenes.get(name), threads=8)
+        assert n == int(golden[name + "__samples"][0])
+        assert np.allclose(fb, golden[name], atol=1e-6), name
+
+
+def test_atlas_layout_roundtrip(vrc):
+    # upload through the micro-block repack, read back logical regions: bit-exact
+    s = scenes.get("hash64_spin")
+    with _gpu(s) as g:
+        info = g.info()
+        assert info["atlas_dim"] == s.atlas_dim and info["slots"] == s.slots
+        for nid in s.ids:
+            assert g.slots[nid] == s.slot_of[nid]
+        out = np.zeros_like(s.atlas)
+        vrc.check(g.L, g.L.vrc_pool_read_region(g.pool, vrc.u32x3(0, 0, 0), vrc.u32x3(*s.atlas_dim),
+                                                out.ctypes.data))
+        assert (out == s.atlas).all()
+        # a ragged sub-region that straddles micro-blocks and slots
+        o, sz = (13, 5, 3), (29, 17, 11)
+        sub = np.zeros((sz[2], sz[1], sz[0]), dtype=np.uint8)
+        vrc.check(g.L, g.L.vrc_pool_read_region(g.pool, vrc.u32x3(*o), vrc.u32x3(*sz), sub.ctypes.data))
+        assert (sub == s.atlas[o[2]:o[2] + sz[2], o[1]:o[1] + sz[1], o[0]:o[0] + sz[0]]).all()
+
+
+@pytest.mark.parametrize("name", sorted(scenes.SCENES))
+def test_scene_parity_both_kernels(vrc, golden, name):
+    s = scenes.get(name)
+    want, n_want = orc.oracle_render(s, threads=8)
+    with _gpu(s) as g:
+        ref, n_ref, st = g.render(kernel=vrc.KERNEL_REFERENCE_ORDER)
+        assert st.kernel_variant == vrc.KERNEL_REFERENCE_ORDER
+        scenes.assert_parity(ref, want, name + " ref-order vs oracle")
+        scenes.assert_parity(ref, golden[name], name + " ref-order vs golden")
+        assert abs(n_ref - n_want) <= 1e-4 * n_want + 8
+        dda, n_dda, st = g.render(kernel=vrc.KERNEL_GRID_DDA)
+        assert st.kernel_variant == vrc.KERNEL_GRID_DDA
+        scenes.assert_parity(dda, want, name + " dda vs oracle")
+        assert abs(n_dda - n_want) <= 2e-4 * n_want + 8
+        auto, _, st = g.render(kernel=vrc.KERNEL_AUTO, count=False)
+        assert st.kernel_variant == vrc.KERNEL_GRID_DDA
+        # counting samples must not change a single bit of the frame
+        assert (auto == dda).all()
+        # idempotence: same inputs, same bits
+        again, _, _ = g.render(kernel=vrc.KERNEL_GRID_DDA)
+        assert (again == dda).all()
+
+
+def test_c1_config_parity(vrc):
+    # mem://#128,128,128,32, 512^2 viewport, 512 samples/ray, 64 leaf bricks
+    s = orc.build_scene(voxels=(128, 128, 128), block=32, viewport=(512, 512))
+    assert s.n_nodes == 64 and s.render.samplesPerRay == 512
+    want, n_want = orc.oracle_render(s, threads=16)
+    with _gpu(s) as g:
+        got, n_got, st = g.render()
+        assert st.kernel_variant == vrc.KERNEL_GRID_DDA and list(st.grid_dims) == [4, 4, 4]
+    scenes.assert_parity(got, want, "C1")
+    assert abs(n_got - n_want) <= 2e-4 * n_want
+    assert 6.0e7 < n_want < 8.0e7  # SURVEY 8d estimate: ~7.0e7 samples/frame
+
+
+def test_nucleon_raw_single_brick(vrc, golden):
+    s = scenes.nucleon_scene()
+    want, n_want = orc.oracle_render(s, threads=8)
+    with _gpu(s) as g:
+        for k in (vrc.KERNEL_REFERENCE_ORDER, vrc.KERNEL_GRID_DDA):
+            got, n_got, _ = g.render(kernel=k)
+            scenes.assert_parity(got, want, "nucleon")
+            scenes.assert_parity(got, golden["nucleon"], "nucleon golden")
+            assert n_got == n_want
+
+
+def test_multipass_equals_single_pass(vrc):
+    s = scenes.get("hash64_spin")
+    with _gpu(s) as g:
+        one, n1, _ = g.render()
+        h = s.n_nodes // 3
+        many, n3, _ = g.render(passes=[(0, h), (h, 2 * h), (2 * h, s.n_nodes)])
+    want, _ = orc.oracle_render(s, threads=8)
+    scenes.assert_parity(many, want, "multipass")
+    scenes.assert_parity(many, one, "multipass vs single")
+
+
+def test_early_ray_termination(vrc):
+    s = scenes.get("hash64_ert")
+    want, n_want = orc.oracle_render(s, threads=8)
+    assert (want[..., 3] > 0.999).mean() > 0.3  # most rays terminate early
+    with _gpu(s) as g:
+        got, n_got, _ = g.render()
+    scenes.assert_parity(got, want, "ert")
+    assert abs(n_got - n_want) <= 1e-3 * n_want
+    # no ray composites past the threshold by more than one sample's alpha
+    assert got[..., 3].max() <= 1.0
+
+
+def test_sort_first_tile_is_crop_of_full_frame(vrc):
+    # Equalizer-style tile: origin-0 viewport + off-axis frustum (livre/eq/Channel.cpp:151-157)
+    kw = dict(scenes.SCENES["hash64_spin"])
+    kw["viewport"] = (48, 48)
+    fulls = orc.build_scene(**kw)
+    t = orc.build_scene(tile=(12, 24, 24, 12, 48, 48), **kw)
+    with _gpu(fulls) as g:
+        full, _, _ = g.render()
+    with _gpu(t) as g:
+        tile, _, _ = g.render()
+    want, _ = orc.oracle_render(t, threads=8)
+    scenes.assert_parity(tile, want, "tile vs oracle")
+    mx, mean, _ = orc.compare(tile, full[24:36, 12:36])
+    assert mx < 5e-3 and mean < 1e-4
+
+
+def test_pool_exhaustion_and_slot_reuse(vrc):
+    L = vrc.load_library()
+    ctx = C.c_void_p()
+    vrc.check(L, L.vrc_ctx_create(0, C.byref(ctx)))
+    pool = C.c_void_p()
+    mb = vrc.u32x3(24, 24, 24)
+    vrc.check(L, L.vrc_pool_create(ctx, 1, 0, 0, 1, mb, 3 * 24 ** 3, C.byref(pool)))
+    brick = np.arange(24 ** 3, dtype=np.uint32).astype(np.uint8)
+    slots = []
+    for _ in range(3):
+        slot = vrc.f32x3()
+        vrc.check(L, L.vrc_pool_copy_to_slot(pool, brick.ctypes.data, mb, slot))
+        slots.append(tuple(slot))
+    assert len(set(slots)) == 3
+    slot = vrc.f32x3()
+    rc = L.vrc_pool_copy_to_slot(pool, brick.ctypes.data, mb, slot)
+    assert rc == vrc.VRC_EFULL and tuple(slot) == (-1.0, -1.0, -1.0)  # TexturePool.cu:180-181
+    vrc.check(L, L.vrc_pool_release_slot(pool, vrc.f32x3(*slots[1])))
+    vrc.check(L, L.vrc_pool_copy_to_slot(pool, brick.ctypes.data, mb, slot))
+    assert tuple(slot) == slots[1]
+    # brick larger than a slot is refused
+    assert L.vrc_pool_copy_to_slot(pool, brick.ctypes.data, vrc.u32x3(25, 24, 24), slot) == vrc.VRC_EINVAL
+    L.vrc_pool_destroy(pool)
+    # unsupported formats are reported, not mis-rendered (quirk Q2)
+    assert L.vrc_pool_create(ctx, 2, 0, 0, 1, mb, 1 << 20, C.byref(pool)) == vrc.VRC_EUNSUPPORTED
+    assert L.vrc_pool_create(ctx, 1, 0, 0, 5, mb, 1 << 20, C.byref(pool)) == vrc.VRC_EUNSUPPORTED
+    assert b"Channel number" in L.vrc_last_error()
+    L.vrc_ctx_destroy(ctx)
+
+
+def test_error_paths(vrc):
+    L = vrc.load_library()
+    ctx = C.c_void_p()
+    assert L.vrc_ctx_create(99, C.byref(ctx)) == vrc.VRC_EINVAL
+    vrc.check(L, L.vrc_ctx_create(0, C.byref(ctx)))
+    s = scenes.get("mem64_axis")
+    view = C.cast(C.byref(s.view), C.POINTER(vrc.ViewData))
+    render = C.cast(C.byref(s.render), C.POINTER(vrc.RenderData))
+    nodes = C.cast(s.nodes, C.POINTER(vrc.NodeData))
+    pool = C.c_void_p()
+    vrc.check(L, L.vrc_pool_create(ctx, 1, 0, 0, 1, vrc.u32x3(24, 24, 24), 1 << 20, C.byref(pool)))
+    # render before pre_render
+    assert L.vrc_render(ctx, view, nodes, s.n_nodes, render, pool) == vrc.VRC_EINVAL
+    assert L.vrc_update(ctx, None, None, 7) == vrc.VRC_EINVAL
+    assert L.vrc_set_option(ctx, vrc.OPT_FILTER, 1) == vrc.VRC_EUNSUPPORTED
+    assert L.vrc_set_option(ctx, 999, 1) == vrc.VRC_EINVAL
+    vrc.check(L, L.vrc_pre_render(ctx, view))
+    # empty node list renders nothing (CudaRaycastRenderer.cpp:157-158)
+    vrc.check(L, L.vrc_render(ctx, view, None, 0, render, pool))
+    fb = np.ones((s.H, s.W, 4), dtype=np.float32)
+    vrc.check(L, L.vrc_post_render(ctx, fb.ctypes.data))
+    assert (fb == 0).all()  # cleared by pre_render (PixelBufferObject.cu:80)
+    L.vrc_pool_destroy(pool)
+    L.vrc_ctx_destroy(ctx)
+
+
+def test_concurrent_uploads_are_thread_safe(vrc):
+    # the reference calls copyToSlot from 3 threads (CudaRaycastPipeline.cpp:60-63)
+    import threading
+    s = scenes.get("hash64_spin")
+    L = vrc.load_library()
+    ctx = C.c_void_p()
+    vrc.check(L, L.vrc_ctx_create(0, C.byref(ctx)))
+    pool = C.c_void_p()
+    mb = vrc.u32x3(24, 24, 24)
+    vrc.check(L, L.vrc_pool_create(ctx, 1, 0, 0, 1, mb, s.pool_bytes, C.byref(pool)))
+    got = {}
+    lock = threading.Lock()
+
+    def work(ids):
+        for nid in ids:
+            slot = vrc.f32x3()
+            rc = L.vrc_pool_copy_to_slot(pool, s.bricks[nid].ctypes.data, mb, slot)
+            with lock:
+                got[nid] = (rc, tuple(slot))
+
+    ths = [threading.Thread(target=work, args=(s.ids[i::3],)) for i in range(3)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert all(rc == 0 for rc, _ in got.values())
+    assert len({sl for _, sl in got.values()}) == len(s.ids)
+    vrc.check(L, L.vrc_pool_synchronize(pool))
+    for nid in s.ids:  # every brick landed intact in its slot
+        sl = got[nid][1]
+        o = [int(round(sl[a] * s.atlas_dim[a])) for a in range(3)]
+        out = np.zeros((24, 24, 24), dtype=np.uint8)
+        vrc.check(L, L.vrc_pool_read_region(pool, vrc.u32x3(*o), mb, out.ctypes.data))
+        assert (out == s.bricks[nid]).all()
+    L.vrc_pool_destroy(pool)
+    L.vrc_ctx_destroy(ctx)
