@@ -22,6 +22,19 @@
 #define VRC_HD inline
 #endif
 
+/* Ray and brick-segment set-up is evaluated without FMA contraction, operation for operation
+ * as the oracle does: the first sample of every brick segment lies exactly on a brick face
+ * (= a voxel face), so one ulp in rayStart decides which of two voxels it reads.  The
+ * per-sample loop keeps contraction (it is the hot path). */
+#if defined( __clang__ )
+#pragma clang fp contract( off ) /* file scope: everything below unless re-enabled */
+#define VRC_STRICT_FP _Pragma( "clang fp contract(off)" )
+#define VRC_FAST_FP _Pragma( "clang fp contract(fast)" )
+#else
+#define VRC_STRICT_FP
+#define VRC_FAST_FP
+#endif
+
 #define VRC_EARLY_EXIT 0.999f     /* Renderer.cu:34 */
 #define VRC_EPSILON 0.0000000001f /* Renderer.cu:35 */
 
@@ -133,6 +146,7 @@ VRC_HD vrc_f4 vrc_lut_entry( const float* tf, uint32_t d, vrc_lut_params p )
 /* cuda/math.cuh:1457-1464 (column-major 4x4 times vec4) */
 VRC_HD vrc_f4 vrc_mul44( const float* m, vrc_f4 v )
 {
+    VRC_STRICT_FP
     vrc_f4 r;
     r.x = m[0] * v.x + m[4] * v.y + m[8] * v.z + m[12] * v.w;
     r.y = m[1] * v.x + m[5] * v.y + m[9] * v.z + m[13] * v.w;
@@ -141,11 +155,16 @@ VRC_HD vrc_f4 vrc_mul44( const float* m, vrc_f4 v )
     return r;
 }
 
-VRC_HD float vrc_dot( vrc_f3 a, vrc_f3 b ) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+VRC_HD float vrc_dot( vrc_f3 a, vrc_f3 b )
+{
+    VRC_STRICT_FP
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
 
 /* cuda/math.cuh:1310-1314 */
 VRC_HD vrc_f3 vrc_normalize( vrc_f3 v )
 {
+    VRC_STRICT_FP
     const float invLen = 1.0f / sqrtf( vrc_dot( v, v ) );
     vrc_f3 r = { v.x * invLen, v.y * invLen, v.z * invLen };
     return r;
@@ -155,6 +174,7 @@ VRC_HD vrc_f3 vrc_normalize( vrc_f3 v )
 VRC_HD bool vrc_intersect_box( vrc_f3 origin, vrc_f3 invR, vrc_f3 boxMin, vrc_f3 boxMax,
                                float* tnear, float* tfar )
 {
+    VRC_STRICT_FP
     const float tbx = invR.x * ( boxMin.x - origin.x ), ttx = invR.x * ( boxMax.x - origin.x );
     const float tby = invR.y * ( boxMin.y - origin.y ), tty = invR.y * ( boxMax.y - origin.y );
     const float tbz = invR.z * ( boxMin.z - origin.z ), ttz = invR.z * ( boxMax.z - origin.z );
@@ -178,6 +198,7 @@ struct vrc_ray
 /* Renderer.cu:106-149 + :159-160: pixel -> world ray, global box, clip planes, near plane */
 VRC_HD vrc_ray vrc_setup_ray( const vrc_frame& f, uint32_t px, uint32_t py )
 {
+    VRC_STRICT_FP
     vrc_ray r;
     /* Renderer.cu:40-51 */
     const float wx = (float)px + f.pixelOffX, wy = (float)py + f.pixelOffY;
@@ -238,6 +259,7 @@ struct vrc_segment
 VRC_HD bool vrc_brick_segment( const vrc_ray& r, const vrc_dev_node& n, float stepSize,
                                vrc_segment* s, bool* stop )
 {
+    VRC_STRICT_FP
     const vrc_f3 boxMin = { n.aabbMin[0], n.aabbMin[1], n.aabbMin[2] };
     const vrc_f3 boxMax = { boxMin.x + n.aabbSize[0], boxMin.y + n.aabbSize[1],
                             boxMin.z + n.aabbSize[2] };
@@ -281,6 +303,7 @@ VRC_HD bool vrc_brick_segment( const vrc_ray& r, const vrc_dev_node& n, float st
 template < bool CLAMP >
 VRC_HD uint32_t vrc_voxel_index( const vrc_dev_node& n, const vrc_frame& f, vrc_f3 pos )
 {
+    VRC_FAST_FP
     const float lx = ( pos.x - n.aabbMin[0] ) * n.voxPerWorld[0] + n.localOrigin[0];
     const float ly = ( pos.y - n.aabbMin[1] ) * n.voxPerWorld[1] + n.localOrigin[1];
     const float lz = ( pos.z - n.aabbMin[2] ) * n.voxPerWorld[2] + n.localOrigin[2];
@@ -301,6 +324,7 @@ VRC_HD uint32_t vrc_voxel_index( const vrc_dev_node& n, const vrc_frame& f, vrc_
 /* Renderer.cu:83-93 with the classified table: e = (rgb*alpha', alpha') for the density */
 VRC_HD void vrc_composite( vrc_f4& c, const vrc_f4& e )
 {
+    VRC_FAST_FP
     const float t = 1.0f - c.w;
     c.x = c.x + e.x * t;
     c.y = c.y + e.y * t;

@@ -61,6 +61,15 @@ def build_oracle():
 
 
 def build_harness(sanitize=False):
+    if sanitize == "fma":
+        # emulate the GPU build's floating-point contraction on the host: clang, FMA enabled,
+        # contraction "fast" but honouring the pragmas in vrc_core.h (hipcc's default mode)
+        out = os.path.join(HARNESS_DIR, "libharness_fma.so")
+        src = os.path.join(HARNESS_DIR, "harness.cpp")
+        subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-O2", "-std=c++17", "-fPIC",
+                               "-shared", "-mfma", "-ffp-contract=fast-honor-pragmas",
+                               "-Wno-unknown-pragmas", "-o", out, src])
+        return out
     out = HARNESS_SO if not sanitize else os.path.join(HARNESS_DIR, "libharness_asan.so")
     src = os.path.join(HARNESS_DIR, "harness.cpp")
     deps = [src] + [os.path.join(ROOT, "libre_amd", "csrc", f) for f in ("vrc_core.h", "vrc_tables.h")]

@@ -21,6 +21,7 @@ SCENES = {
     "hash64_axis": dict(voxels=(64, 64, 64), block=16, viewport=(48, 48), volume="hash"),
     "hash64_spin": dict(voxels=(64, 64, 64), block=16, viewport=(40, 56), volume="hash", spin=(0.5, 0.35)),
     "hash64_ert": dict(voxels=(64, 64, 64), block=16, viewport=(48, 48), volume="hash", spin=(0.3, -0.2), alpha=1.0),
+    "mem64_ert": dict(voxels=(64, 64, 64), block=16, viewport=(48, 48), spin=(0.3, -0.2), alpha=1.0),
     "mem_ragged": dict(voxels=(96, 64, 32), block=16, viewport=(37, 29), spin=(0.2, 0.9)),
     "hash_spr300": dict(voxels=(64, 64, 64), block=32, viewport=(33, 31), volume="hash", spin=(0.1, 0.2), spr=300),
     "hash_clip": dict(voxels=(64, 64, 64), block=16, viewport=(48, 48), volume="hash", spin=(0.5, 0.35),

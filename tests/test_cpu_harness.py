@@ -154,3 +154,17 @@ def test_sanitized_build_runs_clean():
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("name", ["hash64_ert", "hash64_spin", "hash_clip", "mem64_ert"])
+def test_gpu_like_fma_contraction_keeps_parity(name):
+    # the gfx950 build contracts a*b+c in the sample loop (voxel index, compositing) but not
+    # in ray / brick-segment set-up (VRC_STRICT_FP); emulate that on the host with clang -mfma
+    import os
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("no clang")
+    s = scenes.get(name)
+    want, n_want = orc.oracle_render(s, threads=4)
+    got, n_got, _ = orc.harness_render(s, kernel=2, sanitize="fma")
+    scenes.assert_parity(got, want, name)
+    assert abs(n_got - n_want) <= 2e-4 * n_want + 8

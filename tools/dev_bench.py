@@ -1,0 +1,64 @@
+"""Developer micro-bench of the raycast kernel on oracle-derived inputs (NOT bench.py: the
+judged benchmark drives the C++ host; this exists to iterate on the kernel)."""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import orc  # noqa: E402
+from gpu_run import GpuScene  # noqa: E402
+from libre_amd import vrc  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--voxels", type=int, default=1024)
+    ap.add_argument("--block", type=int, default=128)
+    ap.add_argument("--viewport", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--volume", default="mem")
+    ap.add_argument("--spin", type=float, nargs=2, default=(0.0, 0.0))
+    ap.add_argument("--alpha", type=float, default=0.05)
+    ap.add_argument("--ref-order", action="store_true")
+    a = ap.parse_args()
+    t0 = time.time()
+    s = orc.build_scene(voxels=(a.voxels,) * 3, block=a.block, viewport=(a.viewport,) * 2,
+                        volume=a.volume, spin=tuple(a.spin), alpha=a.alpha)
+    print("scene built in %.1fs: %d nodes spr %d atlas %s" % (time.time() - t0, s.n_nodes,
+          s.render.samplesPerRay, s.atlas_dim), flush=True)
+    with GpuScene(s) as g:
+        print("uploaded in %.1fs" % (time.time() - t0), g.info(), flush=True)
+        fb, n, st = g.render(count=True)
+        print("samples/frame %d, counted-kernel %.3f ms, variant %d grid %s alpha max %.3f" %
+              (n, st.kernel_ms, st.kernel_variant, list(st.grid_dims), fb[..., 3].max()), flush=True)
+        L = g.L
+        view = C.cast(C.byref(s.view), C.POINTER(vrc.ViewData))
+        render = C.cast(C.byref(s.render), C.POINTER(vrc.RenderData))
+        nodes = C.cast(s.nodes, C.POINTER(vrc.NodeData))
+        vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_COUNT_SAMPLES, 0))
+        kernels = [vrc.KERNEL_GRID_DDA] + ([vrc.KERNEL_REFERENCE_ORDER] if a.ref_order else [])
+        for k in kernels:
+            vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_KERNEL, k))
+            ms = []
+            stt = vrc.Stats()
+            for i in range(a.steps + 2):
+                vrc.check(L, L.vrc_pre_render(g.ctx, view))
+                vrc.check(L, L.vrc_render(g.ctx, view, nodes, s.n_nodes, render, g.pool))
+                vrc.check(L, L.vrc_get_stats(g.ctx, C.byref(stt)))
+                if i >= 2:
+                    ms.append(stt.kernel_ms)
+            ms = np.array(ms)
+            A = a.voxels ** 3 + a.viewport ** 2 * 16 + s.n_nodes * 48 + 4096
+            print("kernel %d: median %.3f ms min %.3f ms -> %.1f Msamples/s, %.1f fps, algorithmic %.1f GB/s"
+                  % (k, np.median(ms), ms.min(), n / np.median(ms) / 1e3, 1e3 / np.median(ms),
+                     A / np.median(ms) / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    main()
