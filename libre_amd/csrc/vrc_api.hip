@@ -48,7 +48,6 @@ struct vrc_pool
     uint32_t slotDim[3] = { 0, 0, 0 }; /* maxBlock rounded up to the micro-block size */
     uint32_t slots[3] = { 1, 1, 1 };
     uint32_t atlasDim[3] = { 0, 0, 0 };
-    uint32_t nbx = 0, nby = 0, nbz = 0;
     size_t slotBytes = 0, atlasBytes = 0;
     void* dAtlas = nullptr;
 
@@ -108,6 +107,13 @@ struct vrc_ctx
     bool cachedClamp = false;
     vrc_frame cachedGridFrame; /* only grid* fields are meaningful */
 
+    /* tile schedule */
+    uint32_t* dTileOrder = nullptr;
+    size_t dTileOrderCap = 0;
+    bool tileOrderValid = false;
+    vrc_frame tileOrderFrame;
+    int64_t optTileOrder = 1;
+
     unsigned long long* dCounter = nullptr;
     unsigned long long* hCounter = nullptr; /* pinned */
 
@@ -143,7 +149,7 @@ int vrc_ctx_create( int device, vrc_ctx** out )
     std::memset( c->planes, 0, sizeof( c->planes ) );
     hipError_t e = hipStreamCreateWithFlags( &c->ownStream, hipStreamNonBlocking );
     if( e == hipSuccess ) e = hipMalloc( &c->dTf, 256 * 4 * sizeof( float ) );
-    if( e == hipSuccess ) e = hipMalloc( &c->dLut, 256 * sizeof( vrc_f4 ) );
+    if( e == hipSuccess ) e = hipMalloc( &c->dLut, 257 * sizeof( vrc_f4 ) );
     if( e == hipSuccess ) e = hipMalloc( &c->dCounter, sizeof( unsigned long long ) );
     if( e == hipSuccess ) e = hipHostMalloc( &c->hCounter, sizeof( unsigned long long ) );
     if( e == hipSuccess ) e = hipEventCreate( &c->evStart );
@@ -186,6 +192,7 @@ void vrc_ctx_destroy( vrc_ctx* c )
     if( c->dNodes ) (void)hipFree( c->dNodes );
     if( c->dGrid ) (void)hipFree( c->dGrid );
     if( c->hStage ) (void)hipHostFree( c->hStage );
+    if( c->dTileOrder ) (void)hipFree( c->dTileOrder );
     if( c->dCounter ) (void)hipFree( c->dCounter );
     if( c->hCounter ) (void)hipHostFree( c->hCounter );
     if( c->evStart ) (void)hipEventDestroy( c->evStart );
@@ -227,6 +234,7 @@ int vrc_set_option( vrc_ctx* c, int option, int64_t value )
         c->optTfFracBits = value;
         return VRC_OK;
     case VRC_OPT_COUNT_SAMPLES: c->optCount = value ? 1 : 0; return VRC_OK;
+    case VRC_OPT_TILE_ORDER: c->optTileOrder = value ? 1 : 0; return VRC_OK;
     default: return fail( VRC_EINVAL, "vrc_set_option: unknown option" );
     }
 }
@@ -241,6 +249,7 @@ int vrc_get_option( vrc_ctx* c, int option, int64_t* value )
     case VRC_OPT_FILTER: *value = c->optFilter; return VRC_OK;
     case VRC_OPT_TF_FRAC_BITS: *value = c->optTfFracBits; return VRC_OK;
     case VRC_OPT_COUNT_SAMPLES: *value = c->optCount; return VRC_OK;
+    case VRC_OPT_TILE_ORDER: *value = c->optTileOrder; return VRC_OK;
     default: return fail( VRC_EINVAL, "vrc_get_option: unknown option" );
     }
 }
@@ -280,6 +289,11 @@ int vrc_pool_create( vrc_ctx* c, size_t bytesPerVoxel, int isSigned, int isFloat
         }
     }
     p->slotBytes = (size_t)p->slotDim[0] * p->slotDim[1] * p->slotDim[2] * p->elemBytes;
+    if( (size_t)p->slotDim[0] * p->slotDim[1] * p->slotDim[2] >= ( 1u << 24 ) )
+    {
+        delete p;
+        return fail( VRC_EINVAL, "vrc_pool_create: block of 2^24 voxels or more (max 248^3)" );
+    }
 
     /* cuda/TexturePool.cu:119-135, with 64-bit arithmetic (fixes quirk Q12) */
     size_t freeMem = 0, totalMem = 0;
@@ -299,9 +313,6 @@ int vrc_pool_create( vrc_ctx* c, size_t bytesPerVoxel, int isSigned, int isFloat
                             std::max( maxBlocks / ( p->slots[0] * p->slots[1] ), 1u ) );
     for( int a = 0; a < 3; ++a )
         p->atlasDim[a] = p->slots[a] * p->slotDim[a];
-    p->nbx = p->atlasDim[0] / VRC_MB;
-    p->nby = p->atlasDim[1] / VRC_MB;
-    p->nbz = p->atlasDim[2] / VRC_MB;
     p->atlasBytes = (size_t)p->atlasDim[0] * p->atlasDim[1] * p->atlasDim[2] * p->elemBytes;
     if( p->atlasBytes / p->elemBytes >= 0xFFFFFFFFull )
     {
@@ -431,8 +442,19 @@ static int pool_upload( vrc_pool* p, const void* src, bool srcIsDevice, const ui
             devSrc = st.device;
         }
         if( e == hipSuccess )
-            e = vrc_launch_repack_brick( devSrc, p->dAtlas, p->elemBytes, size, o, p->nbx, p->nby,
-                                         p->uploadStream );
+        {
+            vrc_layout lay;
+            for( int a = 0; a < 3; ++a )
+            {
+                lay.slots[a] = p->slots[a];
+                lay.slotDim[a] = p->slotDim[a];
+            }
+            const uint32_t base = vrc_slot_base( lay, o[0] / p->slotDim[0], o[1] / p->slotDim[1],
+                                                 o[2] / p->slotDim[2] );
+            e = vrc_launch_repack_brick( devSrc, (uint8_t*)p->dAtlas + (size_t)base * p->elemBytes,
+                                         p->elemBytes, size, p->slotDim[0] / VRC_MB,
+                                         p->slotDim[1] / VRC_MB, p->uploadStream );
+        }
         if( e == hipSuccess )
             e = hipEventRecord( st.done, p->uploadStream );
         st.used = true;
@@ -530,8 +552,16 @@ int vrc_pool_read_region( vrc_pool* p, const uint32_t origin[3], const uint32_t 
     VRC_HIP_CHECK( hipMalloc( &tmp, bytes ) );
     hipError_t e = hipStreamSynchronize( p->uploadStream );
     if( e == hipSuccess )
-        e = vrc_launch_read_region( p->dAtlas, tmp, p->elemBytes, origin, size, p->nbx, p->nby,
+    {
+        vrc_layout lay;
+        for( int a = 0; a < 3; ++a )
+        {
+            lay.slots[a] = p->slots[a];
+            lay.slotDim[a] = p->slotDim[a];
+        }
+        e = vrc_launch_read_region( p->dAtlas, tmp, p->elemBytes, origin, size, lay,
                                     p->uploadStream );
+    }
     if( e == hipSuccess ) e = hipStreamSynchronize( p->uploadStream );
     if( e == hipSuccess ) e = hipMemcpy( hostOut, tmp, bytes, hipMemcpyDeviceToHost );
     (void)hipFree( tmp );
@@ -727,8 +757,8 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
             geom.atlasDim[a] = pool->atlasDim[a];
             geom.slotDim[a] = pool->slotDim[a];
         }
-        geom.nbx = pool->nbx;
-        geom.nby = pool->nby;
+        for( int a = 0; a < 3; ++a )
+            geom.slots[a] = pool->slots[a];
         vrc_build_tables( geom, nodes, nNodes, t );
         const int rc = ensure_capacity( c, t.nodes.size(), t.grid.size() );
         if( rc != VRC_OK )
@@ -768,10 +798,34 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
             geom.atlasDim[i] = pool->atlasDim[i];
             geom.slotDim[i] = pool->slotDim[i];
         }
-        geom.nbx = pool->nbx;
-        geom.nby = pool->nby;
+        for( int a = 0; a < 3; ++a )
+            geom.slots[a] = pool->slots[a];
         vrc_fill_frame( f, *view, *render, geom, c->cachedGridFrame, c->planes, c->nPlanes, nNodes,
                         c->fbW, c->fbH, 0.0f, 0.0f );
+    }
+
+    /* tile schedule, recomputed only when the frame constants changed */
+    a.tileOrder = nullptr;
+    if( c->optTileOrder )
+    {
+        const size_t nTiles = (size_t)( ( c->fbW + 7 ) / 8 ) * ( ( c->fbH + 7 ) / 8 );
+        if( nTiles > c->dTileOrderCap )
+        {
+            VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
+            if( c->dTileOrder ) VRC_HIP_CHECK( hipFree( c->dTileOrder ) );
+            c->dTileOrder = nullptr;
+            c->dTileOrderCap = 0;
+            VRC_HIP_CHECK( hipMalloc( &c->dTileOrder, nTiles * sizeof( uint32_t ) ) );
+            c->dTileOrderCap = nTiles;
+            c->tileOrderValid = false;
+        }
+        if( !c->tileOrderValid || std::memcmp( &c->tileOrderFrame, &f, sizeof( f ) ) != 0 )
+        {
+            VRC_HIP_CHECK( vrc_launch_tile_order( f, c->dTileOrder, c->stream ) );
+            std::memcpy( &c->tileOrderFrame, &f, sizeof( f ) );
+            c->tileOrderValid = true;
+        }
+        a.tileOrder = c->dTileOrder;
     }
 
     a.nodes = c->dNodes;

@@ -59,8 +59,8 @@ struct vrc_dev_node
     float aabbSize[3];
     float voxPerWorld[3]; /* texSize*atlasDim/aabbSize: atlas voxels per world unit */
     float localOrigin[3]; /* atlas-voxel coordinate of aabbMin, relative to the slot origin */
-    uint32_t slotBlock;   /* micro-block index of the slot origin */
-    uint32_t slotVoxel[3]; /* atlas voxel coordinate of the slot origin (multiple of 8) */
+    uint32_t slotBase;    /* element offset of the brick's slot in the atlas buffer */
+    uint32_t pad[3];
 };
 
 /* Frame constants, derived on the host exactly as Renderer.cu:159-170 does per thread. */
@@ -79,7 +79,7 @@ struct vrc_frame
     float planes[6][4];
     uint32_t nodeCount;
     /* atlas */
-    uint32_t nbx, nby;             /* micro-blocks per atlas row / column */
+    uint32_t sbx, sby;             /* micro-blocks per slot row / column (slotDim/8) */
     uint32_t slotDim[3];           /* padded slot size in voxels */
     /* brick grid for the DDA kernel */
     float gridMin[3];
@@ -88,13 +88,41 @@ struct vrc_frame
     int32_t gridDim[3];
 };
 
-/* physical element index of logical atlas voxel (x,y,z) */
-VRC_HD uint32_t vrc_swizzle( uint32_t x, uint32_t y, uint32_t z, uint32_t nbx, uint32_t nby )
+/* Atlas memory layout.  The logical atlas is the reference's 3-D array of slots
+ * (cuda/TexturePool.cu:128-150); physically every slot is one contiguous run of
+ * slotDim.x*slotDim.y*slotDim.z elements, and inside a slot voxels are grouped in 8x8x8
+ * micro-blocks (x fastest inside a block, blocks x-fastest inside the slot).  A brick is
+ * therefore one contiguous 2.4 MiB range (TLB-friendly) and the 64 fetches of a wave step
+ * land in a few 64-byte segments. */
+struct vrc_layout
 {
-    const uint32_t blk = ( ( z >> VRC_MB_SHIFT ) * nby + ( y >> VRC_MB_SHIFT ) ) * nbx +
+    uint32_t slots[3];   /* slot grid */
+    uint32_t slotDim[3]; /* padded slot size in voxels, multiples of 8 */
+};
+
+/* element offset of voxel (x,y,z), local to a slot of sbx x sby x * micro-blocks */
+VRC_HD uint32_t vrc_slot_local_index( uint32_t x, uint32_t y, uint32_t z, uint32_t sbx, uint32_t sby )
+{
+    const uint32_t blk = ( ( z >> VRC_MB_SHIFT ) * sby + ( y >> VRC_MB_SHIFT ) ) * sbx +
                          ( x >> VRC_MB_SHIFT );
     const uint32_t inner = ( ( z & 7u ) << 6 ) | ( ( y & 7u ) << 3 ) | ( x & 7u );
     return blk * VRC_MB_VOXELS + inner;
+}
+
+/* element offset of slot (i,j,k) */
+VRC_HD uint32_t vrc_slot_base( const vrc_layout& l, uint32_t i, uint32_t j, uint32_t k )
+{
+    const uint32_t slotVoxels = l.slotDim[0] * l.slotDim[1] * l.slotDim[2];
+    return ( ( k * l.slots[1] + j ) * l.slots[0] + i ) * slotVoxels;
+}
+
+/* physical element index of logical atlas voxel (x,y,z) */
+VRC_HD uint32_t vrc_atlas_index( const vrc_layout& l, uint32_t x, uint32_t y, uint32_t z )
+{
+    const uint32_t i = x / l.slotDim[0], j = y / l.slotDim[1], k = z / l.slotDim[2];
+    return vrc_slot_base( l, i, j, k ) +
+           vrc_slot_local_index( x - i * l.slotDim[0], y - j * l.slotDim[1], z - k * l.slotDim[2],
+                                 l.slotDim[0] >> VRC_MB_SHIFT, l.slotDim[1] >> VRC_MB_SHIFT );
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -295,30 +323,72 @@ VRC_HD bool vrc_brick_segment( const vrc_ray& r, const vrc_dev_node& n, float st
     return true;
 }
 
+/* 24-bit multiply (v_mul_u32_u24 / v_mad_u32_u24 on gfx950: full rate, where a 32-bit
+ * multiply is quarter rate). */
+VRC_HD uint32_t vrc_mul24( uint32_t a, uint32_t b )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+    return __umul24( a, b );
+#else
+    return ( a & 0xFFFFFFu ) * ( b & 0xFFFFFFu );
+#endif
+}
+
+/* Per-brick sampler constants, hoisted out of the march loop. */
+struct vrc_sampler
+{
+    float minx, miny, minz;   /* aabbMin */
+    float kx, ky, kz;         /* atlas voxels per world unit */
+    float ox, oy, oz;         /* slot-local voxel coordinate of aabbMin (= overlap) */
+    float hix, hiy, hiz;      /* slotDim - 1 (clamped sampler only) */
+    uint32_t slotBase;        /* element offset of the slot */
+    uint32_t cy, cz;          /* element stride of one micro-block step in y / z */
+};
+
+VRC_HD vrc_sampler vrc_make_sampler( const vrc_dev_node& n, const vrc_frame& f )
+{
+    vrc_sampler s;
+    s.minx = n.aabbMin[0]; s.miny = n.aabbMin[1]; s.minz = n.aabbMin[2];
+    s.kx = n.voxPerWorld[0]; s.ky = n.voxPerWorld[1]; s.kz = n.voxPerWorld[2];
+    s.ox = n.localOrigin[0]; s.oy = n.localOrigin[1]; s.oz = n.localOrigin[2];
+    s.hix = (float)( f.slotDim[0] - 1u );
+    s.hiy = (float)( f.slotDim[1] - 1u );
+    s.hiz = (float)( f.slotDim[2] - 1u );
+    s.slotBase = n.slotBase;
+    s.cy = f.sbx * VRC_MB_VOXELS;
+    s.cz = f.sbx * f.sby * VRC_MB_VOXELS;
+    return s;
+}
+
 /* brick-local voxel of a world position (nearest, Renderer.cu:210-214 + point sampling of
  * cuda/TexturePool.cu:163-170), as the physical element index in the atlas.
  * Evaluated brick-locally so the float grid is finer than the reference's normalized
  * atlas coordinate; voxel choice can differ only for samples within ~1e-4 voxel of a
- * voxel face ("nearest-voxel flips"). */
+ * voxel face ("nearest-voxel flips").  Coordinates are >= 0 here, so the
+ * float->int truncation is the floor of the point-sampling rule. */
 template < bool CLAMP >
-VRC_HD uint32_t vrc_voxel_index( const vrc_dev_node& n, const vrc_frame& f, vrc_f3 pos )
+VRC_HD uint32_t vrc_voxel_index( const vrc_sampler& s, vrc_f3 pos )
 {
     VRC_FAST_FP
-    const float lx = ( pos.x - n.aabbMin[0] ) * n.voxPerWorld[0] + n.localOrigin[0];
-    const float ly = ( pos.y - n.aabbMin[1] ) * n.voxPerWorld[1] + n.localOrigin[1];
-    const float lz = ( pos.z - n.aabbMin[2] ) * n.voxPerWorld[2] + n.localOrigin[2];
-    int ix = (int)floorf( lx ), iy = (int)floorf( ly ), iz = (int)floorf( lz );
+    float lx = ( pos.x - s.minx ) * s.kx + s.ox;
+    float ly = ( pos.y - s.miny ) * s.ky + s.oy;
+    float lz = ( pos.z - s.minz ) * s.kz + s.oz;
     if( CLAMP )
     {
-        ix = ix < 0 ? 0 : ( ix > (int)f.slotDim[0] - 1 ? (int)f.slotDim[0] - 1 : ix );
-        iy = iy < 0 ? 0 : ( iy > (int)f.slotDim[1] - 1 ? (int)f.slotDim[1] - 1 : iy );
-        iz = iz < 0 ? 0 : ( iz > (int)f.slotDim[2] - 1 ? (int)f.slotDim[2] - 1 : iz );
+        lx = fminf( fmaxf( lx, 0.0f ), s.hix );
+        ly = fminf( fmaxf( ly, 0.0f ), s.hiy );
+        lz = fminf( fmaxf( lz, 0.0f ), s.hiz );
     }
-    const uint32_t ux = (uint32_t)ix, uy = (uint32_t)iy, uz = (uint32_t)iz;
-    const uint32_t blk = n.slotBlock + ( ( uz >> VRC_MB_SHIFT ) * f.nby + ( uy >> VRC_MB_SHIFT ) ) * f.nbx +
-                         ( ux >> VRC_MB_SHIFT );
-    const uint32_t inner = ( ( uz & 7u ) << 6 ) | ( ( uy & 7u ) << 3 ) | ( ux & 7u );
-    return blk * VRC_MB_VOXELS + inner;
+    const uint32_t ux = (uint32_t)(int)lx, uy = (uint32_t)(int)ly, uz = (uint32_t)(int)lz;
+    /* element = slotBase + fx(x) + fy(y) + fz(z), each axis: (c >> 3) * blockStride +
+     * ((c & 7) << bits).  Slot-local block counts are <= 512 and the strides < 2^24 (slot
+     * < 16 Mi elements, checked at pool creation), so the products are 24-bit multiplies. */
+    uint32_t e = s.slotBase + ( ( ux >> VRC_MB_SHIFT ) << 9 );
+    e = vrc_mul24( uy >> VRC_MB_SHIFT, s.cy ) + e;
+    e = ( ( uy & 7u ) << 3 ) + e;
+    e = vrc_mul24( uz >> VRC_MB_SHIFT, s.cz ) + e;
+    e = ( ( uz & 7u ) << 6 ) + e;
+    return e + ( ux & 7u );
 }
 
 /* Renderer.cu:83-93 with the classified table: e = (rgb*alpha', alpha') for the density */
@@ -333,50 +403,63 @@ VRC_HD void vrc_composite( vrc_f4& c, const vrc_f4& e )
 }
 
 /* ------------------------------------------------------------------------------------------
- * March one brick segment (Renderer.cu:206-223).  Samples are taken in groups of four so
- * that four atlas fetches are in flight per lane; each sample is composited only if the
- * reference loop would have reached it (travel > 0 and no early exit yet), so the result
- * is the reference's sample sequence exactly.
+ * March one brick segment (Renderer.cu:206-223).
+ *
+ * Samples are generated in groups of VRC_GROUP so that VRC_GROUP byte gathers are in flight
+ * per lane (the march is latency-bound on the gather otherwise).  The loop body is branch-free:
+ * a sample the reference loop would not reach (travel <= 0, or after the early exit) fetches
+ * atlas element 0 and composites table entry 256, which is all zeros -- an exact no-op --
+ * so the composited sample sequence is the reference's, sample for sample.
+ * lut has 257 entries; lut[256] = 0.
  * Returns true when the early-ray-termination threshold was crossed (Renderer.cu:219-226).
  * ---------------------------------------------------------------------------------------- */
+#ifndef VRC_GROUP
+#define VRC_GROUP 8
+#endif
+
 template < bool CLAMP, bool COUNT, typename ATLAS_T >
 VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_segment s,
                                const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
                                vrc_f4& color, uint32_t& nSamples )
 {
     const float stepSize = f.stepSize;
+    const vrc_sampler sm = vrc_make_sampler( n, f );
     float travel = s.dist;
     vrc_f3 pos = s.pos;
     bool done = false;
+    if( !( travel > 0.0f ) )
+        return false;
+
+    /* One group per iteration: VRC_GROUP indices, VRC_GROUP fetches issued back to back,
+     * then the group is composited in order (the compiler waits with a counted vmcnt before
+     * each use, so sample k is composited while fetches k+1.. are still in flight).  Nothing
+     * in the body is conditional, so there is nothing for the compiler to sink or hoist. */
     while( travel > 0.0f && !done )
     {
-        uint32_t idx[4];
-        bool valid[4];
+        uint32_t idx[VRC_GROUP], d[VRC_GROUP], n = 0;
 #pragma unroll
-        for( int k = 0; k < 4; ++k )
+        for( int k = 0; k < VRC_GROUP; ++k )
         {
-            valid[k] = travel > 0.0f;
-            /* positions past the end of the segment are computed but never fetched */
-            idx[k] = vrc_voxel_index< CLAMP >( n, f, pos );
+            const bool v = travel > 0.0f;
+            n += v ? 1u : 0u;
+            const uint32_t i = vrc_voxel_index< CLAMP >( sm, pos );
+            idx[k] = v ? i : 0u;
             pos.x += s.step.x;
             pos.y += s.step.y;
             pos.z += s.step.z;
             travel -= stepSize;
         }
-        uint32_t d[4];
 #pragma unroll
-        for( int k = 0; k < 4; ++k )
-            d[k] = valid[k] ? (uint32_t)atlas[idx[k]] : 0u;
+        for( int k = 0; k < VRC_GROUP; ++k )
+            d[k] = (uint32_t)atlas[idx[k]];
 #pragma unroll
-        for( int k = 0; k < 4; ++k )
+        for( int k = 0; k < VRC_GROUP; ++k )
         {
-            if( valid[k] && !done )
-            {
-                vrc_composite( color, lut[d[k]] );
-                if( COUNT )
-                    ++nSamples;
-                done = color.w > VRC_EARLY_EXIT;
-            }
+            const bool active = ( (uint32_t)k < n ) && !done;
+            vrc_composite( color, lut[active ? d[k] : 256u] );
+            if( COUNT )
+                nSamples += active ? 1u : 0u;
+            done = done || ( color.w > VRC_EARLY_EXIT );
         }
     }
     return done;

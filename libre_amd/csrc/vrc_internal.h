@@ -8,19 +8,20 @@
 
 #include "vrc_core.h"
 
-/* tf: 256 float4 (device).  lut: 256 float4 (device): (rgb*alpha', alpha'). */
+/* tf: 256 float4 (device).  lut: 257 float4 (device): (rgb*alpha', alpha'), entry 256 = 0. */
 hipError_t vrc_launch_build_lut( const float* tf, vrc_f4* lut, vrc_lut_params p,
                                  hipStream_t stream );
 
-/* row-major brick (size voxels, elemBytes per voxel) -> micro-blocked atlas at slot origin */
-hipError_t vrc_launch_repack_brick( const void* srcRowMajor, void* atlas, uint32_t elemBytes,
-                                    const uint32_t size[3], const uint32_t slotVoxel[3],
-                                    uint32_t nbx, uint32_t nby, hipStream_t stream );
+/* row-major brick (size voxels, elemBytes per voxel) -> micro-blocked slot (slot = device
+ * pointer to the slot's first element; sbx/sby = micro-blocks per slot row/column) */
+hipError_t vrc_launch_repack_brick( const void* srcRowMajor, void* slot, uint32_t elemBytes,
+                                    const uint32_t size[3], uint32_t sbx, uint32_t sby,
+                                    hipStream_t stream );
 
-/* inverse, for tests: atlas region -> row-major */
+/* inverse, for tests: logical atlas region -> row-major */
 hipError_t vrc_launch_read_region( const void* atlas, void* dstRowMajor, uint32_t elemBytes,
                                    const uint32_t origin[3], const uint32_t size[3],
-                                   uint32_t nbx, uint32_t nby, hipStream_t stream );
+                                   const vrc_layout& lay, hipStream_t stream );
 
 struct vrc_raycast_args
 {
@@ -31,9 +32,13 @@ struct vrc_raycast_args
     const vrc_f4* lut;
     vrc_f4* pixelBuffer;
     unsigned long long* sampleCounter; /* NULL = do not count */
+    const uint32_t* tileOrder;         /* NULL = row-major tile order */
     bool clamp;
     bool gridDda;
 };
+
+/* heaviest-first tile schedule for the frame (order: one uint32 per 8x8 tile) */
+hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, hipStream_t stream );
 
 hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream );
 

@@ -28,6 +28,12 @@ __global__ void vrc_k_build_lut( const float* __restrict__ tf, vrc_f4* __restric
     const uint32_t d = threadIdx.x;
     if( d < 256u )
         lut[d] = vrc_lut_entry( tf, d, p );
+    if( d == 0 )
+    {
+        /* entry 256: the no-op sample (vrc_march_segment) */
+        const vrc_f4 z = { 0.f, 0.f, 0.f, 0.f };
+        lut[256] = z;
+    }
 }
 
 hipError_t vrc_launch_build_lut( const float* tf, vrc_f4* lut, vrc_lut_params p,
@@ -41,10 +47,11 @@ hipError_t vrc_launch_build_lut( const float* tf, vrc_f4* lut, vrc_lut_params p,
  * brick upload: row-major brick -> micro-blocked atlas (replaces the cudaMemcpy3DAsync into
  * a cudaArray of cuda/TexturePool.cu:187-201; the "array layout" is ours to define)
  * ---------------------------------------------------------------------------------------- */
-/* fast path: 1-byte voxels, x extent a multiple of 8: one thread moves one 8-voxel run */
-__global__ void vrc_k_repack_u8x8( const uint2* __restrict__ src, uint8_t* __restrict__ atlas,
-                                   uint32_t sx8, uint32_t sy, uint32_t sz, uint32_t ox,
-                                   uint32_t oy, uint32_t oz, uint32_t nbx, uint32_t nby )
+/* fast path: 1-byte voxels, x extent a multiple of 8: one thread moves one 8-voxel run
+ * (= one row of a micro-block z-slice, 8-byte aligned on both sides) */
+__global__ void vrc_k_repack_u8x8( const uint2* __restrict__ src, uint8_t* __restrict__ slot,
+                                   uint32_t sx8, uint32_t sy, uint32_t sz, uint32_t sbx,
+                                   uint32_t sby )
 {
     const uint32_t total = sx8 * sy * sz;
     for( uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -54,15 +61,15 @@ __global__ void vrc_k_repack_u8x8( const uint2* __restrict__ src, uint8_t* __res
         const uint32_t y = ( i / sx8 ) % sy;
         const uint32_t z = i / ( sx8 * sy );
         const uint2 v = src[i];
-        const uint32_t e = vrc_swizzle( ox + x8 * 8u, oy + y, oz + z, nbx, nby );
-        *reinterpret_cast< uint2* >( atlas + e ) = v;
+        const uint32_t e = vrc_slot_local_index( x8 * 8u, y, z, sbx, sby );
+        *reinterpret_cast< uint2* >( slot + e ) = v;
     }
 }
 
 template < typename T >
-__global__ void vrc_k_repack_generic( const T* __restrict__ src, T* __restrict__ atlas,
-                                      uint32_t sx, uint32_t sy, uint32_t sz, uint32_t ox,
-                                      uint32_t oy, uint32_t oz, uint32_t nbx, uint32_t nby )
+__global__ void vrc_k_repack_generic( const T* __restrict__ src, T* __restrict__ slot,
+                                      uint32_t sx, uint32_t sy, uint32_t sz, uint32_t sbx,
+                                      uint32_t sby )
 {
     const size_t total = (size_t)sx * sy * sz;
     for( size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -71,14 +78,14 @@ __global__ void vrc_k_repack_generic( const T* __restrict__ src, T* __restrict__
         const uint32_t x = (uint32_t)( i % sx );
         const uint32_t y = (uint32_t)( ( i / sx ) % sy );
         const uint32_t z = (uint32_t)( i / ( (size_t)sx * sy ) );
-        atlas[vrc_swizzle( ox + x, oy + y, oz + z, nbx, nby )] = src[i];
+        slot[vrc_slot_local_index( x, y, z, sbx, sby )] = src[i];
     }
 }
 
 template < typename T >
 __global__ void vrc_k_read_region( const T* __restrict__ atlas, T* __restrict__ dst,
                                    uint32_t sx, uint32_t sy, uint32_t sz, uint32_t ox,
-                                   uint32_t oy, uint32_t oz, uint32_t nbx, uint32_t nby )
+                                   uint32_t oy, uint32_t oz, const vrc_layout lay )
 {
     const size_t total = (size_t)sx * sy * sz;
     for( size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -87,7 +94,7 @@ __global__ void vrc_k_read_region( const T* __restrict__ atlas, T* __restrict__ 
         const uint32_t x = (uint32_t)( i % sx );
         const uint32_t y = (uint32_t)( ( i / sx ) % sy );
         const uint32_t z = (uint32_t)( i / ( (size_t)sx * sy ) );
-        dst[i] = atlas[vrc_swizzle( ox + x, oy + y, oz + z, nbx, nby )];
+        dst[i] = atlas[vrc_atlas_index( lay, ox + x, oy + y, oz + z )];
     }
 }
 
@@ -101,41 +108,41 @@ static uint32_t grid_for( size_t total, uint32_t block )
     return (uint32_t)g;
 }
 
-hipError_t vrc_launch_repack_brick( const void* src, void* atlas, uint32_t elemBytes,
-                                    const uint32_t size[3], const uint32_t o[3], uint32_t nbx,
-                                    uint32_t nby, hipStream_t stream )
+hipError_t vrc_launch_repack_brick( const void* src, void* slot, uint32_t elemBytes,
+                                    const uint32_t size[3], uint32_t sbx, uint32_t sby,
+                                    hipStream_t stream )
 {
     const size_t total = (size_t)size[0] * size[1] * size[2];
     if( total == 0 )
         return hipSuccess;
     if( elemBytes == 1 && ( size[0] % 8u ) == 0 && ( ( (uintptr_t)src ) % 8u ) == 0 &&
-        ( o[0] % 8u ) == 0 && total / 8 < 0xFFFFFFFFull )
+        ( ( (uintptr_t)slot ) % 8u ) == 0 && total / 8 < 0xFFFFFFFFull )
     {
         const uint32_t sx8 = size[0] / 8u;
         hipLaunchKernelGGL( vrc_k_repack_u8x8, dim3( grid_for( total / 8, 256 ) ), dim3( 256 ), 0,
-                            stream, (const uint2*)src, (uint8_t*)atlas, sx8, size[1], size[2],
-                            o[0], o[1], o[2], nbx, nby );
+                            stream, (const uint2*)src, (uint8_t*)slot, sx8, size[1], size[2], sbx,
+                            sby );
     }
     else if( elemBytes == 1 )
         hipLaunchKernelGGL( vrc_k_repack_generic< uint8_t >, dim3( grid_for( total, 256 ) ),
-                            dim3( 256 ), 0, stream, (const uint8_t*)src, (uint8_t*)atlas, size[0],
-                            size[1], size[2], o[0], o[1], o[2], nbx, nby );
+                            dim3( 256 ), 0, stream, (const uint8_t*)src, (uint8_t*)slot, size[0],
+                            size[1], size[2], sbx, sby );
     else if( elemBytes == 2 )
         hipLaunchKernelGGL( vrc_k_repack_generic< uint16_t >, dim3( grid_for( total, 256 ) ),
-                            dim3( 256 ), 0, stream, (const uint16_t*)src, (uint16_t*)atlas,
-                            size[0], size[1], size[2], o[0], o[1], o[2], nbx, nby );
+                            dim3( 256 ), 0, stream, (const uint16_t*)src, (uint16_t*)slot, size[0],
+                            size[1], size[2], sbx, sby );
     else if( elemBytes == 4 )
         hipLaunchKernelGGL( vrc_k_repack_generic< uint32_t >, dim3( grid_for( total, 256 ) ),
-                            dim3( 256 ), 0, stream, (const uint32_t*)src, (uint32_t*)atlas,
-                            size[0], size[1], size[2], o[0], o[1], o[2], nbx, nby );
+                            dim3( 256 ), 0, stream, (const uint32_t*)src, (uint32_t*)slot, size[0],
+                            size[1], size[2], sbx, sby );
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 hipError_t vrc_launch_read_region( const void* atlas, void* dst, uint32_t elemBytes,
-                                   const uint32_t o[3], const uint32_t size[3], uint32_t nbx,
-                                   uint32_t nby, hipStream_t stream )
+                                   const uint32_t o[3], const uint32_t size[3],
+                                   const vrc_layout& lay, hipStream_t stream )
 {
     const size_t total = (size_t)size[0] * size[1] * size[2];
     if( total == 0 )
@@ -143,17 +150,79 @@ hipError_t vrc_launch_read_region( const void* atlas, void* dst, uint32_t elemBy
     const dim3 g( grid_for( total, 256 ) ), b( 256 );
     if( elemBytes == 1 )
         hipLaunchKernelGGL( vrc_k_read_region< uint8_t >, g, b, 0, stream, (const uint8_t*)atlas,
-                            (uint8_t*)dst, size[0], size[1], size[2], o[0], o[1], o[2], nbx, nby );
+                            (uint8_t*)dst, size[0], size[1], size[2], o[0], o[1], o[2], lay );
     else if( elemBytes == 2 )
         hipLaunchKernelGGL( vrc_k_read_region< uint16_t >, g, b, 0, stream,
                             (const uint16_t*)atlas, (uint16_t*)dst, size[0], size[1], size[2],
-                            o[0], o[1], o[2], nbx, nby );
+                            o[0], o[1], o[2], lay );
     else if( elemBytes == 4 )
         hipLaunchKernelGGL( vrc_k_read_region< uint32_t >, g, b, 0, stream,
                             (const uint32_t*)atlas, (uint32_t*)dst, size[0], size[1], size[2],
-                            o[0], o[1], o[2], nbx, nby );
+                            o[0], o[1], o[2], lay );
     else
         return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------------------------
+ * tile schedule: order the 8x8 tiles by estimated work, heaviest first.  One workgroup:
+ * cost = chord of the tile-centre ray through the (clipped) volume box, counting sort over
+ * 256 cost buckets in LDS.  Re-run only when the view changes (~10 us).
+ * ---------------------------------------------------------------------------------------- */
+__device__ __forceinline__ uint32_t vrc_tile_bucket( const vrc_frame& f, uint32_t tile,
+                                                     uint32_t tilesX, float invDiag )
+{
+    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
+    uint32_t px = tx * VRC_TILE + VRC_TILE / 2, py = ty * VRC_TILE + VRC_TILE / 2;
+    px = px < f.width ? px : f.width - 1;
+    py = py < f.height ? py : f.height - 1;
+    const vrc_ray r = vrc_setup_ray( f, px, py );
+    if( !r.hit )
+        return 255u;
+    const float chord = r.tFarGlobal - fmaxf( r.tNearGlobal, r.tNearPlane );
+    const float q = fminf( fmaxf( chord * invDiag, 0.0f ), 1.0f );
+    return 255u - (uint32_t)( q * 255.0f );
+}
+
+__global__ __launch_bounds__( 1024 ) void vrc_k_tile_order( const vrc_frame f,
+                                                            const uint32_t tilesX,
+                                                            const uint32_t nTiles,
+                                                            uint32_t* __restrict__ order )
+{
+    __shared__ uint32_t hist[256];
+    const float dx = f.aabbMax[0] - f.aabbMin[0], dy = f.aabbMax[1] - f.aabbMin[1],
+                dz = f.aabbMax[2] - f.aabbMin[2];
+    const float invDiag = 1.0f / sqrtf( dx * dx + dy * dy + dz * dz );
+    if( threadIdx.x < 256 )
+        hist[threadIdx.x] = 0;
+    __syncthreads();
+    for( uint32_t t = threadIdx.x; t < nTiles; t += blockDim.x )
+        atomicAdd( &hist[vrc_tile_bucket( f, t, tilesX, invDiag )], 1u );
+    __syncthreads();
+    if( threadIdx.x == 0 )
+    {
+        uint32_t acc = 0;
+        for( int b = 0; b < 256; ++b )
+        {
+            const uint32_t c = hist[b];
+            hist[b] = acc;
+            acc += c;
+        }
+    }
+    __syncthreads();
+    for( uint32_t t = threadIdx.x; t < nTiles; t += blockDim.x )
+    {
+        const uint32_t pos = atomicAdd( &hist[vrc_tile_bucket( f, t, tilesX, invDiag )], 1u );
+        order[pos] = t;
+    }
+}
+
+hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, hipStream_t stream )
+{
+    const uint32_t tilesX = ( f.width + VRC_TILE - 1 ) / VRC_TILE;
+    const uint32_t tilesY = ( f.height + VRC_TILE - 1 ) / VRC_TILE;
+    hipLaunchKernelGGL( vrc_k_tile_order, dim3( 1 ), dim3( 1024 ), 0, stream, f, tilesX,
+                        tilesX * tilesY, order );
     return hipGetLastError();
 }
 
@@ -165,22 +234,25 @@ __global__ __launch_bounds__( VRC_WG ) void vrc_k_raycast(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ gridTable, const uint8_t* __restrict__ atlas,
     const vrc_f4* __restrict__ lutGlobal, vrc_f4* __restrict__ pixelBuffer,
-    unsigned long long* __restrict__ sampleCounter, const uint32_t tilesX, const uint32_t nTiles )
+    unsigned long long* __restrict__ sampleCounter, const uint32_t* __restrict__ tileOrder,
+    const uint32_t tilesX, const uint32_t nTiles )
 {
-    __shared__ vrc_f4 lut[256];
+    __shared__ vrc_f4 lut[257];
     const uint32_t lane = threadIdx.x;
 #pragma unroll
     for( uint32_t i = 0; i < 256u / VRC_WG; ++i )
         lut[lane + i * VRC_WG] = lutGlobal[lane + i * VRC_WG];
+    if( lane == 0 )
+        lut[256] = lutGlobal[256];
     __syncthreads();
 
-    /* XCD-aware remap: workgroups b and b+8 run on the same XCD (MI355X_MICROARCH.md,
-     * "Workgroup dispatch"); give XCD k the k-th contiguous run of tiles (row-major), so
-     * each XCD's L2 serves one horizontal band of the image.  Bijective for any nTiles. */
-    const uint32_t b = blockIdx.x;
-    const uint32_t xcd = b & 7u, j = b >> 3;
-    const uint32_t per = nTiles >> 3, rem = nTiles & 7u;
-    const uint32_t tile = xcd * per + ( xcd < rem ? xcd : rem ) + j;
+    /* Workgroup -> tile.  Ray lengths vary by more than 2x over the image and whole tiles miss
+     * the volume, so dispatch order matters more than L2 affinity here (every voxel is
+     * touched by about one wave; there is next to no inter-tile reuse to keep in an L2):
+     * tileOrder lists tiles heaviest-first (vrc_k_tile_order), and because the dispatcher
+     * deals workgroups b, b+1, ... round-robin over the 8 XCDs (MI355X_MICROARCH.md,
+     * "Workgroup dispatch") every XCD gets the same mix and the long tiles start first. */
+    const uint32_t tile = tileOrder ? tileOrder[blockIdx.x] : blockIdx.x;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     const uint32_t px = tx * VRC_TILE + ( lane & 7u );
     const uint32_t py = ty * VRC_TILE + ( lane >> 3 );
@@ -217,7 +289,7 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
         return hipSuccess;
     hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT > ), dim3( nTiles ), dim3( VRC_WG ), 0,
                         stream, a.frame, a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut,
-                        a.pixelBuffer, a.sampleCounter, tilesX, nTiles );
+                        a.pixelBuffer, a.sampleCounter, a.tileOrder, tilesX, nTiles );
     return hipGetLastError();
 }
 

@@ -17,7 +17,7 @@ struct vrc_atlas_geom
 {
     uint32_t atlasDim[3];
     uint32_t slotDim[3];
-    uint32_t nbx, nby;
+    uint32_t slots[3];
 };
 
 struct vrc_host_tables
@@ -45,6 +45,7 @@ inline void vrc_build_tables( const vrc_atlas_geom& p, const vrc_node_data* in, 
     {
         const vrc_node_data& s = in[i];
         vrc_dev_node& d = t.nodes[i];
+        uint32_t slotIdx[3];
         for( int a = 0; a < 3; ++a )
         {
             d.aabbMin[a] = s.aabbMin[a];
@@ -56,17 +57,22 @@ inline void vrc_build_tables( const vrc_atlas_geom& p, const vrc_node_data* in, 
             long tv = (long)std::floor( texMinVox + 0.5 );
             if( tv < 0 ) tv = 0;
             if( tv > (long)p.atlasDim[a] - 1 ) tv = (long)p.atlasDim[a] - 1;
-            const uint32_t slotIdx = (uint32_t)tv / p.slotDim[a];
-            d.slotVoxel[a] = slotIdx * p.slotDim[a];
-            d.localOrigin[a] = (float)( texMinVox - (double)d.slotVoxel[a] );
+            slotIdx[a] = (uint32_t)tv / p.slotDim[a];
+            d.localOrigin[a] = (float)( texMinVox - (double)( slotIdx[a] * p.slotDim[a] ) );
             /* samples may land one voxel outside the interior on either side; if that can
              * leave the slot (overlap 0), the kernel clamps inside the slot */
             if( d.localOrigin[a] < 1.0f ||
                 d.localOrigin[a] + (float)texSizeVox > (float)p.slotDim[a] - 1.0f )
                 t.clamp = true;
         }
-        d.slotBlock = ( ( d.slotVoxel[2] / VRC_MB ) * p.nby + ( d.slotVoxel[1] / VRC_MB ) ) * p.nbx +
-                      ( d.slotVoxel[0] / VRC_MB );
+        vrc_layout lay;
+        for( int a = 0; a < 3; ++a )
+        {
+            lay.slots[a] = p.slots[a];
+            lay.slotDim[a] = p.slotDim[a];
+        }
+        d.slotBase = vrc_slot_base( lay, slotIdx[0], slotIdx[1], slotIdx[2] );
+        d.pad[0] = d.pad[1] = d.pad[2] = 0;
     }
 
     /* brick grid: cells of the finest brick size covering the union of the node boxes */
@@ -183,8 +189,8 @@ inline void vrc_fill_frame( vrc_frame& f, const vrc_view_data& view, const vrc_r
         for( int k = 0; k < 4; ++k )
             f.planes[i][k] = planes[i][k];
     f.nodeCount = nNodes;
-    f.nbx = geom.nbx;
-    f.nby = geom.nby;
+    f.sbx = geom.slotDim[0] / VRC_MB;
+    f.sby = geom.slotDim[1] / VRC_MB;
 }
 
 #endif

@@ -26,15 +26,20 @@ extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atla
         geom.atlasDim[a] = atlasDim[a];
         geom.slotDim[a] = slotDim[a];
     }
-    geom.nbx = atlasDim[0] / 8u;
-    geom.nby = atlasDim[1] / 8u;
+    vrc_layout lay;
+    for( int a = 0; a < 3; ++a )
+    {
+        geom.slots[a] = atlasDim[a] / slotDim[a];
+        lay.slots[a] = geom.slots[a];
+        lay.slotDim[a] = slotDim[a];
+    }
 
     /* micro-blocked copy of the atlas, as the upload kernel lays it out */
     std::vector< uint8_t > atlas( (size_t)atlasDim[0] * atlasDim[1] * atlasDim[2] );
     for( uint32_t z = 0; z < atlasDim[2]; ++z )
         for( uint32_t y = 0; y < atlasDim[1]; ++y )
             for( uint32_t x = 0; x < atlasDim[0]; ++x )
-                atlas[vrc_swizzle( x, y, z, geom.nbx, geom.nby )] =
+                atlas[vrc_atlas_index( lay, x, y, z )] =
                     atlasRowMajor[( (size_t)z * atlasDim[1] + y ) * atlasDim[0] + x];
 
     vrc_lut_params lp;
@@ -42,9 +47,10 @@ extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atla
     lp.rangeMax = render->dataSourceRange[1];
     lp.alphaCorrection = (float)render->maxSamplesPerRay / (float)render->samplesPerRay;
     lp.fracBits = fracBits;
-    std::vector< vrc_f4 > lut( 256 );
+    std::vector< vrc_f4 > lut( 257 );
     for( uint32_t d = 0; d < 256; ++d )
         lut[d] = vrc_lut_entry( tf, d, lp );
+    lut[256] = vrc_f4{ 0.f, 0.f, 0.f, 0.f };
 
     vrc_host_tables t;
     vrc_build_tables( geom, nodes, nNodes, t );
