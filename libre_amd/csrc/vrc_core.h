@@ -342,7 +342,7 @@ struct vrc_sampler
     float ox, oy, oz;         /* slot-local voxel coordinate of aabbMin (= overlap) */
     float hix, hiy, hiz;      /* slotDim - 1 (clamped sampler only) */
     uint32_t slotBase;        /* element offset of the slot */
-    uint32_t cy, cz;          /* element stride of one micro-block step in y / z */
+    uint32_t cyy, czz;        /* micro-block stride in y / z minus the in-block stride * 8 */
 };
 
 VRC_HD vrc_sampler vrc_make_sampler( const vrc_dev_node& n, const vrc_frame& f )
@@ -355,8 +355,8 @@ VRC_HD vrc_sampler vrc_make_sampler( const vrc_dev_node& n, const vrc_frame& f )
     s.hiy = (float)( f.slotDim[1] - 1u );
     s.hiz = (float)( f.slotDim[2] - 1u );
     s.slotBase = n.slotBase;
-    s.cy = f.sbx * VRC_MB_VOXELS;
-    s.cz = f.sbx * f.sby * VRC_MB_VOXELS;
+    s.cyy = f.sbx * VRC_MB_VOXELS - 64u;
+    s.czz = f.sbx * f.sby * VRC_MB_VOXELS - 512u;
     return s;
 }
 
@@ -380,22 +380,28 @@ VRC_HD uint32_t vrc_voxel_index( const vrc_sampler& s, vrc_f3 pos )
         lz = fminf( fmaxf( lz, 0.0f ), s.hiz );
     }
     const uint32_t ux = (uint32_t)(int)lx, uy = (uint32_t)(int)ly, uz = (uint32_t)(int)lz;
-    /* element = slotBase + fx(x) + fy(y) + fz(z), each axis: (c >> 3) * blockStride +
-     * ((c & 7) << bits).  Slot-local block counts are <= 512 and the strides < 2^24 (slot
-     * < 16 Mi elements, checked at pool creation), so the products are 24-bit multiplies. */
-    uint32_t e = s.slotBase + ( ( ux >> VRC_MB_SHIFT ) << 9 );
-    e = vrc_mul24( uy >> VRC_MB_SHIFT, s.cy ) + e;
-    e = ( ( uy & 7u ) << 3 ) + e;
-    e = vrc_mul24( uz >> VRC_MB_SHIFT, s.cz ) + e;
-    e = ( ( uz & 7u ) << 6 ) + e;
-    return e + ( ux & 7u );
+    /* element = slotBase + sum over axes of (c >> 3) * blockStride + (c & 7) * inStride with
+     * inStride = 1, 8, 64 and blockStride = 512, 512*sbx, 512*sbx*sby.  Since
+     * (c & 7) * s = c * s - (c >> 3) * 8 * s this is
+     *   slotBase + x + 8 y + 64 z + qx * 504 + qy * (512 sbx - 64) + qz * (512 sbx sby - 512):
+     * three shifts, three 24-bit multiply-adds (full rate; operands < 2^24: slot-local block
+     * counts <= 512, slot < 16 Mi elements, checked at pool creation), two shift-adds, one add. */
+    uint32_t e = vrc_mul24( ux >> VRC_MB_SHIFT, 504u ) + ux;
+    e = vrc_mul24( uy >> VRC_MB_SHIFT, s.cyy ) + e;
+    e = vrc_mul24( uz >> VRC_MB_SHIFT, s.czz ) + e;
+    e = ( uy << 3 ) + e;
+    e = ( uz << 6 ) + e;
+    return e + s.slotBase;
 }
 
-/* Renderer.cu:83-93 with the classified table: e = (rgb*alpha', alpha') for the density */
-VRC_HD void vrc_composite( vrc_f4& c, const vrc_f4& e )
+/* Renderer.cu:83-93 with the classified table: e = (rgb*alpha', alpha') for the density.
+ * frozen: the ray already crossed the early-exit threshold; the weight is forced to 0 so the
+ * step is an exact no-op (x + e*0 == x) without making the table address depend on it. */
+VRC_HD void vrc_composite( vrc_f4& c, const vrc_f4& e, bool frozen = false )
 {
     VRC_FAST_FP
-    const float t = 1.0f - c.w;
+    float t = 1.0f - c.w;
+    t = frozen ? 0.0f : t;
     c.x = c.x + e.x * t;
     c.y = c.y + e.y * t;
     c.z = c.z + e.z * t;
@@ -405,11 +411,21 @@ VRC_HD void vrc_composite( vrc_f4& c, const vrc_f4& e )
 /* ------------------------------------------------------------------------------------------
  * March one brick segment (Renderer.cu:206-223).
  *
- * Samples are generated in groups of VRC_GROUP so that VRC_GROUP byte gathers are in flight
- * per lane (the march is latency-bound on the gather otherwise).  The loop body is branch-free:
- * a sample the reference loop would not reach (travel <= 0, or after the early exit) fetches
- * atlas element 0 and composites table entry 256, which is all zeros -- an exact no-op --
- * so the composited sample sequence is the reference's, sample for sample.
+ * The kernel is VALU-issue bound on MI355X (a wave64 VALU instruction costs ~4 cycles of its
+ * SIMD; measured: removing every memory access changes the frame time by < 15 %), so the
+ * march is organised to spend as few vector instructions per sample as possible:
+ *   - samples are taken in groups of VRC_GROUP: indices, then VRC_GROUP byte gathers issued
+ *     back to back, then VRC_GROUP table reads, then the blends;
+ *   - FAST groups: while more than VRC_GROUP steps remain on the segment every sample of the
+ *     group is one the reference loop reaches, so there is no per-sample bounds test, no
+ *     index select and no table-index select;
+ *   - early ray termination is tested once per group (alpha never decreases); only when the
+ *     threshold was crossed inside the group is the group replayed sample by sample from the
+ *     saved colour, which reproduces the reference's exit after the crossing sample exactly;
+ *   - the TAIL (at most VRC_GROUP + 1 remaining steps) runs the general branch-free form: a
+ *     sample the reference would not reach fetches element 0 and blends table entry 256,
+ *     which is all zeros -- an exact no-op.
+ * The composited sample sequence is the reference's, sample for sample, in both paths.
  * lut has 257 entries; lut[256] = 0.
  * Returns true when the early-ray-termination threshold was crossed (Renderer.cu:219-226).
  * ---------------------------------------------------------------------------------------- */
@@ -427,21 +443,66 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
     float travel = s.dist;
     vrc_f3 pos = s.pos;
     bool done = false;
-    if( !( travel > 0.0f ) )
-        return false;
 
-    /* One group per iteration: VRC_GROUP indices, VRC_GROUP fetches issued back to back,
-     * then the group is composited in order (the compiler waits with a counted vmcnt before
-     * each use, so sample k is composited while fetches k+1.. are still in flight).  Nothing
-     * in the body is conditional, so there is nothing for the compiler to sink or hoist. */
+    /* all VRC_GROUP samples of a group are reached by the reference loop if more than
+     * VRC_GROUP steps remain (the sequentially rounded travel differs from the exact one by
+     * far less than one step) */
+    const float guard = stepSize * (float)( VRC_GROUP + 1 );
+    while( travel > guard )
+    {
+        uint32_t idx[VRC_GROUP];
+#pragma unroll
+        for( int k = 0; k < VRC_GROUP; ++k )
+        {
+            idx[k] = vrc_voxel_index< CLAMP >( sm, pos );
+            pos.x += s.step.x;
+            pos.y += s.step.y;
+            pos.z += s.step.z;
+            travel -= stepSize; /* same sequential subtraction as the reference */
+        }
+        vrc_f4 e[VRC_GROUP];
+#pragma unroll
+        for( int k = 0; k < VRC_GROUP; ++k )
+        {
+#if defined( VRC_ABLATE_NO_FETCH ) /* timing experiment only */
+            e[k] = lut[64u + ( idx[k] >> 31 )];
+#else
+            e[k] = lut[(uint32_t)atlas[idx[k]]];
+#endif
+        }
+        const vrc_f4 saved = color;
+#pragma unroll
+        for( int k = 0; k < VRC_GROUP; ++k )
+            vrc_composite( color, e[k] );
+        if( COUNT )
+            nSamples += VRC_GROUP;
+        if( color.w > VRC_EARLY_EXIT )
+        {
+            /* crossed inside this group: replay it with the reference's per-sample exit */
+            color = saved;
+            if( COUNT )
+                nSamples -= VRC_GROUP;
+#pragma unroll
+            for( int k = 0; k < VRC_GROUP; ++k )
+            {
+                vrc_composite( color, e[k], done );
+                if( COUNT )
+                    nSamples += done ? 0u : 1u;
+                done = done || ( color.w > VRC_EARLY_EXIT );
+            }
+            return true;
+        }
+    }
+
+    /* tail: general form */
     while( travel > 0.0f && !done )
     {
-        uint32_t idx[VRC_GROUP], d[VRC_GROUP], n = 0;
+        uint32_t idx[VRC_GROUP], d[VRC_GROUP], cnt = 0;
 #pragma unroll
         for( int k = 0; k < VRC_GROUP; ++k )
         {
             const bool v = travel > 0.0f;
-            n += v ? 1u : 0u;
+            cnt += v ? 1u : 0u;
             const uint32_t i = vrc_voxel_index< CLAMP >( sm, pos );
             idx[k] = v ? i : 0u;
             pos.x += s.step.x;
@@ -452,11 +513,15 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
 #pragma unroll
         for( int k = 0; k < VRC_GROUP; ++k )
             d[k] = (uint32_t)atlas[idx[k]];
+        vrc_f4 e[VRC_GROUP];
+#pragma unroll
+        for( int k = 0; k < VRC_GROUP; ++k )
+            e[k] = lut[(uint32_t)k < cnt ? d[k] : 256u];
 #pragma unroll
         for( int k = 0; k < VRC_GROUP; ++k )
         {
-            const bool active = ( (uint32_t)k < n ) && !done;
-            vrc_composite( color, lut[active ? d[k] : 256u] );
+            const bool active = ( (uint32_t)k < cnt ) && !done;
+            vrc_composite( color, e[k], done );
             if( COUNT )
                 nSamples += active ? 1u : 0u;
             done = done || ( color.w > VRC_EARLY_EXIT );

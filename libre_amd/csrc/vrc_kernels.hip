@@ -229,8 +229,11 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, hipStream
 /* ------------------------------------------------------------------------------------------
  * the raycast kernel
  * ---------------------------------------------------------------------------------------- */
+#ifndef VRC_MIN_WAVES
+#define VRC_MIN_WAVES 4
+#endif
 template < bool DDA, bool CLAMP, bool COUNT >
-__global__ __launch_bounds__( VRC_WG ) void vrc_k_raycast(
+__global__ __launch_bounds__( VRC_WG, VRC_MIN_WAVES ) void vrc_k_raycast(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ gridTable, const uint8_t* __restrict__ atlas,
     const vrc_f4* __restrict__ lutGlobal, vrc_f4* __restrict__ pixelBuffer,
@@ -254,8 +257,16 @@ __global__ __launch_bounds__( VRC_WG ) void vrc_k_raycast(
      * "Workgroup dispatch") every XCD gets the same mix and the long tiles start first. */
     const uint32_t tile = tileOrder ? tileOrder[blockIdx.x] : blockIdx.x;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
-    const uint32_t px = tx * VRC_TILE + ( lane & 7u );
-    const uint32_t py = ty * VRC_TILE + ( lane >> 3 );
+#if defined( VRC_LANES_ROWMAJOR )
+    const uint32_t lx = lane & 7u, ly = lane >> 3;
+#else
+    /* Morton lane order: every 4 consecutive lanes (the unit the texture addresser works on)
+     * are a 2x2 pixel quad, so their voxels usually share one 64-byte segment */
+    const uint32_t lx = ( lane & 1u ) | ( ( lane >> 1 ) & 2u ) | ( ( lane >> 2 ) & 4u );
+    const uint32_t ly = ( ( lane >> 1 ) & 1u ) | ( ( lane >> 2 ) & 2u ) | ( ( lane >> 3 ) & 4u );
+#endif
+    const uint32_t px = tx * VRC_TILE + lx;
+    const uint32_t py = ty * VRC_TILE + ly;
 
     uint32_t nSamples = 0;
     if( px < f.width && py < f.height )

@@ -63,7 +63,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("VRC_HIP_LIB") or LIB_PATH  # VRC_HIP_LIB: developer A/B builds
     if not os.path.exists(p):
         raise FileNotFoundError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
