@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric: Msamples/s (and frames/s) of the raycast hot path on a
+1024^3 uint8 mem:// volume at a 1024^2 viewport (configs[1], "C2"), on N MI355X of one node.
+
+One "step" = one frame: RenderPipeline("hip")::render with every brick resident in the HBM
+atlas (steady state; the first, uploading frame is reported separately and never timed), i.e.
+pre-render (clear) -> node-table/LUT reuse -> raycast kernel -> post-render.  The product path
+is C++ host (libre_amd/host) -> C ABI (include/vrc_hip.h) -> gfx950 kernels; Python only
+parses flags, barriers and prints.  N > 1: sort-first screen tiles, one process per GPU
+(torch.distributed over RCCL), every rank holds the whole volume, tiles are gathered to rank 0
+each frame inside the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is the HBM roofline of the raycast kernel with the
+algorithmic bytes of SURVEY.md 8(d); `cpu_baseline` times the CPU oracle (oracle/, "port") on a
+bounded sample of the same workload on the host cores (rank 0, N = 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--voxels", type=int, default=1024)
+    ap.add_argument("--block", type=int, default=128)
+    ap.add_argument("--viewport", type=int, default=1024)
+    ap.add_argument("--alpha", type=float, default=0.05, help="TF: rgba[i]=(i,i,i,alpha*i)/255")
+    ap.add_argument("--spin", type=float, nargs=2, default=(0.0, 0.0))
+    ap.add_argument("--bands", type=int, default=4, help="interleaved row bands per rank (N>1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-row-stride", type=int, default=8)
+    return ap.parse_args()
+
+
+def linear_ramp(alpha):
+    import numpy as np
+    i = np.arange(256, dtype=np.float32) / np.float32(255.0)
+    return np.ascontiguousarray(np.stack([i, i, i, np.float32(alpha) * i], axis=1))
+
+
+def band_layout(height, world, bands_per_rank):
+    """Sort-first decomposition into row bands: world*bands_per_rank equal bands, rank r takes
+    bands r, r+world, ... so every rank gets a mix of short-ray (top/bottom) and long-ray
+    (centre) rows.  Returns per rank a list of (y0, h)."""
+    nb = world * bands_per_rank if world > 1 else 1
+    edges = [round(height * k / nb) for k in range(nb + 1)]
+    out = [[] for _ in range(world)]
+    for b in range(nb):
+        out[b % world].append((edges[b], edges[b + 1] - edges[b]))
+    return out
+
+
+def cpu_baseline(a, samples_gpu_frame):
+    """Oracle (CPU port of the reference algorithm) on every `stride`-th row of the same frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import orc
+    s = orc.build_scene(voxels=(a.voxels,) * 3, block=a.block, viewport=(a.viewport,) * 2,
+                        alpha=a.alpha, spin=tuple(a.spin))
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    stride = max(1, a.cpu_row_stride)
+    t0 = time.perf_counter()
+    fb, n = orc.oracle_render(s, threads=cores, rows=(0, s.H, stride))
+    dt = time.perf_counter() - t0
+    del fb, np
+    return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "oracle/livre_oracle.c on every %d-th row of the same %dx%d frame "
+                      "(%d of ~%d samples, %.1f s)" % (stride, a.viewport, a.viewport, n,
+                                                        samples_gpu_frame, dt)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from libre_amd import driver, vrc
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W = H = a.viewport
+    uri = "mem://#%d,%d,%d,%d" % (a.voxels, a.voxels, a.voxels, a.block)
+    bands = band_layout(H, world, a.bands)[rank]
+    rows = sum(h for _, h in bands)
+    # per-rank framebuffer: this rank's bands, stacked (device memory owned by torch)
+    fb = torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream()
+
+    # leaves only: --min-lod = --max-lod = depth-1 (BASELINE.md "single LOD")
+    probe = driver.App(uri, W, H, device=local_rank)
+    depth = probe.volume_info()["depth"]
+    probe.close()
+    apps = []
+    off = 0
+    for (y0, h) in bands:
+        app = driver.App(uri, W, H, device=local_rank, tile=(0, y0, W, h), synchronous=True,
+                         min_lod=depth - 1, max_lod=depth - 1, gpu_cache_mb=3072)
+        app.set_camera(spin=tuple(a.spin))
+        app.set_colormap(linear_ramp(a.alpha))
+        app.set_stream(stream.cuda_stream)
+        app.set_framebuffer(fb.data_ptr() + off * W * 16)
+        apps.append(app)
+        off += h
+
+    counts = [rows]
+    if world > 1:
+        counts = [sum(h for _, h in b) for b in band_layout(H, world, a.bands)]
+        gathered = [torch.empty((c, W, 4), dtype=torch.float32, device="cuda") for c in counts] \
+            if rank == 0 else None
+
+    equal_tiles = world > 1 and len(set(counts)) == 1
+
+    def frame():
+        for app in apps:
+            app.render_frame(readback=False)
+        if world > 1:  # sort-first assembly: per-tile RGBA to the display rank over RCCL/xGMI
+            if equal_tiles:
+                dist.gather(fb, gathered, dst=0)
+            elif rank == 0:
+                gathered[0].copy_(fb)
+                reqs = [dist.irecv(gathered[r], src=r) for r in range(1, world)]
+                for q in reqs:
+                    q.wait()
+            else:
+                dist.send(fb, dst=0)
+
+    # first frame: uploads every brick through the 2-thread upload path (not timed below)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frame()
+    torch.cuda.synchronize()
+    first_frame_ms = (time.perf_counter() - t0) * 1e3
+
+    # samples per frame (deterministic for a fixed view): one counted frame, outside the timing
+    for app in apps:
+        app.set_option(vrc.OPT_COUNT_SAMPLES, 1)
+    samples = 0
+    for app in apps:
+        app.render_frame(readback=False)
+        samples += app.stats().samples
+    for app in apps:
+        app.set_option(vrc.OPT_COUNT_SAMPLES, 0)
+    st = torch.tensor([samples], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(st)
+    samples_frame = int(st.item())
+
+    for _ in range(a.warmup):
+        frame()
+    for app in apps:
+        app.stats()  # reset the kernel-time accumulators
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        frame()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+
+    # HIP-event kernel time of the timed region (events recorded on the render stream)
+    ksum, klaunch = 0.0, 0
+    for app in apps:
+        s = app.stats()
+        ksum += s.kernel_ms_sum
+        klaunch += s.kernel_launches
+    kt = torch.tensor([ksum], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+    kernel_ms_per_frame = float(kt.item()) / a.steps  # slowest rank's kernels per frame
+
+    if rank == 0:
+        n_nodes = (a.voxels // a.block) ** 3
+        # interior voxels of marched bricks + one RGBA32F write + node table + TF.
+        # With N ranks every rank marches (nearly) every brick for its rows: bricks count N times.
+        alg_bytes = world * (a.voxels ** 3 + n_nodes * 48 + 4096) + W * H * 16
+        per_rank_alg = a.voxels ** 3 + n_nodes * 48 + 4096 + rows * W * 16
+        achieved = per_rank_alg / (kernel_ms_per_frame * 1e-3) / 1e9
+        out = {
+            "metric": "Msamples/s + frames/s, 1024^3 volume @ 1024^2 viewport",
+            "value": samples_frame * a.steps / dt / 1e6,
+            "unit": "Msamples/s",
+            "frames_per_s": a.steps / dt,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u8 voxels, f32 compositing",
+            "data": "synthetic (mem:// rule of datasources/memory/MemoryDataSource.cpp:54-57)",
+            "config": {"workload": "C2: %s uint8, %dx%d viewport, leaves only (%d bricks of %d^3), "
+                                   "%d samples/ray, linear-ramp TF alpha=%.3g, default camera"
+                                   % (uri, W, H, n_nodes, a.block + 8,
+                                      apps[0].stats().samples_per_ray, a.alpha),
+                       "parallelism": "sort-first, %d rank(s) x %d interleaved row band(s), "
+                                      "RGBA32F gather to rank 0" % (world, len(bands)),
+                       "samples_per_frame": samples_frame,
+                       "first_frame_with_upload_ms": first_frame_ms},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "vrc_k_raycast<true,false,false>",
+                         "kernel_ms_per_frame": kernel_ms_per_frame,
+                         "algorithmic_bytes_per_launch": per_rank_alg / max(1, len(bands)),
+                         "algorithmic_bytes_per_frame_all_ranks": alg_bytes,
+                         "launches_per_frame": len(bands),
+                         "note": "the kernel is VALU-issue bound, not HBM bound (DESIGN.md); "
+                                 "traffic: see profiles/ (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a, samples_frame)
+        print(json.dumps(out), flush=True)
+
+    for app in apps:
+        app.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,90 @@
+/*
+ * livre_hip_driver.h -- flat C entry points of libLivreHipRaycastPipeline.so for hosts that are
+ * not C++ (the Python bench and tests bind them with ctypes).  It is the headless stand-in for
+ * what apps/livre + livre/eq do around the plugin: open the data source (livre/eq/Node.cpp:51-77),
+ * create the RenderPipeline by renderer name (livre/eq/Window.cpp:59-63), build RenderInputs per
+ * frame and call RenderPipeline::render (livre/eq/Channel.cpp:259-308).  Everything below the
+ * call is the C++ plugin surface (libre_amd/host) and the device C ABI (vrc_hip.h).
+ */
+#ifndef LIVRE_HIP_DRIVER_H
+#define LIVRE_HIP_DRIVER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lvh_app lvh_app;
+
+/* rendererParameters.fbs:4-13 + ApplicationParameters.cpp:52-61 defaults when a field is 0 /
+ * negative as documented */
+typedef struct
+{
+    int device;                 /* HIP device of this process */
+    uint32_t width, height;     /* full frame */
+    uint32_t tile[4];           /* x, y, w, h of this process' sort-first tile; w = 0 -> full frame */
+    int synchronous;            /* --synchronous */
+    uint32_t samples_per_ray;   /* --samples-per-ray, 0 = auto */
+    uint32_t min_lod, max_lod;  /* --min-lod / --max-lod; max_lod 0 -> 9 (default) */
+    float sse;                  /* --sse, 0 -> 4.0 */
+    uint32_t gpu_cache_mb;      /* --gpu-cache-mem, 0 -> 3072 */
+    uint32_t cpu_cache_mb;      /* --cpu-cache-mem, 0 -> 8192 */
+} lvh_params;
+
+typedef struct
+{
+    uint64_t n_available, n_not_available, n_render_available; /* RenderStatistics */
+    uint32_t n_passes;
+    float kernel_ms;   /* HIP-event time of the last raycast kernel */
+    uint64_t samples;  /* composited samples of the last kernel when counting is on */
+    uint32_t samples_per_ray;
+    double kernel_ms_sum;     /* raycast kernel time summed over the launches since the last */
+    uint32_t kernel_launches; /* lvh_app_get_stats call (HIP events on the render stream)   */
+} lvh_frame_stats;
+
+const char* lvh_last_error( void );
+/* volume_uri: mem://#x,y,z,block | raw://file.raw#x,y,z,type | hash://#x,y,z,block ;
+ * renderer: "hip" (PluginFactory: unknown name -> error "No plugin implementation available") */
+int lvh_app_create( const char* volume_uri, const char* renderer, const lvh_params* params,
+                    lvh_app** out );
+void lvh_app_destroy( lvh_app* app );
+/* camera: ApplicationParameters camera-position / camera-lookat, CameraSettings::spinModel */
+int lvh_app_set_camera( lvh_app* app, const float position[3], const float lookat[3],
+                        float spin_x, float spin_y );
+int lvh_app_set_modelview( lvh_app* app, const float mv[16] );
+int lvh_app_set_colormap( lvh_app* app, const float rgba256[1024] );
+int lvh_app_set_clip_planes( lvh_app* app, const float* planes, uint32_t n );
+int lvh_app_set_option( lvh_app* app, int vrc_option, int64_t value );
+/* render on a caller-owned stream / into caller-owned device memory (tile gather) */
+int lvh_app_set_stream( lvh_app* app, void* hip_stream );
+int lvh_app_set_framebuffer( lvh_app* app, void* device_rgba );
+/* one frame: Channel::frameDraw. host_rgba may be NULL (frame stays in HBM). */
+int lvh_app_render_frame( lvh_app* app, float* host_rgba, lvh_frame_stats* stats );
+int lvh_app_get_stats( lvh_app* app, lvh_frame_stats* stats ); /* kernel_ms/samples after sync */
+int lvh_app_wait_uploads( lvh_app* app );
+int lvh_app_synchronize( lvh_app* app );
+/* introspection used by the parity tests */
+int lvh_app_volume_info( lvh_app* app, uint32_t voxels[3], uint32_t max_block[3],
+                         uint32_t overlap[3], float world_size[3], uint32_t* depth,
+                         uint32_t root_blocks[3] );
+int lvh_app_visible_set( lvh_app* app, uint64_t* ids, size_t capacity, size_t* n );
+int lvh_app_view_matrices( lvh_app* app, float mv[16], float proj[16] );
+int lvh_app_cache_stats( lvh_app* app, uint64_t tex[4], uint64_t data[4] ); /* used, max, count, misses */
+/* standalone LOD cut with explicit matrices (tests/lib/lodSelection.cpp harness) */
+int lvh_select_visibles( const char* volume_uri, const float mv[16], const float proj[16],
+                         uint32_t window_height, float sse, uint32_t min_lod, uint32_t max_lod,
+                         uint64_t* ids, size_t capacity, size_t* n );
+/* host-only checks of the mirrored classes (no GPU): returns 0 when all pass, else the number
+ * of the first failing check; message via lvh_last_error */
+int lvh_selftest_cache( void );
+int lvh_selftest_plugin_factory( void );
+int lvh_selftest_camera( float out_matrices[4][16] );
+int lvh_datasource_brick( const char* volume_uri, uint64_t node_id, uint8_t* out, size_t capacity,
+                          size_t* n );
+
+#ifdef __cplusplus
+}
+#endif
+#endif

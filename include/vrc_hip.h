@@ -76,6 +76,8 @@ typedef struct
     uint64_t samples;       /* samples composited by the last vrc_render (0 if counting is off) */
     uint32_t kernel_variant; /* which kernel ran: VRC_KERNEL_* */
     uint32_t grid_dims[3];  /* brick-grid dims used by the DDA kernel (0 if not used) */
+    double kernel_ms_sum;   /* sum of HIP-event times of the raycast kernels launched since ... */
+    uint32_t kernel_launches; /* ... the previous vrc_get_stats call, and how many they were */
 } vrc_stats;
 
 /* ---- options (vrc_set_option) ---------------------------------------------------------- */

@@ -42,7 +42,9 @@ constexpr int kStagingSlots = 4;
 
 struct vrc_pool
 {
-    vrc_ctx* ctx = nullptr;
+    vrc_ctx* ctx = nullptr; /* creating context (device identification only) */
+    int device = 0;
+    uint64_t uid = 0;       /* unique per process, keys the node-table caches of contexts */
     uint32_t elemBytes = 1;
     uint32_t maxBlock[3] = { 0, 0, 0 };
     uint32_t slotDim[3] = { 0, 0, 0 }; /* maxBlock rounded up to the micro-block size */
@@ -102,7 +104,7 @@ struct vrc_ctx
     void* hStage = nullptr; /* pinned staging for nodes + grid */
     size_t hStageCap = 0;
     std::vector< vrc_node_data > cachedNodes;
-    const vrc_pool* cachedPool = nullptr;
+    uint64_t cachedPoolUid = 0;
     bool cachedGridOk = false;
     bool cachedClamp = false;
     vrc_frame cachedGridFrame; /* only grid* fields are meaningful */
@@ -117,7 +119,9 @@ struct vrc_ctx
     unsigned long long* dCounter = nullptr;
     unsigned long long* hCounter = nullptr; /* pinned */
 
-    hipEvent_t evStart = nullptr, evStop = nullptr;
+    /* one event pair per raycast launch since the last vrc_get_stats (ring, grows on demand) */
+    std::vector< std::pair< hipEvent_t, hipEvent_t > > evPairs;
+    size_t evUsed = 0;
     bool timed = false;
 
     int64_t optKernel = VRC_KERNEL_AUTO;
@@ -152,8 +156,6 @@ int vrc_ctx_create( int device, vrc_ctx** out )
     if( e == hipSuccess ) e = hipMalloc( &c->dLut, 257 * sizeof( vrc_f4 ) );
     if( e == hipSuccess ) e = hipMalloc( &c->dCounter, sizeof( unsigned long long ) );
     if( e == hipSuccess ) e = hipHostMalloc( &c->hCounter, sizeof( unsigned long long ) );
-    if( e == hipSuccess ) e = hipEventCreate( &c->evStart );
-    if( e == hipSuccess ) e = hipEventCreate( &c->evStop );
     if( e != hipSuccess )
     {
         const std::string msg = std::string( "vrc_ctx_create: " ) + hipGetErrorString( e );
@@ -195,8 +197,11 @@ void vrc_ctx_destroy( vrc_ctx* c )
     if( c->dTileOrder ) (void)hipFree( c->dTileOrder );
     if( c->dCounter ) (void)hipFree( c->dCounter );
     if( c->hCounter ) (void)hipHostFree( c->hCounter );
-    if( c->evStart ) (void)hipEventDestroy( c->evStart );
-    if( c->evStop ) (void)hipEventDestroy( c->evStop );
+    for( auto& pr : c->evPairs )
+    {
+        (void)hipEventDestroy( pr.first );
+        (void)hipEventDestroy( pr.second );
+    }
     if( c->ownStream ) (void)hipStreamDestroy( c->ownStream );
     delete c;
 }
@@ -275,8 +280,15 @@ int vrc_pool_create( vrc_ctx* c, size_t bytesPerVoxel, int isSigned, int isFloat
         return fail( VRC_EINVAL, "vrc_pool_create: zero block size" );
     VRC_HIP_CHECK( hipSetDevice( c->device ) );
 
+    static std::mutex uidMutex;
+    static uint64_t nextUid = 1;
     vrc_pool* p = new vrc_pool();
     p->ctx = c;
+    p->device = c->device;
+    {
+        std::lock_guard< std::mutex > lock( uidMutex );
+        p->uid = nextUid++;
+    }
     p->elemBytes = (uint32_t)( bytesPerVoxel * nComponents );
     for( int a = 0; a < 3; ++a )
     {
@@ -353,14 +365,9 @@ void vrc_pool_destroy( vrc_pool* p )
 {
     if( !p )
         return;
-    (void)hipSetDevice( p->ctx->device );
-    if( p->uploadStream ) (void)hipStreamSynchronize( p->uploadStream );
-    if( p->ctx->cachedPool == p )
-    {
-        (void)hipStreamSynchronize( p->ctx->stream );
-        p->ctx->cachedPool = nullptr;
-        p->ctx->cachedNodes.clear();
-    }
+    /* the caller guarantees no context is still rendering from this pool */
+    (void)hipSetDevice( p->device );
+    (void)hipDeviceSynchronize();
     for( int s = 0; s < kStagingSlots; ++s )
     {
         if( p->staging[s].pinned ) (void)hipHostFree( p->staging[s].pinned );
@@ -413,7 +420,7 @@ static int pool_upload( vrc_pool* p, const void* src, bool srcIsDevice, const ui
     int rc = pool_check_size( p, size );
     if( rc != VRC_OK )
         return rc;
-    VRC_HIP_CHECK( hipSetDevice( p->ctx->device ) );
+    VRC_HIP_CHECK( hipSetDevice( p->device ) );
     float slot[3];
     rc = pool_take_slot( p, slot );
     if( rc != VRC_OK )
@@ -531,7 +538,7 @@ int vrc_pool_synchronize( vrc_pool* p )
 {
     if( !p )
         return fail( VRC_EINVAL, "vrc_pool_synchronize: pool is NULL" );
-    VRC_HIP_CHECK( hipSetDevice( p->ctx->device ) );
+    VRC_HIP_CHECK( hipSetDevice( p->device ) );
     VRC_HIP_CHECK( hipStreamSynchronize( p->uploadStream ) );
     return VRC_OK;
 }
@@ -544,7 +551,7 @@ int vrc_pool_read_region( vrc_pool* p, const uint32_t origin[3], const uint32_t 
     for( int a = 0; a < 3; ++a )
         if( (uint64_t)origin[a] + size[a] > p->atlasDim[a] )
             return fail( VRC_EINVAL, "vrc_pool_read_region: region outside the atlas" );
-    VRC_HIP_CHECK( hipSetDevice( p->ctx->device ) );
+    VRC_HIP_CHECK( hipSetDevice( p->device ) );
     const size_t bytes = (size_t)size[0] * size[1] * size[2] * p->elemBytes;
     if( bytes == 0 )
         return VRC_OK;
@@ -714,8 +721,8 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         return fail( VRC_EINVAL, "vrc_render: NULL argument" );
     if( nNodes > 0 && !nodes )
         return fail( VRC_EINVAL, "vrc_render: nodes is NULL" );
-    if( pool->ctx != c )
-        return fail( VRC_EINVAL, "vrc_render: pool belongs to another context" );
+    if( pool->device != c->device )
+        return fail( VRC_EINVAL, "vrc_render: pool lives on another device" );
     if( !ctx_fb( c ) || c->fbW == 0 )
         return fail( VRC_EINVAL, "vrc_render: vrc_pre_render has not been called" );
     if( view->glViewport[2] != c->fbW || view->glViewport[3] != c->fbH )
@@ -745,7 +752,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
 
     /* node table + grid, re-derived and re-uploaded only when the node list changed
      * (the reference re-uploads synchronously every pass, Renderer.cu:259-267) */
-    const bool sameNodes = c->cachedPool == pool && c->cachedNodes.size() == nNodes &&
+    const bool sameNodes = c->cachedPoolUid == pool->uid && c->cachedNodes.size() == nNodes &&
                            std::memcmp( c->cachedNodes.data(), nodes,
                                         nNodes * sizeof( vrc_node_data ) ) == 0;
     if( !sameNodes )
@@ -776,7 +783,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
                 hipMemcpyAsync( c->dGrid, h + nb, gb, hipMemcpyHostToDevice, c->stream ) );
         }
         c->cachedNodes.assign( nodes, nodes + nNodes );
-        c->cachedPool = pool;
+        c->cachedPoolUid = pool->uid;
         c->cachedGridOk = t.gridOk;
         c->cachedClamp = t.clamp;
         c->cachedGridFrame = t.g;
@@ -845,9 +852,22 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     }
     if( c->optCount )
         VRC_HIP_CHECK( hipMemsetAsync( c->dCounter, 0, sizeof( unsigned long long ), c->stream ) );
-    VRC_HIP_CHECK( hipEventRecord( c->evStart, c->stream ) );
+    if( c->evUsed == c->evPairs.size() )
+    {
+        if( c->evPairs.size() >= 4096 ) /* nobody is reading the timings: start over */
+            c->evUsed = 0;
+        else
+        {
+            hipEvent_t a0 = nullptr, a1 = nullptr;
+            VRC_HIP_CHECK( hipEventCreate( &a0 ) );
+            VRC_HIP_CHECK( hipEventCreate( &a1 ) );
+            c->evPairs.push_back( { a0, a1 } );
+        }
+    }
+    const auto& evp = c->evPairs[c->evUsed++];
+    VRC_HIP_CHECK( hipEventRecord( evp.first, c->stream ) );
     VRC_HIP_CHECK( vrc_launch_raycast( a, c->stream ) );
-    VRC_HIP_CHECK( hipEventRecord( c->evStop, c->stream ) );
+    VRC_HIP_CHECK( hipEventRecord( evp.second, c->stream ) );
     if( c->optCount )
         VRC_HIP_CHECK( hipMemcpyAsync( c->hCounter, c->dCounter, sizeof( unsigned long long ),
                                        hipMemcpyDeviceToHost, c->stream ) );
@@ -889,12 +909,20 @@ int vrc_get_stats( vrc_ctx* c, vrc_stats* out )
     if( !c || !out )
         return fail( VRC_EINVAL, "vrc_get_stats: NULL argument" );
     VRC_HIP_CHECK( hipSetDevice( c->device ) );
-    if( c->timed )
+    c->stats.kernel_ms_sum = 0.0;
+    c->stats.kernel_launches = 0;
+    if( c->timed && c->evUsed > 0 )
     {
-        VRC_HIP_CHECK( hipEventSynchronize( c->evStop ) );
+        VRC_HIP_CHECK( hipEventSynchronize( c->evPairs[c->evUsed - 1].second ) );
         float ms = 0.f;
-        VRC_HIP_CHECK( hipEventElapsedTime( &ms, c->evStart, c->evStop ) );
-        c->stats.kernel_ms = ms;
+        for( size_t i = 0; i < c->evUsed; ++i )
+        {
+            VRC_HIP_CHECK( hipEventElapsedTime( &ms, c->evPairs[i].first, c->evPairs[i].second ) );
+            c->stats.kernel_ms_sum += ms;
+        }
+        c->stats.kernel_launches = (uint32_t)c->evUsed;
+        c->stats.kernel_ms = ms; /* the last launch */
+        c->evUsed = 0;
         if( c->optCount )
         {
             VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );

@@ -1,0 +1,253 @@
+/*
+ * cache.h -- CacheObject, CacheStatistics, thread-safe LRU Cache<T>, DataObject.
+ * Mirrors livre/core/cache/{CacheObject.h,Cache.h,Cache.ipp,CacheStatistics.h} and
+ * livre/lib/cache/DataObject.h of the reference.
+ */
+#ifndef LIVRE_HIP_CACHE_H
+#define LIVRE_HIP_CACHE_H
+
+#include <deque>
+#include <exception>
+#include <sstream>
+
+#include "data.h"
+
+namespace livre
+{
+/** livre/core/cache/CacheObject.h:32-44 */
+class CacheLoadException : public std::exception
+{
+public:
+    CacheLoadException( const Identifier& id, const std::string& message )
+    {
+        std::stringstream s;
+        s << "Id: " << id << " " << message;
+        _message = s.str();
+    }
+    const char* what() const throw() { return _message.c_str(); }
+
+private:
+    std::string _message;
+};
+
+/** livre/core/cache/CacheObject.h:49-74 */
+class CacheObject
+{
+public:
+    virtual ~CacheObject() {}
+    virtual size_t getSize() const = 0;
+    CacheId getId() const { return _cacheId; }
+    virtual bool operator==( const CacheObject& o ) const { return _cacheId == o._cacheId; }
+
+protected:
+    explicit CacheObject( const CacheId& cacheId = INVALID_CACHE_ID ) : _cacheId( cacheId ) {}
+
+private:
+    CacheId _cacheId;
+};
+typedef std::shared_ptr< CacheObject > CacheObjectPtr;
+typedef std::shared_ptr< const CacheObject > ConstCacheObjectPtr;
+typedef std::vector< ConstCacheObjectPtr > ConstCacheObjects;
+typedef std::vector< CacheId > CacheIds;
+typedef std::unordered_map< CacheId, ConstCacheObjectPtr > ConstCacheMap;
+
+/** livre/core/cache/CacheStatistics.h:34-109 */
+class CacheStatistics
+{
+public:
+    CacheStatistics( const std::string& name, size_t maxMemBytes )
+        : _name( name ), _usedMemBytes( 0 ), _maxMemBytes( maxMemBytes ), _objCount( 0 ),
+          _cacheHit( 0 ), _cacheMiss( 0 ) {}
+    size_t getBlockCount() const { return _objCount; }
+    size_t getUsedMemory() const { return _usedMemBytes; }
+    size_t getMaximumMemory() const { return _maxMemBytes; }
+    std::string getName() const { return _name; }
+    size_t getHits() const { return _cacheHit; }
+    size_t getMisses() const { return _cacheMiss; }
+    void notifyMiss() { ++_cacheMiss; }
+    void notifyHit() { ++_cacheHit; }
+    void notifyLoaded( const CacheObject& o ) { ++_objCount; _usedMemBytes += o.getSize(); }
+    void notifyUnloaded( const CacheObject& o ) { --_objCount; _usedMemBytes -= o.getSize(); }
+    void clear() { _usedMemBytes = 0; _objCount = 0; _cacheHit = 0; _cacheMiss = 0; }
+
+private:
+    std::string _name;
+    size_t _usedMemBytes;
+    const size_t _maxMemBytes;
+    size_t _objCount, _cacheHit, _cacheMiss;
+};
+
+/** livre/core/cache/Cache.h:38-101 + Cache.ipp.  LRU by load order; an object is evicted only
+ *  when nobody outside the cache holds it (Cache.ipp:207-220: use_count() <= 2 counting the
+ *  map's reference and the local copy). */
+template < class CacheObjectT > class Cache
+{
+public:
+    typedef std::shared_ptr< const CacheObjectT > ObjectPtr;
+
+    Cache( const std::string& name, size_t maxMemBytes )
+        : _maxMemBytes( maxMemBytes ), _statistics( name, maxMemBytes ) {}
+
+    ObjectPtr get( const CacheId& cacheId ) const
+    {
+        std::shared_lock< std::shared_timed_mutex > lock( _mutex );
+        const auto it = _cacheMap.find( cacheId );
+        return it == _cacheMap.end() ? ObjectPtr() : it->second->obj;
+    }
+
+    /** Cache.ipp:146-195: create-if-absent; constructor runs outside the map lock, under the
+     *  entry's own lock, so concurrent loads of the same id construct once and of different
+     *  ids run in parallel; a CacheLoadException yields an empty pointer (Cache.ipp:98-115). */
+    template < class... Args > ObjectPtr load( const CacheId& cacheId, Args&&... args )
+    {
+        if( cacheId == INVALID_CACHE_ID )
+            return ObjectPtr();
+        std::shared_ptr< Entry > entry;
+        {
+            std::unique_lock< std::shared_timed_mutex > lock( _mutex );
+            auto it = _cacheMap.find( cacheId );
+            if( it == _cacheMap.end() )
+                it = _cacheMap.emplace( cacheId, std::make_shared< Entry >() ).first;
+            entry = it->second;
+            if( entry->obj )
+            {
+                _statistics.notifyHit();
+                return entry->obj;
+            }
+            applyPolicy();
+        }
+        ObjectPtr obj;
+        bool constructed = false;
+        {
+            std::lock_guard< std::mutex > elock( entry->mutex );
+            if( !entry->obj )
+            {
+                try
+                {
+                    entry->obj.reset( new CacheObjectT( cacheId, args... ) );
+                    constructed = true;
+                }
+                catch( const CacheLoadException& )
+                {
+                }
+            }
+            obj = entry->obj;
+        }
+        std::unique_lock< std::shared_timed_mutex > lock( _mutex );
+        if( obj )
+        {
+            if( constructed )
+            {
+                _statistics.notifyMiss();
+                _statistics.notifyLoaded( *obj );
+                lruInsert( cacheId );
+                applyPolicy();
+            }
+        }
+        else
+        {
+            const auto it = _cacheMap.find( cacheId );
+            if( it != _cacheMap.end() && !it->second->obj )
+                _cacheMap.erase( it );
+        }
+        return obj;
+    }
+
+    /** Cache.ipp:222-240 */
+    bool unload( const CacheId& cacheId )
+    {
+        std::unique_lock< std::shared_timed_mutex > lock( _mutex );
+        return unloadLocked( cacheId );
+    }
+
+    size_t getCount() const
+    {
+        std::shared_lock< std::shared_timed_mutex > lock( _mutex );
+        return _cacheMap.size();
+    }
+    const CacheStatistics& getStatistics() const { return _statistics; }
+
+    void purge()
+    {
+        std::unique_lock< std::shared_timed_mutex > lock( _mutex );
+        _statistics.clear();
+        _lru.clear();
+        _cacheMap.clear();
+    }
+    void purge( const CacheId& cacheId )
+    {
+        std::unique_lock< std::shared_timed_mutex > lock( _mutex );
+        _cacheMap.erase( cacheId );
+    }
+
+private:
+    struct Entry
+    {
+        std::mutex mutex;
+        ObjectPtr obj;
+    };
+
+    void lruInsert( const CacheId& id )
+    {
+        lruRemove( id );
+        _lru.push_back( id );
+    }
+    void lruRemove( const CacheId& id )
+    {
+        for( auto it = _lru.begin(); it != _lru.end(); ++it )
+            if( *it == id )
+            {
+                _lru.erase( it );
+                return;
+            }
+    }
+    bool unloadLocked( const CacheId& cacheId )
+    {
+        const auto it = _cacheMap.find( cacheId );
+        if( it == _cacheMap.end() )
+            return false;
+        const ObjectPtr obj = it->second->obj; /* +1 reference, as in Cache.ipp:212 */
+        if( !obj || obj.use_count() > 2 )      /* still loading or referenced outside */
+            return false;
+        lruRemove( cacheId );
+        _statistics.notifyUnloaded( *obj );
+        _cacheMap.erase( it );
+        return true;
+    }
+    /** Cache.ipp:132-144: when used >= max, unload in LRU order until used < max */
+    void applyPolicy()
+    {
+        if( _cacheMap.empty() || _statistics.getUsedMemory() < _maxMemBytes )
+            return;
+        const std::deque< CacheId > ids = _lru;
+        for( const CacheId& id : ids )
+        {
+            unloadLocked( id );
+            if( _statistics.getUsedMemory() < _maxMemBytes )
+                return;
+        }
+    }
+
+    const size_t _maxMemBytes;
+    CacheStatistics _statistics;
+    mutable std::shared_timed_mutex _mutex;
+    std::unordered_map< CacheId, std::shared_ptr< Entry > > _cacheMap;
+    std::deque< CacheId > _lru;
+};
+
+/** livre/lib/cache/DataObject.h:31-60: a brick in CPU memory */
+class DataObject : public CacheObject
+{
+public:
+    DataObject( const CacheId& cacheId, DataSource& dataSource );
+    size_t getSize() const final { return _data->getAllocSize(); }
+    const void* getDataPtr() const { return _data->getData< void >(); }
+    size_t getMemSize() const { return _data->getMemSize(); }
+
+private:
+    ConstMemoryUnitPtr _data;
+};
+typedef std::shared_ptr< const DataObject > ConstDataObjectPtr;
+typedef Cache< DataObject > DataCache;
+}
+#endif

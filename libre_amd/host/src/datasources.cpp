@@ -1,0 +1,298 @@
+/* datasources.cpp -- the DataSourcePlugin implementations the path is fed by:
+ *   mem://  datasources/memory/MemoryDataSource.cpp (synthetic, constant value per brick)
+ *   raw://  datasources/raw/RawDataSource.cpp       (mmap'd file, one brick = whole volume)
+ *   hash:// build-defined seeded-noise volume ("Volume N" of SURVEY 8d), bricked like mem://
+ * Registered at load time through static PluginRegisterer objects, as the reference does
+ * (MemoryDataSource.cpp:46, RawDataSource.cpp:50). */
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+
+#include "livre_hip/data.h"
+
+namespace livre
+{
+namespace
+{
+std::vector< std::string > split( const std::string& s, char sep )
+{
+    std::vector< std::string > out;
+    std::stringstream ss( s );
+    std::string item;
+    while( std::getline( ss, item, sep ) )
+        out.push_back( item );
+    return out;
+}
+
+bool endsWith( const std::string& s, const std::string& suffix )
+{
+    return s.size() >= suffix.size() && s.compare( s.size() - suffix.size(), suffix.size(), suffix ) == 0;
+}
+
+uint32_t toUint( const std::string& s )
+{
+    size_t pos = 0;
+    const unsigned long v = std::stoul( s, &pos );
+    if( pos != s.size() )
+        throw std::runtime_error( "bad lexical cast: " + s );
+    return uint32_t( v );
+}
+}
+
+/* ---- mem:// -------------------------------------------------------------------------------- */
+class MemoryDataSource : public DataSourcePlugin
+{
+public:
+    explicit MemoryDataSource( const DataSourcePluginData& initData );
+    MemoryUnitPtr getData( const LODNode& node ) final;
+    static bool handles( const DataSourcePluginData& initData )
+    {
+        return initData.getURI().getScheme() == "mem"; /* MemoryDataSource.cpp:164-167 */
+    }
+
+private:
+    float _sparsity;
+};
+
+/* MemoryDataSource.cpp:48-72 */
+template < typename T >
+static MemoryUnitPtr computeData( const LODNode& node, size_t dataSize, float sparsity, size_t nVoxels )
+{
+    const Identifier nodeId = node.getNodeId().getId();
+    const uint8_t* id = reinterpret_cast< const uint8_t* >( &nodeId );
+    const T value = T( ( id[0] ^ id[1] ^ id[2] ^ id[3] ) + 16 +
+                       127 * std::sin( ( float( node.getNodeId().getTimeStep() ) + 1 ) / 200.f ) );
+    std::shared_ptr< AllocMemoryUnit > memoryUnit( new AllocMemoryUnit( dataSize ) );
+    T* dst = memoryUnit->getData< T >();
+    for( size_t i = 0; i < nVoxels; ++i )
+    {
+        if( sparsity < 1.f )
+        {
+            const int32_t random = rand() % 1000000 + 1;
+            dst[i] = random < 1000000.0f * sparsity ? value : T( 0 );
+        }
+        else
+            dst[i] = value;
+    }
+    return memoryUnit;
+}
+
+/* MemoryDataSource.cpp:74-131 */
+MemoryDataSource::MemoryDataSource( const DataSourcePluginData& initData ) : _sparsity( 1.0f )
+{
+    _volumeInfo.overlap = Vector3ui( 4 );
+    const URI& uri = initData.getURI();
+    const std::vector< std::string > parameters = split( uri.getFragment(), ',' );
+    std::string v;
+    try
+    {
+        if( uri.findQuery( "sparsity", v ) )
+            _sparsity = std::stof( v );
+        if( !uri.findQuery( "datatype", v ) || v == "uint8" ) _volumeInfo.dataType = DT_UINT8;
+        else if( v == "uint16" ) _volumeInfo.dataType = DT_UINT16;
+        else if( v == "uint32" ) _volumeInfo.dataType = DT_UINT32;
+        else if( v == "int8" || v == "char" ) _volumeInfo.dataType = DT_INT8;
+        else if( v == "int16" || v == "short" ) _volumeInfo.dataType = DT_INT16;
+        else if( v == "int32" ) _volumeInfo.dataType = DT_INT32;
+        else if( v == "float" ) _volumeInfo.dataType = DT_FLOAT;
+
+        if( parameters.size() < 4 ) /* defaults */
+        {
+            _volumeInfo.voxels = Vector3ui( 4096 );
+            _volumeInfo.maximumBlockSize = Vector3ui( 32 ) + _volumeInfo.overlap * 2u;
+        }
+        else
+        {
+            _volumeInfo.voxels[0] = toUint( parameters[0] );
+            _volumeInfo.voxels[1] = toUint( parameters[1] );
+            _volumeInfo.voxels[2] = toUint( parameters[2] );
+            _volumeInfo.maximumBlockSize = Vector3ui( toUint( parameters[3] ) ) + _volumeInfo.overlap * 2u;
+        }
+    }
+    catch( const std::exception& e )
+    {
+        throw std::runtime_error( e.what() );
+    }
+    _volumeInfo.frameRange = FULL_FRAME_RANGE;
+    if( !fillRegularVolumeInfo( _volumeInfo ) )
+        throw std::runtime_error( "Cannot setup the regular tree" );
+}
+
+/* MemoryDataSource.cpp:137-162 */
+MemoryUnitPtr MemoryDataSource::getData( const LODNode& node )
+{
+    const Vector3ui blockSize = node.getBlockSize() + _volumeInfo.overlap * 2u;
+    const size_t nVoxels = size_t( blockSize[0] ) * blockSize[1] * blockSize[2];
+    const size_t dataSize = nVoxels * _volumeInfo.compCount * _volumeInfo.getBytesPerVoxel();
+    switch( _volumeInfo.dataType )
+    {
+    case DT_UINT8: return computeData< uint8_t >( node, dataSize, _sparsity, nVoxels );
+    case DT_UINT16: return computeData< uint16_t >( node, dataSize, _sparsity, nVoxels );
+    case DT_UINT32: return computeData< uint32_t >( node, dataSize, _sparsity, nVoxels );
+    case DT_INT8: return computeData< int8_t >( node, dataSize, _sparsity, nVoxels );
+    case DT_INT16: return computeData< int16_t >( node, dataSize, _sparsity, nVoxels );
+    case DT_INT32: return computeData< int32_t >( node, dataSize, _sparsity, nVoxels );
+    case DT_FLOAT: return computeData< float >( node, dataSize, _sparsity, nVoxels );
+    default: throw std::runtime_error( "Unimplemented data type." );
+    }
+}
+
+/* ---- hash:// (build-defined): v(x,y,z) = lowbias32(x + vx*(y + vy*z) + seed) >> 24, 3-tap box
+ * per axis with wrap-around, at the finest level; coarser levels sample every 2^k-th voxel.
+ * Same URI fragment and tree as mem://. -------------------------------------------------------- */
+class HashDataSource : public DataSourcePlugin
+{
+public:
+    explicit HashDataSource( const DataSourcePluginData& initData )
+    {
+        _volumeInfo.overlap = Vector3ui( 4 );
+        const std::vector< std::string > p = split( initData.getURI().getFragment(), ',' );
+        if( p.size() < 4 )
+            throw std::runtime_error( "hash://#x,y,z,block expected" );
+        _volumeInfo.voxels = Vector3ui( toUint( p[0] ), toUint( p[1] ), toUint( p[2] ) );
+        _volumeInfo.maximumBlockSize = Vector3ui( toUint( p[3] ) ) + _volumeInfo.overlap * 2u;
+        _seed = p.size() > 4 ? toUint( p[4] ) : 0x5EEDu;
+        _volumeInfo.dataType = DT_UINT8;
+        _volumeInfo.frameRange = FULL_FRAME_RANGE;
+        fillRegularVolumeInfo( _volumeInfo );
+    }
+    static bool handles( const DataSourcePluginData& d ) { return d.getURI().getScheme() == "hash"; }
+
+    static uint32_t hash32( uint32_t h )
+    {
+        h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+        return h;
+    }
+    float raw( int64_t x, int64_t y, int64_t z ) const
+    {
+        const int64_t vx = _volumeInfo.voxels[0], vy = _volumeInfo.voxels[1], vz = _volumeInfo.voxels[2];
+        x = ( x % vx + vx ) % vx; y = ( y % vy + vy ) % vy; z = ( z % vz + vz ) % vz;
+        const uint64_t idx = uint64_t( x ) + uint64_t( vx ) * ( uint64_t( y ) + uint64_t( vy ) * uint64_t( z ) );
+        return float( hash32( uint32_t( ( idx + _seed ) & 0xFFFFFFFFull ) ) >> 24 );
+    }
+    uint8_t voxel( int64_t x, int64_t y, int64_t z ) const
+    {
+        /* separable 3-tap box with wrap-around, filtered along z, then y, then x, each pass
+         * ((prev + cur) + next) / 3 in float32 -- the order tests/orc.py:hash_volume uses */
+        float fy[3];
+        for( int dx = -1; dx <= 1; ++dx )
+        {
+            float fz[3];
+            for( int dy = -1; dy <= 1; ++dy )
+                fz[dy + 1] = ( ( raw( x + dx, y + dy, z - 1 ) + raw( x + dx, y + dy, z ) ) +
+                               raw( x + dx, y + dy, z + 1 ) ) / 3.0f;
+            fy[dx + 1] = ( ( fz[0] + fz[1] ) + fz[2] ) / 3.0f;
+        }
+        const float v = std::floor( ( ( fy[0] + fy[1] ) + fy[2] ) / 3.0f );
+        return uint8_t( v < 0.f ? 0.f : ( v > 255.f ? 255.f : v ) );
+    }
+    MemoryUnitPtr getData( const LODNode& node ) final
+    {
+        const Vector3ui bs = node.getBlockSize() + _volumeInfo.overlap * 2u;
+        std::shared_ptr< AllocMemoryUnit > mem( new AllocMemoryUnit( size_t( bs[0] ) * bs[1] * bs[2] ) );
+        uint8_t* dst = mem->getData< uint8_t >();
+        const uint32_t shift = _volumeInfo.rootNode.getDepth() - 1 - node.getRefLevel();
+        const Vector3ui o = node.getVoxelBox().getMin();
+        const Vector3ui vox = _volumeInfo.voxels;
+        for( uint32_t z = 0; z < bs[2]; ++z )
+            for( uint32_t y = 0; y < bs[1]; ++y )
+                for( uint32_t x = 0; x < bs[0]; ++x )
+                {
+                    /* clamp at the volume border, like a bricking tool does */
+                    int64_t gx = ( int64_t( o[0] ) + x - _volumeInfo.overlap[0] ) << shift;
+                    int64_t gy = ( int64_t( o[1] ) + y - _volumeInfo.overlap[1] ) << shift;
+                    int64_t gz = ( int64_t( o[2] ) + z - _volumeInfo.overlap[2] ) << shift;
+                    gx = gx < 0 ? 0 : ( gx > int64_t( vox[0] ) - 1 ? int64_t( vox[0] ) - 1 : gx );
+                    gy = gy < 0 ? 0 : ( gy > int64_t( vox[1] ) - 1 ? int64_t( vox[1] ) - 1 : gy );
+                    gz = gz < 0 ? 0 : ( gz > int64_t( vox[2] ) - 1 ? int64_t( vox[2] ) - 1 : gz );
+                    dst[( size_t( z ) * bs[1] + y ) * bs[0] + x] = voxel( gx, gy, gz );
+                }
+        return mem;
+    }
+
+private:
+    uint32_t _seed;
+};
+
+/* ---- raw:// : datasources/raw/RawDataSource.cpp:56-129 ------------------------------------- */
+class RawDataSource : public DataSourcePlugin
+{
+public:
+    explicit RawDataSource( const DataSourcePluginData& initData ) : _mmapPtr( nullptr ), _fd( -1 ), _size( 0 )
+    {
+        const URI& uri = initData.getURI();
+        const std::string& path = uri.getPath();
+        if( !endsWith( path, ".raw" ) && !endsWith( path, ".img" ) )
+            throw std::runtime_error( "Volume extension does not include raw or nrrd" );
+        _fd = ::open( path.c_str(), O_RDONLY );
+        struct stat sb;
+        if( _fd == -1 || ::fstat( _fd, &sb ) == -1 )
+            throw std::runtime_error( "Cannot mmap file" );
+        _size = size_t( sb.st_size );
+        _mmapPtr = ::mmap( nullptr, _size, PROT_READ, MAP_PRIVATE, _fd, 0 );
+        if( _mmapPtr == MAP_FAILED )
+        {
+            ::close( _fd );
+            _mmapPtr = nullptr;
+            throw std::runtime_error( "Cannot mmap file" );
+        }
+        const std::vector< std::string > p = split( uri.getFragment(), ',' );
+        if( p.size() < 4 )
+            throw std::runtime_error( "Not enough parameters for the raw file" );
+        _volumeInfo.voxels = Vector3ui( toUint( p[0] ), toUint( p[1] ), toUint( p[2] ) );
+        setDataType( p[3] );
+        _volumeInfo.frameRange = Vector2ui( 0u, 1u );
+        _volumeInfo.compCount = 1;
+        _volumeInfo.worldSpacePerVoxel = 1.0f / float( _volumeInfo.voxels.find_max() );
+        _volumeInfo.worldSize = Vector3f( float( _volumeInfo.voxels[0] ), float( _volumeInfo.voxels[1] ),
+                                          float( _volumeInfo.voxels[2] ) ) * _volumeInfo.worldSpacePerVoxel;
+        _volumeInfo.overlap = Vector3ui( 0u );
+        _volumeInfo.rootNode = RootNode( 1, Vector3ui( 1 ) ); /* one brick = whole volume, depth 1 */
+        _volumeInfo.maximumBlockSize = _volumeInfo.voxels;
+        if( size_t( _volumeInfo.voxels.product() ) * _volumeInfo.getBytesPerVoxel() > _size )
+            throw std::runtime_error( "raw file smaller than the declared volume" );
+    }
+    ~RawDataSource()
+    {
+        if( _mmapPtr ) ::munmap( _mmapPtr, _size );
+        if( _fd != -1 ) ::close( _fd );
+    }
+    static bool handles( const DataSourcePluginData& d ) { return d.getURI().getScheme() == "raw"; }
+    MemoryUnitPtr getData( const LODNode& node ) final
+    {
+        /* RawDataSource.cpp:123-129 reports blockSize.product() bytes whatever the voxel type
+         * (quirk Q14); here the size includes bytes per voxel */
+        const size_t dataSize = size_t( node.getBlockSize().product() ) * _volumeInfo.getBytesPerVoxel();
+        return MemoryUnitPtr( new ConstMemoryUnit( static_cast< const uint8_t* >( _mmapPtr ), dataSize ) );
+    }
+
+private:
+    void setDataType( const std::string& t )
+    {
+        if( t == "char" || t == "int8" ) _volumeInfo.dataType = DT_INT8;
+        else if( t == "unsigned char" || t == "uint8" ) _volumeInfo.dataType = DT_UINT8;
+        else if( t == "short" || t == "int16" ) _volumeInfo.dataType = DT_INT16;
+        else if( t == "unsigned short" || t == "uint16" ) _volumeInfo.dataType = DT_UINT16;
+        else if( t == "int" || t == "int32" ) _volumeInfo.dataType = DT_INT32;
+        else if( t == "unsigned int" || t == "uint32" ) _volumeInfo.dataType = DT_UINT32;
+        else if( t == "float" ) _volumeInfo.dataType = DT_FLOAT;
+        else throw std::runtime_error( "Not supported data format" );
+    }
+    void* _mmapPtr;
+    int _fd;
+    size_t _size;
+};
+
+namespace
+{
+PluginRegisterer< MemoryDataSource, const DataSourcePluginData& > memRegisterer;
+PluginRegisterer< RawDataSource, const DataSourcePluginData& > rawRegisterer;
+PluginRegisterer< HashDataSource, const DataSourcePluginData& > hashRegisterer;
+}
+}

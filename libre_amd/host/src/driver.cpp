@@ -1,0 +1,453 @@
+/* driver.cpp -- implementation of include/livre_hip_driver.h (headless apps/livre + livre/eq
+ * Channel::frameDraw around the plugin surface). */
+#include "livre_hip_driver.h"
+
+#include <cstring>
+
+#include "livre_hip/hip.h"
+
+using namespace livre;
+
+namespace
+{
+thread_local std::string g_error;
+int fail( const std::string& m )
+{
+    g_error = m;
+    return 1;
+}
+const float nearPlane = 0.1f; /* livre/eq/Channel.cpp:61-62 */
+const float farPlane = 15.0f;
+}
+
+struct lvh_app
+{
+    std::unique_ptr< DataSource > dataSource;
+    std::unique_ptr< RenderPipeline > pipeline;
+    lvh_params params;
+    CameraSettings camera;
+    RenderSettings renderSettings;
+    RendererParameters vrParameters;
+    uint32_t frameId = 0;
+    RenderStatistics lastStats;
+
+    HipRaycastRenderer& renderer()
+    {
+        return static_cast< HipRaycastRenderer& >( pipeline->getRenderer().getPlugin() );
+    }
+    HipRaycastPipeline& hipPipeline() { return static_cast< HipRaycastPipeline& >( pipeline->getPlugin() ); }
+
+    void tile( uint32_t t[4] ) const
+    {
+        if( params.tile[2] == 0 || params.tile[3] == 0 )
+        {
+            t[0] = t[1] = 0;
+            t[2] = params.width;
+            t[3] = params.height;
+        }
+        else
+            std::memcpy( t, params.tile, sizeof( params.tile ) );
+    }
+
+    /* Channel::setupFrustum (livre/eq/Channel.cpp:151-164): the channel's sub-frustum of the
+     * wall frustum l/r/b/t = -/+0.05 at near 0.1 */
+    Matrix4f projection() const
+    {
+        uint32_t t[4];
+        tile( t );
+        const float l = -0.05f, r = 0.05f, b = -0.05f, tp = 0.05f;
+        const float W = float( params.width ), H = float( params.height );
+        const float tl = l + ( r - l ) * float( t[0] ) / W;
+        const float tr = l + ( r - l ) * float( t[0] + t[2] ) / W;
+        const float tb = b + ( tp - b ) * float( t[1] ) / H;
+        const float tt = b + ( tp - b ) * float( t[1] + t[3] ) / H;
+        return perspectiveFrustum( tl, tr, tb, tt, nearPlane, farPlane );
+    }
+
+    RenderInputs inputs()
+    {
+        uint32_t t[4];
+        tile( t );
+        const Frustum frustum( camera.getModelViewMatrix(), projection() );
+        return RenderInputs{ FrameInfo( frustum, 0, frameId ),
+                             Range{ { 0.0f, 1.0f } },
+                             Vector2f( 0.0f, 255.0f ), /* hard-coded at Channel.cpp:284 */
+                             PixelViewport( 0, 0, int32_t( t[2] ), int32_t( t[3] ) ),
+                             Viewport( float( t[0] ) / params.width, float( t[1] ) / params.height,
+                                       float( t[2] ) / params.width, float( t[3] ) / params.height ),
+                             renderSettings,
+                             vrParameters,
+                             nullptr,
+                             *dataSource };
+    }
+};
+
+extern "C" {
+
+const char* lvh_last_error( void ) { return g_error.c_str(); }
+
+int lvh_app_create( const char* uri, const char* rendererName, const lvh_params* p, lvh_app** out )
+{
+    if( !uri || !rendererName || !p || !out )
+        return fail( "lvh_app_create: NULL argument" );
+    *out = nullptr;
+    try
+    {
+        std::unique_ptr< lvh_app > app( new lvh_app() );
+        app->params = *p;
+        if( p->width == 0 || p->height == 0 )
+            return fail( "lvh_app_create: empty frame" );
+        setHipDevice( p->device );
+        app->dataSource.reset( new DataSource( std::string( uri ) ) );
+        app->pipeline.reset( new RenderPipeline( rendererName ) );
+        RendererParameters& v = app->vrParameters;
+        v.synchronousMode = p->synchronous != 0;
+        v.samplesPerRay = p->samples_per_ray;
+        v.minLOD = p->min_lod;
+        if( p->max_lod ) v.maxLOD = p->max_lod;
+        if( p->sse > 0.f ) v.screenSpaceError = p->sse;
+        if( p->gpu_cache_mb ) v.maxGPUCacheMemoryMB = p->gpu_cache_mb;
+        if( p->cpu_cache_mb ) v.maxCPUCacheMemoryMB = p->cpu_cache_mb;
+        /* ApplicationParameters.cpp:54-55 + Config: position then look-at */
+        app->camera.setCameraPosition( Vector3f( 0.f, 0.f, 1.5f ) );
+        app->camera.setCameraLookAt( Vector3f( 0.f, 0.f, 0.f ) );
+        *out = app.release();
+        return 0;
+    }
+    catch( const std::exception& e )
+    {
+        return fail( e.what() );
+    }
+}
+
+void lvh_app_destroy( lvh_app* app ) { delete app; }
+
+int lvh_app_set_camera( lvh_app* app, const float pos[3], const float lookat[3], float sx, float sy )
+{
+    if( !app || !pos || !lookat ) return fail( "NULL argument" );
+    app->camera = CameraSettings();
+    app->camera.setCameraPosition( Vector3f( pos[0], pos[1], pos[2] ) );
+    app->camera.setCameraLookAt( Vector3f( lookat[0], lookat[1], lookat[2] ) );
+    app->camera.spinModel( sx, sy );
+    return 0;
+}
+
+int lvh_app_set_modelview( lvh_app* app, const float mv[16] )
+{
+    if( !app || !mv ) return fail( "NULL argument" );
+    app->camera.setModelViewMatrix( Matrix4f( mv, mv + 16 ) );
+    return 0;
+}
+
+int lvh_app_set_colormap( lvh_app* app, const float rgba[1024] )
+{
+    if( !app || !rgba ) return fail( "NULL argument" );
+    app->renderSettings.getColorMap().setSamples( rgba );
+    return 0;
+}
+
+int lvh_app_set_clip_planes( lvh_app* app, const float* planes, uint32_t n )
+{
+    if( !app || ( n && !planes ) ) return fail( "NULL argument" );
+    app->renderSettings.getClipPlanes().clear();
+    for( uint32_t i = 0; i < n; ++i )
+        app->renderSettings.getClipPlanes().addPlane(
+            Vector4f( planes[i * 4], planes[i * 4 + 1], planes[i * 4 + 2], planes[i * 4 + 3] ) );
+    return 0;
+}
+
+#define LVH_TRY( stmt )                   \
+    try                                   \
+    {                                     \
+        stmt;                             \
+        return 0;                         \
+    }                                     \
+    catch( const std::exception& e )      \
+    {                                     \
+        return fail( e.what() );          \
+    }
+
+int lvh_app_set_option( lvh_app* app, int option, int64_t value )
+{
+    if( !app ) return fail( "NULL argument" );
+    LVH_TRY( app->renderer().setOption( option, value ) )
+}
+int lvh_app_set_stream( lvh_app* app, void* s )
+{
+    if( !app ) return fail( "NULL argument" );
+    LVH_TRY( app->renderer().setStream( s ) )
+}
+int lvh_app_set_framebuffer( lvh_app* app, void* d )
+{
+    if( !app ) return fail( "NULL argument" );
+    uint32_t t[4];
+    app->tile( t );
+    LVH_TRY( app->renderer().setFrameBuffer( d, t[2], t[3] ) )
+}
+
+static void fillStats( lvh_app* app, lvh_frame_stats* s, bool sync )
+{
+    std::memset( s, 0, sizeof( *s ) );
+    s->n_available = app->lastStats.nAvailable;
+    s->n_not_available = app->lastStats.nNotAvailable;
+    s->n_render_available = app->lastStats.nRenderAvailable;
+    s->n_passes = app->hipPipeline().lastNumberOfPasses();
+    s->samples_per_ray = app->renderer().getComputedSamplesPerRay();
+    if( sync )
+        app->renderer().kernelStats( &s->kernel_ms, &s->kernel_ms_sum, &s->kernel_launches, &s->samples );
+}
+
+int lvh_app_render_frame( lvh_app* app, float* host, lvh_frame_stats* stats )
+{
+    if( !app ) return fail( "NULL argument" );
+    try
+    {
+        const RenderInputs in = app->inputs();
+        app->lastStats = app->pipeline->render( in );
+        ++app->frameId;
+        if( host )
+            app->renderer().readFrame( host );
+        if( stats )
+            fillStats( app, stats, false );
+        return 0;
+    }
+    catch( const std::exception& e )
+    {
+        return fail( e.what() );
+    }
+}
+
+int lvh_app_get_stats( lvh_app* app, lvh_frame_stats* stats )
+{
+    if( !app || !stats ) return fail( "NULL argument" );
+    LVH_TRY( fillStats( app, stats, true ) )
+}
+int lvh_app_wait_uploads( lvh_app* app )
+{
+    if( !app ) return fail( "NULL argument" );
+    LVH_TRY( app->hipPipeline().waitForUploads() )
+}
+int lvh_app_synchronize( lvh_app* app )
+{
+    if( !app ) return fail( "NULL argument" );
+    LVH_TRY( app->renderer().synchronize() )
+}
+
+int lvh_app_volume_info( lvh_app* app, uint32_t voxels[3], uint32_t maxBlock[3], uint32_t overlap[3],
+                         float worldSize[3], uint32_t* depth, uint32_t rootBlocks[3] )
+{
+    if( !app ) return fail( "NULL argument" );
+    const VolumeInformation& v = app->dataSource->getVolumeInfo();
+    for( int i = 0; i < 3; ++i )
+    {
+        if( voxels ) voxels[i] = v.voxels[i];
+        if( maxBlock ) maxBlock[i] = v.maximumBlockSize[i];
+        if( overlap ) overlap[i] = v.overlap[i];
+        if( worldSize ) worldSize[i] = v.worldSize[i];
+        if( rootBlocks ) rootBlocks[i] = v.rootNode.getBlockSize()[i];
+    }
+    if( depth ) *depth = v.rootNode.getDepth();
+    return 0;
+}
+
+static int copyIds( const NodeIds& ids, uint64_t* out, size_t cap, size_t* n )
+{
+    if( n ) *n = ids.size();
+    if( out )
+        for( size_t i = 0; i < ids.size() && i < cap; ++i )
+            out[i] = ids[i].getId();
+    return 0;
+}
+
+int lvh_app_visible_set( lvh_app* app, uint64_t* ids, size_t cap, size_t* n )
+{
+    if( !app ) return fail( "NULL argument" );
+    try
+    {
+        const RenderInputs in = app->inputs();
+        const RendererParameters& p = in.vrParameters;
+        SelectVisibles visitor( in.dataSource, in.frameInfo.frustum, uint32_t( in.pixelViewPort[3] ),
+                                p.getSSE(), p.getMinLOD(), p.getMaxLOD(), in.renderDataRange,
+                                in.renderSettings.getClipPlanes() );
+        DFSTraversal traverser;
+        traverser.traverse( in.dataSource.getVolumeInfo().rootNode, visitor, 0 );
+        return copyIds( visitor.getVisibles(), ids, cap, n );
+    }
+    catch( const std::exception& e )
+    {
+        return fail( e.what() );
+    }
+}
+
+int lvh_app_view_matrices( lvh_app* app, float mv[16], float proj[16] )
+{
+    if( !app ) return fail( "NULL argument" );
+    if( mv ) std::memcpy( mv, app->camera.getModelViewMatrix().array, 64 );
+    if( proj ) std::memcpy( proj, app->projection().array, 64 );
+    return 0;
+}
+
+int lvh_app_cache_stats( lvh_app* app, uint64_t tex[4], uint64_t data[4] )
+{
+    if( !app ) return fail( "NULL argument" );
+    const CacheStatistics* t = app->hipPipeline().textureCacheStatistics();
+    const CacheStatistics* d = app->hipPipeline().dataCacheStatistics();
+    if( tex && t ) { tex[0] = t->getUsedMemory(); tex[1] = t->getMaximumMemory(); tex[2] = t->getBlockCount(); tex[3] = t->getMisses(); }
+    if( data && d ) { data[0] = d->getUsedMemory(); data[1] = d->getMaximumMemory(); data[2] = d->getBlockCount(); data[3] = d->getMisses(); }
+    return ( t && d ) ? 0 : fail( "caches not created yet" );
+}
+
+int lvh_select_visibles( const char* uri, const float mv[16], const float proj[16], uint32_t windowHeight,
+                         float sse, uint32_t minLOD, uint32_t maxLOD, uint64_t* ids, size_t cap, size_t* n )
+{
+    try
+    {
+        DataSource dataSource{ std::string( uri ) };
+        const Frustum frustum( Matrix4f( mv, mv + 16 ), Matrix4f( proj, proj + 16 ) );
+        ClipPlanes planes; /* tests/lib/lodSelection.cpp:52: default-constructed = six planes */
+        SelectVisibles visitor( dataSource, frustum, windowHeight, sse, minLOD, maxLOD,
+                                Range{ { 0.0f, 1.0f } }, planes );
+        DFSTraversal traverser;
+        traverser.traverse( dataSource.getVolumeInfo().rootNode, visitor, 0 );
+        return copyIds( visitor.getVisibles(), ids, cap, n );
+    }
+    catch( const std::exception& e )
+    {
+        return fail( e.what() );
+    }
+}
+
+/* tests/core/cache.cpp:33-75 restated against the mirrored Cache<T> */
+namespace
+{
+class ValidCacheObject : public CacheObject
+{
+public:
+    explicit ValidCacheObject( const CacheId& id ) : CacheObject( id ) {}
+    size_t getSize() const final { return 1000; }
+};
+}
+
+int lvh_selftest_cache( void )
+{
+#define CHECK( n, cond ) if( !( cond ) ) { fail( "cache selftest: " #cond ); return n; }
+    Cache< ValidCacheObject > cache( "Test Cache", 2048u );
+    CHECK( 1, cache.getCount() == 0 );
+    CHECK( 2, cache.getStatistics().getMaximumMemory() == 2048u );
+    CHECK( 3, !cache.get( 1 ) );
+    ConstCacheObjectPtr obj = cache.load( 1 );
+    size_t size = obj->getSize();
+    CHECK( 4, cache.getStatistics().getUsedMemory() == size );
+    obj = cache.load( 2 );
+    CHECK( 5, obj && cache.getCount() == 2 && obj->getId() == 2 && obj.use_count() == 2 );
+    size += obj->getSize();
+    CHECK( 6, cache.getStatistics().getUsedMemory() == size );
+    obj = cache.load( 1 );
+    CHECK( 7, obj && cache.getCount() == 2 && obj->getId() == 1 && obj.use_count() == 2 );
+    CHECK( 8, cache.getStatistics().getUsedMemory() == size );
+    obj.reset();
+    ConstCacheObjectPtr trigger = cache.load( 3 );
+    CHECK( 9, trigger && cache.getCount() == 2 && trigger->getId() == 3 && trigger.use_count() == 2 );
+    CHECK( 10, cache.getStatistics().getUsedMemory() == size );
+    /* a referenced object is never evicted */
+    ConstCacheObjectPtr held = cache.load( 4 );
+    ConstCacheObjectPtr held2 = cache.load( 5 );
+    CHECK( 11, cache.get( 3 ) && cache.get( 4 ) && cache.get( 5 ) ); /* all referenced: over budget, kept */
+    cache.purge();
+    CHECK( 12, cache.getCount() == 0 && cache.getStatistics().getUsedMemory() == 0 );
+    CHECK( 13, !cache.load( INVALID_CACHE_ID ) );
+    return 0;
+}
+
+/* tests/core/pluginFactory.cpp:115-203: no plugin -> runtime_error; first handles()==true wins */
+namespace
+{
+struct TestPlugin
+{
+    typedef TestPlugin PluginT;
+    explicit TestPlugin( const int& v ) : value( v ) {}
+    virtual ~TestPlugin() {}
+    virtual int id() const = 0;
+    int value;
+};
+struct PluginA : TestPlugin
+{
+    explicit PluginA( const int& v ) : TestPlugin( v ) {}
+    static bool handles( const int& v ) { return v < 10; }
+    int id() const final { return 1; }
+};
+struct PluginB : TestPlugin
+{
+    explicit PluginB( const int& v ) : TestPlugin( v ) {}
+    static bool handles( const int& v ) { return v < 100; }
+    int id() const final { return 2; }
+};
+}
+
+int lvh_selftest_plugin_factory( void )
+{
+    typedef PluginFactory< TestPlugin, const int& > Factory;
+    Factory& f = Factory::getInstance();
+    f.deregisterAll();
+    try { f.create( 1 ); fail( "factory created without plugins" ); return 1; }
+    catch( const std::runtime_error& ) {}
+    {
+        PluginRegisterer< PluginA, const int& > a;
+        PluginRegisterer< PluginB, const int& > b;
+        std::unique_ptr< TestPlugin > p( f.create( 5 ) );
+        CHECK( 2, p->id() == 1 && p->value == 5 );
+        p.reset( f.create( 50 ) );
+        CHECK( 3, p->id() == 2 );
+        try { f.create( 500 ); fail( "factory created for unhandled data" ); return 4; }
+        catch( const std::runtime_error& ) {}
+    }
+    f.deregisterAll();
+    /* the renderer registry: unknown name throws, "hip" is registered by this library */
+    try { Renderer r( "no-such-renderer" ); fail( "unknown renderer accepted" ); return 5; }
+    catch( const std::runtime_error& ) {}
+    CHECK( 6, HipRaycastRenderer::handles( "hip" ) && !HipRaycastRenderer::handles( "cuda" ) );
+    return 0;
+#undef CHECK
+}
+
+/* tests/eq/settings/cameraSettings.cpp:42-144 cases: spin, lookat, everything, default app view */
+int lvh_selftest_camera( float out[4][16] )
+{
+    CameraSettings a;
+    a.spinModel( 20.0f, 20.0f );
+    std::memcpy( out[0], a.getModelViewMatrix().array, 64 );
+    CameraSettings b;
+    b.setCameraLookAt( Vector3f( 20.0f, 20.0f, 20.0f ) );
+    std::memcpy( out[1], b.getModelViewMatrix().array, 64 );
+    CameraSettings c;
+    c.setCameraPosition( Vector3f( 0.5f, 1.17f, 6.78f ) );
+    c.setCameraLookAt( Vector3f( 13.52f, 123.53f, 21.12f ) );
+    c.spinModel( 13.54f, 21.49f );
+    c.moveCamera( 13.54f, 21.49f, 33.25f );
+    std::memcpy( out[2], c.getModelViewMatrix().array, 64 );
+    CameraSettings d;
+    d.setCameraPosition( Vector3f( 0.f, 0.f, 1.5f ) );
+    d.setCameraLookAt( Vector3f( 0.f, 0.f, 0.f ) );
+    std::memcpy( out[3], d.getModelViewMatrix().array, 64 );
+    return 0;
+}
+
+int lvh_datasource_brick( const char* uri, uint64_t nodeId, uint8_t* out, size_t cap, size_t* n )
+{
+    try
+    {
+        DataSource dataSource{ std::string( uri ) };
+        const ConstMemoryUnitPtr mem = dataSource.getData( NodeId( nodeId ) );
+        if( !mem )
+            return fail( "no data for node" );
+        if( n ) *n = mem->getMemSize();
+        if( out )
+            std::memcpy( out, mem->getData< uint8_t >(), std::min( cap, mem->getMemSize() ) );
+        return 0;
+    }
+    catch( const std::exception& e )
+    {
+        return fail( e.what() );
+    }
+}
+}

@@ -1,0 +1,651 @@
+/* hip_plugin.cpp -- HipTexturePool, HipTextureObject, HipRaycastRenderer, HipRaycastPipeline:
+ * the host plugin of the MI355X raycaster.  Follows the renderers/cudaRaycaster sources of the
+ * reference function by function (citations inline); device work is the C ABI of vrc_hip.h. */
+#include "livre_hip/hip.h"
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <queue>
+#include <thread>
+
+#include "vrc_hip.h"
+
+extern "C" int LunchboxPluginGetVersion() { return 1; } /* LIVRECORE_VERSION_ABI, CudaRaycastPipeline.cpp:50-51 */
+extern "C" bool LunchboxPluginRegister() { return true; } /* CudaRaycastPipeline.cpp:53-54 */
+
+namespace livre
+{
+namespace
+{
+const Vector3f INVALID_SLOT_POSITION( -1.0f ); /* CudaTextureObject.cpp:36-39 */
+const uint32_t maxSamplesPerRay = 32;  /* CudaRaycastRenderer.cpp:65 (the opacity-correction reference) */
+const uint32_t minSamplesPerRay = 512; /* CudaRaycastRenderer.cpp:66 */
+const uint32_t SH_UINT = 0u, SH_INT = 1u, SH_FLOAT = 2u;
+const size_t nUploadThreads = 2;      /* CudaRaycastPipeline.cpp:60-63 */
+const size_t nAsyncUploadThreads = 1;
+
+PluginRegisterer< HipRaycastRenderer, const std::string& > rendererRegisterer;
+PluginRegisterer< HipRaycastPipeline, const std::string& > pipelineRegisterer;
+
+std::atomic< int > g_device( 0 );
+std::mutex g_deviceMutex;
+vrc_ctx* g_deviceCtx = nullptr; /* context the pools are created on */
+
+vrc_ctx* deviceContext()
+{
+    std::lock_guard< std::mutex > lock( g_deviceMutex );
+    if( !g_deviceCtx )
+        throwOnVrcError( vrc_ctx_create( g_device.load(), &g_deviceCtx ), "vrc_ctx_create" );
+    return g_deviceCtx;
+}
+
+/** std::thread stand-in for tuyau::PushExecutor: n workers draining a task queue */
+class Executor
+{
+public:
+    explicit Executor( size_t nThreads ) : _stop( false ), _busy( 0 )
+    {
+        for( size_t i = 0; i < nThreads; ++i )
+            _threads.emplace_back( [this] { run(); } );
+    }
+    ~Executor()
+    {
+        {
+            std::lock_guard< std::mutex > lock( _mutex );
+            _stop = true;
+        }
+        _cv.notify_all();
+        for( std::thread& t : _threads )
+            t.join();
+    }
+    void schedule( std::function< void() > task )
+    {
+        {
+            std::lock_guard< std::mutex > lock( _mutex );
+            _tasks.push( std::move( task ) );
+        }
+        _cv.notify_one();
+    }
+    void wait()
+    {
+        std::unique_lock< std::mutex > lock( _mutex );
+        _idle.wait( lock, [this] { return _tasks.empty() && _busy == 0; } );
+    }
+
+private:
+    void run()
+    {
+        for( ;; )
+        {
+            std::function< void() > task;
+            {
+                std::unique_lock< std::mutex > lock( _mutex );
+                _cv.wait( lock, [this] { return _stop || !_tasks.empty(); } );
+                if( _stop && _tasks.empty() )
+                    return;
+                task = std::move( _tasks.front() );
+                _tasks.pop();
+                ++_busy;
+            }
+            try { task(); } catch( ... ) {}
+            {
+                std::lock_guard< std::mutex > lock( _mutex );
+                --_busy;
+            }
+            _idle.notify_all();
+        }
+    }
+    std::vector< std::thread > _threads;
+    std::queue< std::function< void() > > _tasks;
+    std::mutex _mutex;
+    std::condition_variable _cv, _idle;
+    bool _stop;
+    size_t _busy;
+};
+
+/** CudaRaycastRenderer.cpp:41-61 / CudaRaycastPipeline.cpp:107-127: |MV * box centre| */
+float nodeDistance( const DataSource& dataSource, const Frustum& frustum, const NodeId& id )
+{
+    const LODNode lodNode = dataSource.getNode( id );
+    return ( frustum.getMVMatrix() * lodNode.getWorldBox().getCenter() ).length();
+}
+}
+
+void throwOnVrcError( int rc, const char* what )
+{
+    if( rc != VRC_OK )
+        throw std::runtime_error( std::string( what ) + ": " + vrc_last_error() );
+}
+
+void setHipDevice( int device ) { g_device = device; }
+int getHipDevice() { return g_device; }
+
+/* ---- HipTexturePool: CudaTexturePool.cpp:31-122 --------------------------------------------- */
+HipTexturePool::HipTexturePool( const DataSource& dataSource, size_t textureMemory )
+    : _ctx( deviceContext() ), _pool( nullptr )
+{
+    const VolumeInformation& volInfo = dataSource.getVolumeInfo();
+    bool isSigned = false, isFloat = false;
+    switch( volInfo.dataType )
+    {
+    case DT_UINT8: case DT_UINT16: case DT_UINT32: break;
+    case DT_INT8: case DT_INT16: case DT_INT32: isSigned = true; break;
+    case DT_FLOAT: isFloat = true; break;
+    case DT_UNDEFINED:
+    default: throw std::runtime_error( "Undefined data type" );
+    }
+    const uint32_t maxBlock[3] = { volInfo.maximumBlockSize[0], volInfo.maximumBlockSize[1],
+                                   volInfo.maximumBlockSize[2] };
+    throwOnVrcError( vrc_pool_create( _ctx, volInfo.getBytesPerVoxel(), isSigned, isFloat,
+                                      volInfo.compCount, maxBlock, textureMemory, &_pool ),
+                     "vrc_pool_create" );
+}
+
+HipTexturePool::~HipTexturePool() { vrc_pool_destroy( _pool ); }
+
+Vector3f HipTexturePool::copyToSlot( const unsigned char* ptr, const Vector3ui& size )
+{
+    const uint32_t s[3] = { size[0], size[1], size[2] };
+    float slot[3];
+    const int rc = vrc_pool_copy_to_slot( _pool, ptr, s, slot );
+    if( rc == VRC_EFULL )
+        return INVALID_SLOT_POSITION; /* TexturePool.cu:180-181 */
+    throwOnVrcError( rc, "vrc_pool_copy_to_slot" );
+    return Vector3f( slot[0], slot[1], slot[2] );
+}
+
+void HipTexturePool::releaseSlot( const Vector3f& pos )
+{
+    const float slot[3] = { pos[0], pos[1], pos[2] };
+    vrc_pool_release_slot( _pool, slot );
+}
+
+size_t HipTexturePool::getSlotMemSize() const
+{
+    size_t slotBytes = 0;
+    vrc_pool_info( _pool, &slotBytes, nullptr, nullptr, nullptr, nullptr );
+    return slotBytes;
+}
+
+Vector3ui HipTexturePool::getTextureSize() const
+{
+    uint32_t dim[3];
+    vrc_pool_info( _pool, nullptr, dim, nullptr, nullptr, nullptr );
+    return Vector3ui( dim[0], dim[1], dim[2] );
+}
+
+size_t HipTexturePool::getTextureMem() const
+{
+    size_t atlasBytes = 0;
+    vrc_pool_info( _pool, nullptr, nullptr, &atlasBytes, nullptr, nullptr );
+    return atlasBytes;
+}
+
+/* ---- HipTextureObject: CudaTextureObject.cpp:41-125 ----------------------------------------- */
+HipTextureObject::HipTextureObject( const CacheId& cacheId, const DataCache& dataCache,
+                                    const DataSource& dataSource, HipTexturePool& pool )
+    : CacheObject( cacheId ), _size( 0 ), _texturePool( pool ), _slotPosition( INVALID_SLOT_POSITION )
+{
+    /* CudaTextureObject.cpp:61-84 */
+    const ConstDataObjectPtr data = dataCache.get( cacheId );
+    if( !data )
+        throw CacheLoadException( cacheId, "Unable to construct texture cache object" );
+    const VolumeInformation& volInfo = dataSource.getVolumeInfo();
+    _size = _texturePool.getSlotMemSize();
+    const LODNode lodNode = dataSource.getNode( NodeId( cacheId ) );
+    _slotPosition = _texturePool.copyToSlot( static_cast< const uint8_t* >( data->getDataPtr() ),
+                                             lodNode.getBlockSize() + volInfo.overlap * 2u );
+    if( _slotPosition == INVALID_SLOT_POSITION )
+        throw CacheLoadException( cacheId, "Unable to construct texture cache object" );
+    const Vector3f cacheTextureSize( _texturePool.getTextureSize() );
+    const Vector3f overlap( volInfo.overlap );
+    const Vector3f size( lodNode.getVoxelBox().getSize() );
+    const Vector3f overlapf = overlap / cacheTextureSize;
+    _texturePos = _slotPosition + overlapf;
+    _textureSize = size / cacheTextureSize;
+}
+
+HipTextureObject::~HipTextureObject()
+{
+    if( _slotPosition != INVALID_SLOT_POSITION )
+        _texturePool.releaseSlot( _slotPosition ); /* CudaTextureObject.cpp:55-59 */
+}
+
+/* ---- HipRaycastRenderer: CudaRaycastRenderer.cpp:72-250 -------------------------------------- */
+HipRaycastRenderer::HipRaycastRenderer( const std::string& name )
+    : RendererPlugin( name ), _ctx( nullptr ), _computedSamplesPerRay( 0 )
+{
+    throwOnVrcError( vrc_ctx_create( getHipDevice(), &_ctx ), "vrc_ctx_create" );
+}
+
+HipRaycastRenderer::~HipRaycastRenderer() { vrc_ctx_destroy( _ctx ); }
+
+namespace
+{
+uint32_t getShaderDataType( const VolumeInformation& volInfo ) /* CudaRaycastRenderer.cpp:87-105 */
+{
+    switch( volInfo.dataType )
+    {
+    case DT_UINT8: case DT_UINT16: case DT_UINT32: return SH_UINT;
+    case DT_FLOAT: return SH_FLOAT;
+    case DT_INT8: case DT_INT16: case DT_INT32: return SH_INT;
+    case DT_UNDEFINED:
+    default: throw std::runtime_error( "Unsupported type in the shader." );
+    }
+}
+
+vrc_view_data makeViewData( const RenderInputs& renderInputs ) /* CudaRaycastRenderer.cpp:136-150 */
+{
+    const VolumeInformation& volInfo = renderInputs.dataSource.getVolumeInfo();
+    const Vector3f halfWorldSize = volInfo.worldSize / 2.0f;
+    const Frustum& frustum = renderInputs.frameInfo.frustum;
+    vrc_view_data v;
+    for( int i = 0; i < 3; ++i )
+    {
+        v.eyePosition[i] = frustum.getEyePos()[i];
+        v.aabbMin[i] = -halfWorldSize[i];
+        v.aabbMax[i] = halfWorldSize[i];
+    }
+    /* glGetIntegerv( GL_VIEWPORT ) in the reference: the channel's pixel viewport */
+    for( int i = 0; i < 4; ++i )
+        v.glViewport[i] = uint32_t( renderInputs.pixelViewPort[i] );
+    for( int i = 0; i < 16; ++i )
+    {
+        v.invProjMatrix[i] = frustum.getInvProjMatrix().array[i];
+        v.modelViewMatrix[i] = frustum.getMVMatrix().array[i];
+        v.invViewMatrix[i] = frustum.getInvMVMatrix().array[i];
+    }
+    v.nearPlane = frustum.nearPlane();
+    return v;
+}
+}
+
+void HipRaycastRenderer::preRender( const RenderInputs& renderInputs, const ConstCacheObjects& renderData )
+{
+    /* update(): cuda/Renderer.cu:245-250 */
+    const std::vector< Vector4f >& planes = renderInputs.renderSettings.getClipPlanes().getPlanes();
+    if( planes.size() > 6 )
+        throw std::runtime_error( "More than 6 clip planes" );
+    float flat[24];
+    for( size_t i = 0; i < planes.size(); ++i )
+        for( int k = 0; k < 4; ++k )
+            flat[i * 4 + k] = planes[i][k];
+    throwOnVrcError( vrc_update( _ctx, renderInputs.renderSettings.getColorMap().sampleColors().data(),
+                                 planes.empty() ? nullptr : flat, uint32_t( planes.size() ) ),
+                     "vrc_update" );
+
+    const VolumeInformation& volInfo = renderInputs.dataSource.getVolumeInfo();
+    if( renderInputs.vrParameters.getSamplesPerRay() == 0 ) /* CudaRaycastRenderer.cpp:113-129 */
+    {
+        uint32_t maxLOD = 0;
+        for( const auto& rb : renderData )
+        {
+            const uint32_t level = NodeId( rb->getId() ).getLevel();
+            if( level > maxLOD )
+                maxLOD = level;
+        }
+        const float maxVoxelDim = float( volInfo.voxels.find_max() );
+        const float maxVoxelsAtLOD =
+            maxVoxelDim / float( 1u << ( volInfo.rootNode.getDepth() - maxLOD - 1 ) );
+        _computedSamplesPerRay = uint32_t( std::max( maxVoxelsAtLOD, float( minSamplesPerRay ) ) );
+    }
+    else /* the reference leaves the member uninitialised here (quirk Q7); the GL twin uses the flag */
+        _computedSamplesPerRay = renderInputs.vrParameters.getSamplesPerRay();
+
+    const vrc_view_data viewData = makeViewData( renderInputs );
+    throwOnVrcError( vrc_pre_render( _ctx, &viewData ), "vrc_pre_render" );
+}
+
+void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCacheObjects& renderData )
+{
+    if( renderData.empty() ) /* CudaRaycastRenderer.cpp:157-158 */
+        return;
+    /* CudaRaycastRenderer.cpp:160-163: sort front to back by distance of the box centre.
+     * (keys are precomputed; the reference recomputes them inside the comparator) */
+    const Frustum& frustum = renderInputs.frameInfo.frustum;
+    std::vector< std::pair< float, ConstCacheObjectPtr > > keyed;
+    keyed.reserve( renderData.size() );
+    for( const auto& obj : renderData )
+        keyed.push_back( { nodeDistance( renderInputs.dataSource, frustum, NodeId( obj->getId() ) ), obj } );
+    std::stable_sort( keyed.begin(), keyed.end(),
+                      []( const std::pair< float, ConstCacheObjectPtr >& a,
+                          const std::pair< float, ConstCacheObjectPtr >& b ) { return a.first < b.first; } );
+
+    const VolumeInformation& volInfo = renderInputs.dataSource.getVolumeInfo();
+    std::vector< vrc_node_data > nodeDatas;
+    nodeDatas.reserve( keyed.size() );
+    vrc_pool* pool = nullptr;
+    for( const auto& kv : keyed )
+    {
+        const ConstHipTextureObjectPtr hipObject =
+            std::static_pointer_cast< const HipTextureObject >( kv.second );
+        const LODNode lodNode = renderInputs.dataSource.getNode( NodeId( hipObject->getId() ) );
+        const Boxf& aabb = lodNode.getWorldBox();
+        vrc_node_data nd;
+        const Vector3f tp = hipObject->getTexPosition(), ts = hipObject->getTexSize(),
+                       mn = aabb.getMin(), sz = aabb.getSize();
+        for( int i = 0; i < 3; ++i )
+        {
+            nd.textureMin[i] = tp[i];
+            nd.textureSize[i] = ts[i];
+            nd.aabbMin[i] = mn[i];
+            nd.aabbSize[i] = sz[i];
+        }
+        nodeDatas.push_back( nd );
+        if( !pool )
+            pool = hipObject->getTexturePool()._getHipTexturePool();
+    }
+    const vrc_view_data viewData = makeViewData( renderInputs );
+    vrc_render_data rData; /* CudaRaycastRenderer.cpp:199-206 */
+    rData.samplesPerRay = _computedSamplesPerRay;
+    rData.samplesPerPixel = renderInputs.vrParameters.getSamplesPerPixel();
+    rData.maxSamplesPerRay = maxSamplesPerRay;
+    rData.datatype = getShaderDataType( volInfo );
+    rData.dataSourceRange[0] = 0.0f; /* hard-coded (0,255), CudaRaycastRenderer.cpp:205 */
+    rData.dataSourceRange[1] = 255.0f;
+    throwOnVrcError( vrc_render( _ctx, &viewData, nodeDatas.data(), uint32_t( nodeDatas.size() ),
+                                 &rData, pool ),
+                     "vrc_render" );
+}
+
+void HipRaycastRenderer::postRender( const RenderInputs&, const ConstCacheObjects& )
+{
+    /* the reference unmaps the PBO and draws it (cuda/Renderer.cu:299-326); headless: the frame
+     * stays in device memory until readFrame / the tile gather takes it */
+    throwOnVrcError( vrc_post_render( _ctx, nullptr ), "vrc_post_render" );
+}
+
+void HipRaycastRenderer::readFrame( float* hostRgba )
+{
+    throwOnVrcError( vrc_post_render( _ctx, hostRgba ), "vrc_post_render" );
+}
+void HipRaycastRenderer::getFrameBuffer( void** d, uint32_t* w, uint32_t* h )
+{
+    throwOnVrcError( vrc_get_framebuffer( _ctx, d, w, h ), "vrc_get_framebuffer" );
+}
+void HipRaycastRenderer::setFrameBuffer( void* d, uint32_t w, uint32_t h )
+{
+    throwOnVrcError( vrc_set_framebuffer( _ctx, d, w, h ), "vrc_set_framebuffer" );
+}
+void HipRaycastRenderer::setStream( void* s ) { throwOnVrcError( vrc_ctx_set_stream( _ctx, s ), "vrc_ctx_set_stream" ); }
+void HipRaycastRenderer::setOption( int o, int64_t v ) { throwOnVrcError( vrc_set_option( _ctx, o, v ), "vrc_set_option" ); }
+void HipRaycastRenderer::synchronize() { throwOnVrcError( vrc_synchronize( _ctx ), "vrc_synchronize" ); }
+void HipRaycastRenderer::kernelStats( float* lastMs, double* sumMs, uint32_t* launches, uint64_t* samples )
+{
+    vrc_stats st;
+    throwOnVrcError( vrc_get_stats( _ctx, &st ), "vrc_get_stats" );
+    if( lastMs ) *lastMs = st.kernel_ms;
+    if( sumMs ) *sumMs = st.kernel_ms_sum;
+    if( launches ) *launches = st.kernel_launches;
+    if( samples ) *samples = st.samples;
+}
+
+/* ---- rendering set: RenderingSetGeneratorFilter.ipp:39-95 ----------------------------------- */
+ConstCacheObjects generateRenderingSet( const HipTextureCache& cache, const NodeIds& visibles,
+                                        RenderStatistics& availability )
+{
+    ConstCacheMap cacheMap;
+    for( const NodeId& nodeId : visibles )
+    {
+        /* collectLoadedData: the node itself or its nearest cached ancestor */
+        NodeId current = nodeId;
+        while( current.isValid() )
+        {
+            const ConstCacheObjectPtr data = cache.get( current.getId() );
+            if( data )
+            {
+                cacheMap[current.getId()] = data;
+                break;
+            }
+            current = current.isRoot() ? NodeId() : current.getParent();
+        }
+        cacheMap.count( nodeId.getId() ) > 0 ? ++availability.nAvailable : ++availability.nNotAvailable;
+    }
+    if( visibles.size() != cacheMap.size() )
+    {
+        /* drop every node that has an ancestor in the map.  (The reference tests this with
+         * NodeId::getParents(), RenderingSetGeneratorFilter.ipp:39-48) */
+        size_t previousSize = 0;
+        do
+        {
+            previousSize = cacheMap.size();
+            for( auto it = cacheMap.begin(); it != cacheMap.end(); )
+            {
+                bool hasParent = false;
+                for( const NodeId& parentId : NodeId( it->first ).getParents() )
+                    if( cacheMap.find( parentId.getId() ) != cacheMap.end() )
+                    {
+                        hasParent = true;
+                        break;
+                    }
+                it = hasParent ? cacheMap.erase( it ) : std::next( it );
+            }
+        } while( previousSize != cacheMap.size() );
+    }
+    ConstCacheObjects cacheObjects;
+    cacheObjects.reserve( cacheMap.size() );
+    for( const auto& kv : cacheMap )
+        cacheObjects.push_back( kv.second );
+    availability.nRenderAvailable = cacheObjects.size();
+    return cacheObjects;
+}
+
+/* ---- HipRaycastPipeline: CudaRaycastPipeline.cpp:66-358 -------------------------------------- */
+struct HipRaycastPipeline::Impl
+{
+    Impl() : _uploadExecutor( nUploadThreads ), _asyncUploadExecutor( nAsyncUploadThreads ), _lastPasses( 0 ) {}
+
+    /* VisibleSetGeneratorFilter.cpp:42-75 */
+    NodeIds visibleSet( const RenderInputs& in ) const
+    {
+        const RendererParameters& p = in.vrParameters;
+        SelectVisibles visitor( in.dataSource, in.frameInfo.frustum, uint32_t( in.pixelViewPort[3] ),
+                                p.getSSE(), p.getMinLOD(), p.getMaxLOD(), in.renderDataRange,
+                                in.renderSettings.getClipPlanes() );
+        DFSTraversal traverser;
+        traverser.traverse( in.dataSource.getVolumeInfo().rootNode, visitor, in.frameInfo.timeStep );
+        return visitor.getVisibles();
+    }
+
+    /* CudaRenderUploadFilter.cpp:57-119: cache hits directly, misses through nUploadThreads
+     * data loaders feeding the texture uploader */
+    ConstCacheObjects upload( const NodeIds& nodeIds, const RenderInputs& in, Executor& executor )
+    {
+        ConstCacheObjects cacheObjects;
+        NodeIds notAvailable;
+        for( const NodeId& nodeId : nodeIds )
+        {
+            const auto obj = _hipCache->load( nodeId.getId(), *_dataCache, in.dataSource, *_texturePool );
+            if( obj )
+                cacheObjects.push_back( obj );
+            else
+                notAvailable.push_back( nodeId );
+        }
+        if( notAvailable.empty() )
+            return cacheObjects;
+
+        const size_t perThread = std::max< size_t >( 1, notAvailable.size() / nUploadThreads );
+        std::mutex resultMutex;
+        std::vector< ConstCacheObjectPtr > loaded( notAvailable.size() );
+        std::atomic< size_t > pending( 0 );
+        std::mutex doneMutex;
+        std::condition_variable doneCv;
+        for( size_t i = 0; i < nUploadThreads; ++i )
+        {
+            const size_t begin = perThread * i;
+            if( begin >= notAvailable.size() )
+                continue;
+            const size_t end = ( i == nUploadThreads - 1 ) ? notAvailable.size()
+                                                             : std::min( begin + perThread, notAvailable.size() );
+            ++pending;
+            executor.schedule( [&, begin, end] {
+                for( size_t k = begin; k < end; ++k )
+                {
+                    const CacheId id = notAvailable[k].getId();
+                    /* DataUploadFilter.cpp:35-49 then CudaTextureUploadFilter.cpp:43-60 */
+                    if( _dataCache->load( id, in.dataSource ) )
+                        loaded[k] = _hipCache->load( id, *_dataCache, in.dataSource, *_texturePool );
+                }
+                {
+                    std::lock_guard< std::mutex > lock( doneMutex );
+                    --pending;
+                }
+                doneCv.notify_all();
+            } );
+        }
+        {
+            std::unique_lock< std::mutex > lock( doneMutex );
+            doneCv.wait( lock, [&] { return pending == 0; } );
+        }
+        for( const auto& obj : loaded )
+            if( obj )
+                cacheObjects.push_back( obj );
+        return cacheObjects;
+    }
+
+    /* CudaRaycastPipeline.cpp:129-206 */
+    void renderSync( RenderStatistics& statistics, Renderer& renderer, const RenderInputs& in )
+    {
+        NodeIds nodeIds = visibleSet( in );
+        const Frustum& frustum = in.frameInfo.frustum;
+        std::vector< std::pair< float, NodeId > > keyed;
+        keyed.reserve( nodeIds.size() );
+        for( const NodeId& id : nodeIds )
+            keyed.push_back( { nodeDistance( in.dataSource, frustum, id ), id } );
+        std::stable_sort( keyed.begin(), keyed.end(),
+                          []( const std::pair< float, NodeId >& a, const std::pair< float, NodeId >& b ) {
+                              return a.first < b.first;
+                          } );
+        for( size_t i = 0; i < keyed.size(); ++i )
+            nodeIds[i] = keyed[i].second;
+
+        const uint32_t maxNodesPerPass =
+            uint32_t( _texturePool->getTextureMem() / _texturePool->getSlotMemSize() );
+        const uint32_t numberOfPasses =
+            uint32_t( std::ceil( float( nodeIds.size() ) / float( maxNodesPerPass ) ) );
+        _lastPasses = numberOfPasses;
+        for( uint32_t i = 0; i < numberOfPasses; ++i )
+        {
+            uint32_t renderStages = RENDER_FRAME;
+            if( i == 0 )
+                renderStages |= RENDER_BEGIN;
+            if( i == numberOfPasses - 1u )
+                renderStages |= RENDER_END;
+            const size_t startIndex = size_t( i ) * maxNodesPerPass;
+            const size_t endIndex = std::min( size_t( i + 1 ) * maxNodesPerPass, nodeIds.size() );
+            const NodeIds nodesPerPass( nodeIds.begin() + startIndex, nodeIds.begin() + endIndex );
+            /* createAndExecuteSyncPass, CudaRaycastPipeline.cpp:208-234 */
+            const ConstCacheObjects objects = upload( nodesPerPass, in, _uploadExecutor );
+            renderer.render( in, objects, renderStages );
+            if( numberOfPasses > 1 )
+            {
+                /* a multipass frame re-uses the slots: the bricks of this pass must be
+                 * evictable before the next pass uploads (the render is stream-ordered
+                 * after the uploads, and the next uploads after this render) */
+                static_cast< HipRaycastRenderer& >( renderer.getPlugin() ).synchronize();
+            }
+        }
+        if( numberOfPasses == 0 ) /* nothing visible: still begin/end the frame */
+            renderer.render( in, ConstCacheObjects(), RENDER_BEGIN | RENDER_END );
+        statistics.nAvailable = nodeIds.size();
+        statistics.nNotAvailable = 0;
+        statistics.nRenderAvailable = statistics.nAvailable;
+    }
+
+    /* CudaRaycastPipeline.cpp:236-301: render what is resident (or a cached ancestor), upload
+     * the visible set in the background, ask for a redraw until everything is available */
+    void renderAsync( RenderStatistics& statistics, Renderer& renderer, const RenderInputs& in )
+    {
+        const NodeIds visibles = visibleSet( in );
+        const ConstCacheObjects objects = generateRenderingSet( *_hipCache, visibles, statistics );
+        const bool allAvailable = statistics.nNotAvailable == 0;
+        if( !allAvailable )
+        {
+            /* one upload pipeline in flight at a time on the async executor */
+            bool expected = false;
+            if( _asyncBusy.compare_exchange_strong( expected, true ) )
+            {
+                /* the data source outlives the pipeline (it does in the reference: Node owns it);
+                 * everything else the task touches is owned by this Impl */
+                DataSource* ds = &in.dataSource;
+                _asyncUploadExecutor.schedule( [this, visibles, ds] {
+                    for( const NodeId& id : visibles )
+                    {
+                        if( _hipCache->get( id.getId() ) )
+                            continue;
+                        if( _dataCache->load( id.getId(), *ds ) )
+                            _hipCache->load( id.getId(), *_dataCache, *ds, *_texturePool );
+                    }
+                    _asyncBusy = false;
+                } );
+            }
+        }
+        renderer.render( in, objects, RENDER_ALL );
+        if( in.redrawFilter ) /* RedrawFilter, livre/eq/Channel.cpp:64-90 */
+            in.redrawFilter( allAvailable );
+    }
+
+    /* CudaRaycastPipeline.cpp:303-323 */
+    void init( const RenderInputs& in )
+    {
+        if( _hipCache )
+            return;
+        std::lock_guard< std::mutex > lock( _initMutex );
+        if( _hipCache )
+            return;
+        const RendererParameters& p = in.vrParameters;
+        const size_t gpuMem = size_t( p.getMaxGPUCacheMemoryMB() ) * 1024u * 1024u;
+        _texturePool.reset( new HipTexturePool( in.dataSource, gpuMem ) );
+        if( !_dataCache )
+            _dataCache.reset( new DataCache( "Data Cache", size_t( p.getMaxCPUCacheMemoryMB() ) * 1024u * 1024u ) );
+        _hipCache.reset( new HipTextureCache( "TextureCache", _texturePool->getTextureMem() ) );
+    }
+
+    ~Impl()
+    {
+        _asyncUploadExecutor.wait();
+        _uploadExecutor.wait();
+        /* texture objects release their slots into the pool: drop them before the pool */
+        _hipCache.reset();
+        _dataCache.reset();
+        _texturePool.reset();
+    }
+
+    std::unique_ptr< HipTexturePool > _texturePool;
+    std::unique_ptr< DataCache > _dataCache;
+    std::unique_ptr< HipTextureCache > _hipCache;
+    Executor _uploadExecutor, _asyncUploadExecutor;
+    std::atomic< bool > _asyncBusy{ false };
+    std::mutex _initMutex;
+    uint32_t _lastPasses;
+};
+
+HipRaycastPipeline::HipRaycastPipeline( const std::string& name )
+    : RenderPipelinePlugin( name ), _impl( new Impl() )
+{
+}
+HipRaycastPipeline::~HipRaycastPipeline() {}
+
+RenderStatistics HipRaycastPipeline::render( Renderer& renderer, const RenderInputs& renderInputs )
+{
+    RenderStatistics statistics;
+    _impl->init( renderInputs );
+    if( renderInputs.vrParameters.getSynchronousMode() )
+        _impl->renderSync( statistics, renderer, renderInputs );
+    else
+        _impl->renderAsync( statistics, renderer, renderInputs );
+    return statistics;
+}
+
+const CacheStatistics* HipRaycastPipeline::textureCacheStatistics() const
+{
+    return _impl->_hipCache ? &_impl->_hipCache->getStatistics() : nullptr;
+}
+const CacheStatistics* HipRaycastPipeline::dataCacheStatistics() const
+{
+    return _impl->_dataCache ? &_impl->_dataCache->getStatistics() : nullptr;
+}
+uint32_t HipRaycastPipeline::lastNumberOfPasses() const { return _impl->_lastPasses; }
+void HipRaycastPipeline::waitForUploads() { _impl->_asyncUploadExecutor.wait(); }
+}

@@ -37,7 +37,8 @@ class RenderData(C.Structure):  # vrc_render_data
 
 class Stats(C.Structure):  # vrc_stats
     _fields_ = [("kernel_ms", C.c_float), ("samples", C.c_uint64),
-                ("kernel_variant", C.c_uint32), ("grid_dims", C.c_uint32 * 3)]
+                ("kernel_variant", C.c_uint32), ("grid_dims", C.c_uint32 * 3),
+                ("kernel_ms_sum", C.c_double), ("kernel_launches", C.c_uint32)]
 
 
 class VrcError(RuntimeError):

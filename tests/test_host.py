@@ -1,0 +1,141 @@
+"""Host-side (C++ mirror of Libre's plugin surface) checks that need no GPU: the reference's
+own unit-test known answers, restated against libLivreHipRaycastPipeline.so."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+
+
+@pytest.fixture(scope="module")
+def drv(built):
+    from libre_amd import driver
+    driver.load_library()
+    return driver
+
+
+def test_driver_exports_every_declared_symbol(drv):
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "include", "livre_hip_driver.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(lvh_[a-z_0-9]+)\s*\(", txt)))
+    L = drv.load_library()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert sorted(drv.EXPORTS) == declared
+    # the DSO contract of CudaRaycastPipeline.cpp:50-54
+    assert L.LunchboxPluginGetVersion() == 1 and L.LunchboxPluginRegister()
+
+
+def test_cache_semantics_like_reference_test(drv):
+    # tests/core/cache.cpp:33-75
+    L = drv.load_library()
+    rc = L.lvh_selftest_cache()
+    assert rc == 0, (rc, L.lvh_last_error())
+
+
+def test_plugin_factory_semantics(drv):
+    # tests/core/pluginFactory.cpp:115-203
+    L = drv.load_library()
+    rc = L.lvh_selftest_plugin_factory()
+    assert rc == 0, (rc, L.lvh_last_error())
+
+
+def test_camera_settings_known_answers(drv):
+    # tests/eq/settings/cameraSettings.cpp:42-144
+    L = drv.load_library()
+    out = ((C.c_float * 16) * 4)()
+    assert L.lvh_selftest_camera(out) == 0
+    spin = [0.408082, 0.0, 0.912945, 0.0, 0.833469, 0.408082, -0.372557, 0.0,
+            -0.372557, 0.912945, 0.166531, 0.0, 0.0, 0.0, 0.0, 1.0]
+    look = [-0.707107, -0.408248, -0.57735, 0.0, 0.0, 0.816496, -0.57735, 0.0,
+            0.707107, -0.408248, -0.57735, 0.0, 0.0, 0.0, 0.0, 1.0]
+    everything = [0.413936, -0.460246, -0.785385, 0.0, 0.328941, -0.728848, 0.600482, 0.0,
+                  -0.848796, -0.506907, -0.150303, 0.0, 9.3526, 26.597, 35.243, 1.0]
+    assert np.allclose(list(out[0]), spin, rtol=1e-5, atol=1e-6)
+    assert np.allclose(list(out[1]), look, rtol=1e-5, atol=1e-6)
+    assert np.allclose(list(out[2]), everything, rtol=1e-4, atol=1e-4)
+    # default application camera == the oracle's restatement
+    assert np.allclose(list(out[3]), list(orc.default_mv()), atol=1e-7)
+
+
+PROJ = [2.0, 0, 0, 0, 0, 2.0, 0, 0, 0, 0, -1.01342285, -1, 0, 0, -0.201342285, 0]
+MV = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, -1.0, 1]
+
+LOD_GOLDEN = {
+    # tests/lib/lodSelection.cpp:83-194 (windowHeight, sse, minLOD, maxLOD) -> sorted ids
+    (256, 1.0, 0, 100): [1, 17, 262145, 262161, 8589934594, 8589934610, 8589934626, 8589934642,
+                         8590196738, 8590196754, 8590196770, 8590196786, 8590458882, 8590458898,
+                         8590458914, 8590458930, 8590721026, 8590721042, 8590721058, 8590721074,
+                         12884901890, 12884901906, 12884901922, 12884901938, 12885164034,
+                         12885164050, 12885164066, 12885164082, 12885426178, 12885426194,
+                         12885426210, 12885426226, 12885688322, 12885688338, 12885688354,
+                         12885688370],
+    (256, 2.0, 0, 100): [1, 17, 262145, 262161, 4294967297, 4294967313, 4295229441, 4295229457],
+    (256, 8.0, 0, 100): [0],
+    (512, 2.0, 0, 100): [1, 17, 262145, 262161, 8589934594, 8589934610, 8589934626, 8589934642,
+                         8590196738, 8590196754, 8590196770, 8590196786, 8590458882, 8590458898,
+                         8590458914, 8590458930, 8590721026, 8590721042, 8590721058, 8590721074,
+                         12884901890, 12884901906, 12884901922, 12884901938, 12885164034,
+                         12885164050, 12885164066, 12885164082, 12885426178, 12885426194,
+                         12885426210, 12885426226, 12885688322, 12885688338, 12885688354,
+                         12885688370],
+    (512, 8.0, 0, 100): [0],
+    (512, 1.0, 0, 0): [0],
+    (512, 1.0, 1, 1): [1, 17, 262145, 262161, 4294967297, 4294967313, 4295229441, 4295229457],
+}
+
+
+@pytest.mark.parametrize("case", sorted(LOD_GOLDEN))
+def test_lod_selection_golden_ids(drv, case):
+    h, sse, lo, hi = case
+    got = sorted(drv.select_visibles("mem://#4096,4096,4096,256", MV, PROJ, h, sse, lo, hi))
+    assert got == LOD_GOLDEN[case]
+
+
+def test_lod_selection_golden_ids_512_sse1(drv):
+    # the 120-id list of tests/lib/lodSelection.cpp:126-151: 20 ids of levels 1-2 + 64 level-3
+    # ids with z = 6 + 36 level-3 ids with z = 7, x,y in 1..6
+    got = sorted(drv.select_visibles("mem://#4096,4096,4096,256", MV, PROJ, 512, 1.0, 0, 100))
+    want = [1, 17, 262145, 262161, 8589934594, 8589934610, 8589934626, 8589934642, 8590196738,
+            8590196754, 8590196770, 8590196786, 8590458882, 8590458898, 8590458914, 8590458930,
+            8590721026, 8590721042, 8590721058, 8590721074]
+    want += [orc.pack(3, x, y, 6) for y in range(8) for x in range(8)]
+    want += [orc.pack(3, x, y, 7) for y in range(1, 7) for x in range(1, 7)]
+    assert 25769803779 in want and 30066344035 in want and 30065033235 in want
+    assert got == sorted(want)
+
+
+def test_mem_data_source_matches_reference_kats(drv):
+    # tests/data/dataSource.cpp:45-70, tests/lib/cache.cpp:97-119
+    with_brick = drv.datasource_brick("mem://#1024,1024,512,32", orc.pack(1, 0, 0, 0))
+    assert with_brick.size == 40 ** 3 and (with_brick == 17).all()
+    # bricks equal the oracle's restatement, level 3 of the C2 volume
+    for nid in (orc.pack(3, 7, 7, 2), orc.pack(3, 1, 5, 0)):
+        b = drv.datasource_brick("mem://#1024,1024,1024,128", nid)
+        assert b.size == 136 ** 3 and (b == orc.lib().orc_mem_brick_value_u8(nid)).all()
+
+
+def test_hash_data_source_matches_fixture_generator(drv):
+    vol = orc.hash_volume(32, 32, 32)
+    vi = orc.mem_volume_info(32, 32, 32, 16)
+    for nid in orc.leaf_ids(vi):
+        want = orc.brick_from_volume(vol, vi, orc.lod_node(vi, nid))
+        got = drv.datasource_brick("hash://#32,32,32,16", nid).reshape(want.shape)
+        assert (got == want).all()
+
+
+def test_raw_data_source_single_brick(drv):
+    # tests/lib/rawDatasource.cpp:32-83: nucleon 41^3 u8: depth 1, overlap 0, brick = volume
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nucleon.raw")
+    got = drv.datasource_brick("raw://%s#41,41,41,uint8" % path, orc.pack(0, 0, 0, 0))
+    assert (got == np.fromfile(path, dtype=np.uint8)).all()
+    L = drv.load_library()
+    n = C.c_size_t()
+    assert L.lvh_datasource_brick(b"raw:///nonexistent.raw#4,4,4,uint8", 0, None, 0, C.byref(n)) != 0
+    assert L.lvh_datasource_brick(b"nosuch://x", 0, None, 0, C.byref(n)) != 0
+    assert b"No plugin implementation available" in L.lvh_last_error()
