@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--spin", type=float, nargs=2, default=(0.0, 0.0))
     ap.add_argument("--bands", type=int, default=4, help="interleaved row bands per rank (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-row-stride", type=int, default=8)
+    ap.add_argument("--cpu-row-stride", type=int, default=1)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="oracle threads (GPU box CPU share)")
     return ap.parse_args()
 
 
@@ -73,6 +74,7 @@ def cpu_baseline(a, samples_gpu_frame):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = max(1, min(cores, a.cpu_threads))
     stride = max(1, a.cpu_row_stride)
     t0 = time.perf_counter()
     fb, n = orc.oracle_render(s, threads=cores, rows=(0, s.H, stride))

@@ -498,6 +498,17 @@ struct HipRaycastPipeline::Impl
             std::unique_lock< std::mutex > lock( doneMutex );
             doneCv.wait( lock, [&] { return pending == 0; } );
         }
+        /* Two uploaders can both pass the cache's "has space" test while only one slot is
+         * free (the policy evicts until used < max, i.e. one slot; the reference has the same
+         * window, Cache.ipp:132-144 + TexturePool.cu:180-181); the loser's load comes back
+         * empty.  Retry those serially: with a single loader the policy always leaves a slot. */
+        for( size_t k = 0; k < notAvailable.size(); ++k )
+            if( !loaded[k] )
+            {
+                const CacheId id = notAvailable[k].getId();
+                if( _dataCache->load( id, in.dataSource ) )
+                    loaded[k] = _hipCache->load( id, *_dataCache, in.dataSource, *_texturePool );
+            }
         for( const auto& obj : loaded )
             if( obj )
                 cacheObjects.push_back( obj );

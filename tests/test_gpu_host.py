@@ -87,13 +87,16 @@ def test_lod_cut_mixed_levels_matches_oracle(drv):
 
 def test_multipass_when_atlas_is_smaller_than_the_frame(drv):
     # CudaRaycastPipeline.cpp:149-185: 64 bricks through a pool of a few slots
-    with drv.App("hash://#64,64,64,16", 40, 40, synchronous=True, min_lod=2, max_lod=2,
+    # 64 leaf bricks of 40^3 = 4 MB through a 1 MB atlas (16 slots): 4 passes
+    with drv.App("hash://#128,128,128,32", 40, 40, synchronous=True, min_lod=2, max_lod=2,
                  gpu_cache_mb=1) as small:
         small.set_camera(spin=(0.5, 0.35))
         small.set_colormap(orc.linear_ramp_tf(0.05))
         fb_small, st = small.render_frame()
-        assert st.n_passes > 1
-    with drv.App("hash://#64,64,64,16", 40, 40, synchronous=True, min_lod=2, max_lod=2,
+        assert st.n_passes == 4 and st.n_available == 64
+        tex, _ = small.cache_stats()
+        assert tex["count"] <= 16  # never more texture objects than slots
+    with drv.App("hash://#128,128,128,32", 40, 40, synchronous=True, min_lod=2, max_lod=2,
                  gpu_cache_mb=8) as big:
         big.set_camera(spin=(0.5, 0.35))
         big.set_colormap(orc.linear_ramp_tf(0.05))
