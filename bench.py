@@ -50,18 +50,6 @@ def linear_ramp(alpha):
     return np.ascontiguousarray(np.stack([i, i, i, np.float32(alpha) * i], axis=1))
 
 
-def band_layout(height, world, bands_per_rank):
-    """Sort-first decomposition into row bands: world*bands_per_rank equal bands, rank r takes
-    bands r, r+world, ... so every rank gets a mix of short-ray (top/bottom) and long-ray
-    (centre) rows.  Returns per rank a list of (y0, h)."""
-    nb = world * bands_per_rank if world > 1 else 1
-    edges = [round(height * k / nb) for k in range(nb + 1)]
-    out = [[] for _ in range(world)]
-    for b in range(nb):
-        out[b % world].append((edges[b], edges[b + 1] - edges[b]))
-    return out
-
-
 def cpu_baseline(a, samples_gpu_frame):
     """Oracle (CPU port of the reference algorithm) on every `stride`-th row of the same frame."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -97,7 +85,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from libre_amd import driver, vrc
+    from libre_amd import driver, sortfirst, vrc
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU fallback")
@@ -108,7 +96,8 @@ def main():
 
     W = H = a.viewport
     uri = "mem://#%d,%d,%d,%d" % (a.voxels, a.voxels, a.voxels, a.block)
-    bands = band_layout(H, world, a.bands)[rank]
+    layout = sortfirst.band_layout(H, world, a.bands)
+    bands = layout[rank]
     rows = sum(h for _, h in bands)
     # per-rank framebuffer: this rank's bands, stacked (device memory owned by torch)
     fb = torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda")
@@ -130,27 +119,15 @@ def main():
         apps.append(app)
         off += h
 
-    counts = [rows]
-    if world > 1:
-        counts = [sum(h for _, h in b) for b in band_layout(H, world, a.bands)]
-        gathered = [torch.empty((c, W, 4), dtype=torch.float32, device="cuda") for c in counts] \
-            if rank == 0 else None
-
-    equal_tiles = world > 1 and len(set(counts)) == 1
+    gather = sortfirst.TileGather(layout, W, rank, "cuda") if world > 1 else None
 
     def frame():
         for app in apps:
             app.render_frame(readback=False)
-        if world > 1:  # sort-first assembly: per-tile RGBA to the display rank over RCCL/xGMI
-            if equal_tiles:
-                dist.gather(fb, gathered, dst=0)
-            elif rank == 0:
-                gathered[0].copy_(fb)
-                reqs = [dist.irecv(gathered[r], src=r) for r in range(1, world)]
-                for q in reqs:
-                    q.wait()
-            else:
-                dist.send(fb, dst=0)
+        if gather is not None:  # sort-first assembly: tiles to the display rank over RCCL/xGMI
+            gather.gather(fb)
+            if rank == 0:
+                gather.assemble()
 
     # first frame: uploads every brick through the 2-thread upload path (not timed below)
     torch.cuda.synchronize()
