@@ -86,6 +86,9 @@ typedef struct
 #define VRC_OPT_TF_FRAC_BITS 3    /* 8 (default, CUDA 1.8 fixed-point lerp weight) | 0 exact float */
 #define VRC_OPT_COUNT_SAMPLES 4   /* 0 (default) | 1: count composited samples (slower kernel) */
 #define VRC_OPT_TILE_ORDER 5      /* 1 (default): heaviest-first tile schedule | 0: row-major tiles */
+#define VRC_OPT_STEPPING 6        /* sample positions inside a brick: 1 (default) 8.24 fixed-point
+                                   * voxel-space increments | 0 the reference's float world-space
+                                   * accumulation (cuda/Renderer.cu:208: pos += step) */
 
 #define VRC_KERNEL_AUTO 0
 #define VRC_KERNEL_REFERENCE_ORDER 1 /* O(nodes) loop per ray in host order, cuda/Renderer.cu:172-227 */

@@ -80,6 +80,7 @@ struct vrc_ctx
 
     /* cuda::ColorMap + cuda::ClipPlanes state */
     float* dTf = nullptr;
+    float* hTf = nullptr; /* pinned copy of the last uploaded TF: skips identical re-uploads */
     uint64_t tfVersion = 0;
     float planes[6][4];
     uint32_t nPlanes = 0;
@@ -115,6 +116,7 @@ struct vrc_ctx
     bool tileOrderValid = false;
     vrc_frame tileOrderFrame;
     int64_t optTileOrder = 1;
+    int64_t optStepping = 1;
 
     unsigned long long* dCounter = nullptr;
     unsigned long long* hCounter = nullptr; /* pinned */
@@ -154,6 +156,7 @@ int vrc_ctx_create( int device, vrc_ctx** out )
     hipError_t e = hipStreamCreateWithFlags( &c->ownStream, hipStreamNonBlocking );
     if( e == hipSuccess ) e = hipMalloc( &c->dTf, 256 * 4 * sizeof( float ) );
     if( e == hipSuccess ) e = hipMalloc( &c->dLut, 257 * sizeof( vrc_f4 ) );
+    if( e == hipSuccess ) e = hipHostMalloc( &c->hTf, 256 * 4 * sizeof( float ) );
     if( e == hipSuccess ) e = hipMalloc( &c->dCounter, sizeof( unsigned long long ) );
     if( e == hipSuccess ) e = hipHostMalloc( &c->hCounter, sizeof( unsigned long long ) );
     if( e != hipSuccess )
@@ -170,6 +173,7 @@ int vrc_ctx_create( int device, vrc_ctx** out )
     float tf[256 * 4];
     for( int i = 0; i < 256; ++i )
         tf[i * 4 + 0] = tf[i * 4 + 1] = tf[i * 4 + 2] = tf[i * 4 + 3] = (float)i / 255.0f;
+    std::memcpy( c->hTf, tf, sizeof( tf ) );
     e = hipMemcpy( c->dTf, tf, sizeof( tf ), hipMemcpyHostToDevice );
     if( e != hipSuccess )
     {
@@ -190,6 +194,7 @@ void vrc_ctx_destroy( vrc_ctx* c )
     if( c->stream ) (void)hipStreamSynchronize( c->stream );
     if( c->dTf ) (void)hipFree( c->dTf );
     if( c->dLut ) (void)hipFree( c->dLut );
+    if( c->hTf ) (void)hipHostFree( c->hTf );
     if( c->fbOwn ) (void)hipFree( c->fbOwn );
     if( c->dNodes ) (void)hipFree( c->dNodes );
     if( c->dGrid ) (void)hipFree( c->dGrid );
@@ -240,6 +245,7 @@ int vrc_set_option( vrc_ctx* c, int option, int64_t value )
         return VRC_OK;
     case VRC_OPT_COUNT_SAMPLES: c->optCount = value ? 1 : 0; return VRC_OK;
     case VRC_OPT_TILE_ORDER: c->optTileOrder = value ? 1 : 0; return VRC_OK;
+    case VRC_OPT_STEPPING: c->optStepping = value ? 1 : 0; return VRC_OK;
     default: return fail( VRC_EINVAL, "vrc_set_option: unknown option" );
     }
 }
@@ -255,6 +261,7 @@ int vrc_get_option( vrc_ctx* c, int option, int64_t* value )
     case VRC_OPT_TF_FRAC_BITS: *value = c->optTfFracBits; return VRC_OK;
     case VRC_OPT_COUNT_SAMPLES: *value = c->optCount; return VRC_OK;
     case VRC_OPT_TILE_ORDER: *value = c->optTileOrder; return VRC_OK;
+    case VRC_OPT_STEPPING: *value = c->optStepping; return VRC_OK;
     default: return fail( VRC_EINVAL, "vrc_get_option: unknown option" );
     }
 }
@@ -587,13 +594,16 @@ int vrc_update( vrc_ctx* c, const float tf[256 * 4], const float* planes, uint32
     if( nPlanes > 0 && !planes )
         return fail( VRC_EINVAL, "vrc_update: planes is NULL" );
     VRC_HIP_CHECK( hipSetDevice( c->device ) );
-    if( tf )
+    if( tf && std::memcmp( c->hTf, tf, 256 * 4 * sizeof( float ) ) != 0 )
     {
-        /* 4 KiB, as cudaMemcpyToArray in cuda/ColorMap.cu:61-64; pageable source, so the
-         * call returns once the bytes are staged */
-        VRC_HIP_CHECK( hipMemcpyAsync( c->dTf, tf, 256 * 4 * sizeof( float ),
-                                       hipMemcpyHostToDevice, c->stream ) );
+        /* 4 KiB, as cudaMemcpyToArray in cuda/ColorMap.cu:61-64.  The reference re-uploads every
+         * frame (CudaRaycastRenderer.cpp:109-110); an unchanged map is skipped here, so the
+         * per-frame call neither copies nor synchronizes.  The pinned copy may only be
+         * rewritten once the previous async copy from it has been consumed. */
         VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
+        std::memcpy( c->hTf, tf, 256 * 4 * sizeof( float ) );
+        VRC_HIP_CHECK( hipMemcpyAsync( c->dTf, c->hTf, 256 * 4 * sizeof( float ),
+                                       hipMemcpyHostToDevice, c->stream ) );
         ++c->tfVersion;
     }
     c->nPlanes = nPlanes;
@@ -843,6 +853,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     a.sampleCounter = c->optCount ? c->dCounter : nullptr;
     a.clamp = c->cachedClamp;
     a.gridDda = useDda;
+    a.fixedStepping = c->optStepping != 0;
 
     /* order the march after every brick upload issued so far (fixes quirk Q9) */
     {

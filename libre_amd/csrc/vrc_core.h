@@ -366,32 +366,111 @@ VRC_HD vrc_sampler vrc_make_sampler( const vrc_dev_node& n, const vrc_frame& f )
  * atlas coordinate; voxel choice can differ only for samples within ~1e-4 voxel of a
  * voxel face ("nearest-voxel flips").  Coordinates are >= 0 here, so the
  * float->int truncation is the floor of the point-sampling rule. */
-template < bool CLAMP >
-VRC_HD uint32_t vrc_voxel_index( const vrc_sampler& s, vrc_f3 pos )
+/* element offset of slot-local voxel (ux,uy,uz) */
+VRC_HD uint32_t vrc_voxel_address( const vrc_sampler& s, uint32_t ux, uint32_t uy, uint32_t uz )
 {
-    VRC_FAST_FP
-    float lx = ( pos.x - s.minx ) * s.kx + s.ox;
-    float ly = ( pos.y - s.miny ) * s.ky + s.oy;
-    float lz = ( pos.z - s.minz ) * s.kz + s.oz;
-    if( CLAMP )
-    {
-        lx = fminf( fmaxf( lx, 0.0f ), s.hix );
-        ly = fminf( fmaxf( ly, 0.0f ), s.hiy );
-        lz = fminf( fmaxf( lz, 0.0f ), s.hiz );
-    }
-    const uint32_t ux = (uint32_t)(int)lx, uy = (uint32_t)(int)ly, uz = (uint32_t)(int)lz;
     /* element = slotBase + sum over axes of (c >> 3) * blockStride + (c & 7) * inStride with
      * inStride = 1, 8, 64 and blockStride = 512, 512*sbx, 512*sbx*sby.  Since
      * (c & 7) * s = c * s - (c >> 3) * 8 * s this is
      *   slotBase + x + 8 y + 64 z + qx * 504 + qy * (512 sbx - 64) + qz * (512 sbx sby - 512):
      * three shifts, three 24-bit multiply-adds (full rate; operands < 2^24: slot-local block
      * counts <= 512, slot < 16 Mi elements, checked at pool creation), two shift-adds, one add. */
+#if defined( __HIP_DEVICE_COMPILE__ )
+    /* spelled out: hipcc otherwise emits multiply + 3-input add pairs (eleven instructions).
+     * v_mad_u32_u24 takes one scalar operand (the stride). */
+    uint32_t e, t;
+    asm( "v_mad_u32_u24 %0, %1, %2, %3" : "=v"( e ) : "v"( ux >> VRC_MB_SHIFT ), "s"( 504u ), "v"( ux ) );
+    asm( "v_mad_u32_u24 %0, %1, %2, %3" : "=v"( t ) : "v"( uy >> VRC_MB_SHIFT ), "s"( s.cyy ), "v"( e ) );
+    asm( "v_mad_u32_u24 %0, %1, %2, %3" : "=v"( e ) : "v"( uz >> VRC_MB_SHIFT ), "s"( s.czz ), "v"( t ) );
+    asm( "v_lshl_add_u32 %0, %1, 3, %2" : "=v"( t ) : "v"( uy ), "v"( e ) );
+    asm( "v_lshl_add_u32 %0, %1, 6, %2" : "=v"( e ) : "v"( uz ), "v"( t ) );
+    return e + s.slotBase;
+#else
     uint32_t e = vrc_mul24( ux >> VRC_MB_SHIFT, 504u ) + ux;
     e = vrc_mul24( uy >> VRC_MB_SHIFT, s.cyy ) + e;
     e = vrc_mul24( uz >> VRC_MB_SHIFT, s.czz ) + e;
     e = ( uy << 3 ) + e;
     e = ( uz << 6 ) + e;
     return e + s.slotBase;
+#endif
+}
+
+/* Atlas element indices of the next N samples of a segment, advancing pos by N steps.
+ * Per sample: brick-local voxel of the world position (nearest, Renderer.cu:210-214 + point
+ * sampling of cuda/TexturePool.cu:163-170): l = (pos - aabbMin) * voxelsPerWorld + localOrigin,
+ * voxel = trunc(l) (l >= 0, so truncation is the floor of the point-sampling rule), evaluated
+ * brick-locally so the float grid is finer than the reference's normalized atlas coordinate;
+ * the voxel can differ only for samples within ~1e-4 voxel of a voxel face (DESIGN.md,
+ * "nearest-voxel flips").  pos advances by sequential additions of step, as in the reference.
+ * Scalar f32 instructions on purpose: on gfx950 a v_pk_add/fma_f32 costs ~2.9x a scalar
+ * v_add_f32 (profiles/r1_ubench_valu_issue_costs.txt), so packing two lanes' worth of data
+ * into one instruction loses; the file is also built with -fno-slp-vectorize. */
+template < bool CLAMP, int N >
+VRC_HD void vrc_group_indices( const vrc_sampler& s, vrc_f3& pos, const vrc_f3& step, uint32_t* idx )
+{
+    VRC_FAST_FP
+#pragma unroll
+    for( int k = 0; k < N; ++k )
+    {
+        float lx = ( pos.x - s.minx ) * s.kx + s.ox;
+        float ly = ( pos.y - s.miny ) * s.ky + s.oy;
+        float lz = ( pos.z - s.minz ) * s.kz + s.oz;
+        if( CLAMP )
+        {
+            lx = fminf( fmaxf( lx, 0.0f ), s.hix );
+            ly = fminf( fmaxf( ly, 0.0f ), s.hiy );
+            lz = fminf( fmaxf( lz, 0.0f ), s.hiz );
+        }
+        idx[k] = vrc_voxel_address( s, (uint32_t)(int)lx, (uint32_t)(int)ly, (uint32_t)(int)lz );
+        pos.x += step.x;
+        pos.y += step.y;
+        pos.z += step.z;
+    }
+}
+
+/* Fixed-point alternative to the float position chain above (VRC_OPT_STEPPING = 1).
+ * The slot-local voxel coordinate of the segment's first sample is computed exactly as above
+ * (same float expression, so the sample on the brick face picks the same voxel), converted to
+ * 8.24 fixed point (exact: l < 256 has at most 24 fraction bits below 2^8), and every further
+ * sample adds the per-step voxel increment round(step * voxelsPerWorld * 2^24): one integer
+ * add per axis instead of add + subtract + multiply-add + convert.  It is a more accurate
+ * evaluation of start + n*step than the reference's float accumulation (error <= n * 2^-25
+ * voxel against ~n * 6e-5), but not the same rounding path, so a sample within ~1e-4 voxel
+ * of a voxel face may read the neighbouring voxel ("nearest-voxel flips").
+ * Not used with the clamped sampler (coordinates must stay in [0, 256)). */
+struct vrc_fixpos
+{
+    uint32_t x, y, z;    /* 8.24 slot-local voxel coordinates */
+    uint32_t dx, dy, dz; /* per-step increments (two's complement) */
+};
+
+VRC_HD vrc_fixpos vrc_fixpos_init( const vrc_sampler& s, const vrc_f3& pos, const vrc_f3& step )
+{
+    VRC_FAST_FP
+    vrc_fixpos p;
+    const float lx = ( pos.x - s.minx ) * s.kx + s.ox;
+    const float ly = ( pos.y - s.miny ) * s.ky + s.oy;
+    const float lz = ( pos.z - s.minz ) * s.kz + s.oz;
+    p.x = (uint32_t)( lx * 16777216.0f );
+    p.y = (uint32_t)( ly * 16777216.0f );
+    p.z = (uint32_t)( lz * 16777216.0f );
+    p.dx = (uint32_t)(int32_t)rintf( step.x * s.kx * 16777216.0f );
+    p.dy = (uint32_t)(int32_t)rintf( step.y * s.ky * 16777216.0f );
+    p.dz = (uint32_t)(int32_t)rintf( step.z * s.kz * 16777216.0f );
+    return p;
+}
+
+template < int N >
+VRC_HD void vrc_group_indices_fixed( const vrc_sampler& s, vrc_fixpos& p, uint32_t* idx )
+{
+#pragma unroll
+    for( int k = 0; k < N; ++k )
+    {
+        idx[k] = vrc_voxel_address( s, p.x >> 24, p.y >> 24, p.z >> 24 );
+        p.x += p.dx;
+        p.y += p.dy;
+        p.z += p.dz;
+    }
 }
 
 /* Renderer.cu:83-93 with the classified table: e = (rgb*alpha', alpha') for the density.
@@ -433,7 +512,7 @@ VRC_HD void vrc_composite( vrc_f4& c, const vrc_f4& e, bool frozen = false )
 #define VRC_GROUP 8
 #endif
 
-template < bool CLAMP, bool COUNT, typename ATLAS_T >
+template < bool CLAMP, bool COUNT, bool FIXED, typename ATLAS_T >
 VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_segment s,
                                const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
                                vrc_f4& color, uint32_t& nSamples )
@@ -443,6 +522,11 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
     float travel = s.dist;
     vrc_f3 pos = s.pos;
     bool done = false;
+    if( !( travel > 0.0f ) )
+        return false;
+    vrc_fixpos fp = { 0, 0, 0, 0, 0, 0 };
+    if( FIXED )
+        fp = vrc_fixpos_init( sm, pos, s.step );
 
     /* all VRC_GROUP samples of a group are reached by the reference loop if more than
      * VRC_GROUP steps remain (the sequentially rounded travel differs from the exact one by
@@ -451,15 +535,13 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
     while( travel > guard )
     {
         uint32_t idx[VRC_GROUP];
+        if( FIXED )
+            vrc_group_indices_fixed< VRC_GROUP >( sm, fp, idx );
+        else
+            vrc_group_indices< CLAMP, VRC_GROUP >( sm, pos, s.step, idx );
 #pragma unroll
         for( int k = 0; k < VRC_GROUP; ++k )
-        {
-            idx[k] = vrc_voxel_index< CLAMP >( sm, pos );
-            pos.x += s.step.x;
-            pos.y += s.step.y;
-            pos.z += s.step.z;
             travel -= stepSize; /* same sequential subtraction as the reference */
-        }
         vrc_f4 e[VRC_GROUP];
 #pragma unroll
         for( int k = 0; k < VRC_GROUP; ++k )
@@ -498,16 +580,16 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
     while( travel > 0.0f && !done )
     {
         uint32_t idx[VRC_GROUP], d[VRC_GROUP], cnt = 0;
+        if( FIXED )
+            vrc_group_indices_fixed< VRC_GROUP >( sm, fp, idx );
+        else
+            vrc_group_indices< CLAMP, VRC_GROUP >( sm, pos, s.step, idx );
 #pragma unroll
         for( int k = 0; k < VRC_GROUP; ++k )
         {
             const bool v = travel > 0.0f;
             cnt += v ? 1u : 0u;
-            const uint32_t i = vrc_voxel_index< CLAMP >( sm, pos );
-            idx[k] = v ? i : 0u;
-            pos.x += s.step.x;
-            pos.y += s.step.y;
-            pos.z += s.step.z;
+            idx[k] = v ? idx[k] : 0u;
             travel -= stepSize;
         }
 #pragma unroll
@@ -533,7 +615,7 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
 /* ------------------------------------------------------------------------------------------
  * Reference-order pixel: the O(nodeCount) loop of Renderer.cu:172-227, nodes in host order.
  * ---------------------------------------------------------------------------------------- */
-template < bool CLAMP, bool COUNT, typename ATLAS_T >
+template < bool CLAMP, bool COUNT, bool FIXED, typename ATLAS_T >
 VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
                                        const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
                                        vrc_f4* __restrict__ pixelBuffer, uint32_t px, uint32_t py,
@@ -557,7 +639,7 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
                 break;
             continue;
         }
-        if( vrc_march_segment< CLAMP, COUNT, ATLAS_T >( f, n, s, atlas, lut, color, nSamples ) )
+        if( vrc_march_segment< CLAMP, COUNT, FIXED, ATLAS_T >( f, n, s, atlas, lut, color, nSamples ) )
             break;
     }
     pixelBuffer[pixelPos] = color; /* Renderer.cu:229 */
@@ -569,7 +651,7 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
  * For a regular single-LOD grid the along-ray order equals the reference's host order for
  * every pair of bricks that share a ray ("brick order").
  * ---------------------------------------------------------------------------------------- */
-template < bool CLAMP, bool COUNT, typename ATLAS_T >
+template < bool CLAMP, bool COUNT, bool FIXED, typename ATLAS_T >
 VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
                                 const int32_t* __restrict__ gridTable,
                                 const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
@@ -627,7 +709,7 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
                 bool stop;
                 if( vrc_brick_segment( r, n, f.stepSize, &s, &stop ) )
                 {
-                    if( vrc_march_segment< CLAMP, COUNT, ATLAS_T >( f, n, s, atlas, lut, color,
+                    if( vrc_march_segment< CLAMP, COUNT, FIXED, ATLAS_T >( f, n, s, atlas, lut, color,
                                                                     nSamples ) )
                         break;
                 }

@@ -35,6 +35,7 @@ struct vrc_raycast_args
     const uint32_t* tileOrder;         /* NULL = row-major tile order */
     bool clamp;
     bool gridDda;
+    bool fixedStepping; /* VRC_OPT_STEPPING */
 };
 
 /* heaviest-first tile schedule for the frame (order: one uint32 per 8x8 tile) */

@@ -232,7 +232,7 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, hipStream
 #ifndef VRC_MIN_WAVES
 #define VRC_MIN_WAVES 4
 #endif
-template < bool DDA, bool CLAMP, bool COUNT >
+template < bool DDA, bool CLAMP, bool COUNT, bool FIXED >
 __global__ __launch_bounds__( VRC_WG, VRC_MIN_WAVES ) void vrc_k_raycast(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ gridTable, const uint8_t* __restrict__ atlas,
@@ -272,11 +272,11 @@ __global__ __launch_bounds__( VRC_WG, VRC_MIN_WAVES ) void vrc_k_raycast(
     if( px < f.width && py < f.height )
     {
         if( DDA )
-            vrc_pixel_grid_dda< CLAMP, COUNT, uint8_t >( f, nodes, gridTable, atlas, lut,
-                                                         pixelBuffer, px, py, nSamples );
+            vrc_pixel_grid_dda< CLAMP, COUNT, FIXED, uint8_t >( f, nodes, gridTable, atlas, lut,
+                                                                pixelBuffer, px, py, nSamples );
         else
-            vrc_pixel_reference_order< CLAMP, COUNT, uint8_t >( f, nodes, atlas, lut, pixelBuffer,
-                                                                px, py, nSamples );
+            vrc_pixel_reference_order< CLAMP, COUNT, FIXED, uint8_t >( f, nodes, atlas, lut,
+                                                                       pixelBuffer, px, py, nSamples );
     }
     if( COUNT )
     {
@@ -290,7 +290,7 @@ __global__ __launch_bounds__( VRC_WG, VRC_MIN_WAVES ) void vrc_k_raycast(
     }
 }
 
-template < bool DDA, bool CLAMP, bool COUNT >
+template < bool DDA, bool CLAMP, bool COUNT, bool FIXED >
 static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream )
 {
     const uint32_t tilesX = ( a.frame.width + VRC_TILE - 1 ) / VRC_TILE;
@@ -298,8 +298,8 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
     const uint32_t nTiles = tilesX * tilesY;
     if( nTiles == 0 )
         return hipSuccess;
-    hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT > ), dim3( nTiles ), dim3( VRC_WG ), 0,
-                        stream, a.frame, a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut,
+    hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED > ), dim3( nTiles ), dim3( VRC_WG ),
+                        0, stream, a.frame, a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut,
                         a.pixelBuffer, a.sampleCounter, a.tileOrder, tilesX, nTiles );
     return hipGetLastError();
 }
@@ -307,16 +307,22 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
 hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
 {
     const bool count = a.sampleCounter != nullptr;
-    const int key = ( a.gridDda ? 4 : 0 ) | ( a.clamp ? 2 : 0 ) | ( count ? 1 : 0 );
+    /* the clamped sampler (overlap 0) always uses the float position chain */
+    const bool fixed = a.fixedStepping && !a.clamp;
+    const int key = ( fixed ? 8 : 0 ) | ( a.gridDda ? 4 : 0 ) | ( a.clamp ? 2 : 0 ) | ( count ? 1 : 0 );
     switch( key )
     {
-    case 0: return launch_variant< false, false, false >( a, stream );
-    case 1: return launch_variant< false, false, true >( a, stream );
-    case 2: return launch_variant< false, true, false >( a, stream );
-    case 3: return launch_variant< false, true, true >( a, stream );
-    case 4: return launch_variant< true, false, false >( a, stream );
-    case 5: return launch_variant< true, false, true >( a, stream );
-    case 6: return launch_variant< true, true, false >( a, stream );
-    default: return launch_variant< true, true, true >( a, stream );
+    case 0: return launch_variant< false, false, false, false >( a, stream );
+    case 1: return launch_variant< false, false, true, false >( a, stream );
+    case 2: return launch_variant< false, true, false, false >( a, stream );
+    case 3: return launch_variant< false, true, true, false >( a, stream );
+    case 4: return launch_variant< true, false, false, false >( a, stream );
+    case 5: return launch_variant< true, false, true, false >( a, stream );
+    case 6: return launch_variant< true, true, false, false >( a, stream );
+    case 7: return launch_variant< true, true, true, false >( a, stream );
+    case 8: return launch_variant< false, false, false, true >( a, stream );
+    case 9: return launch_variant< false, false, true, true >( a, stream );
+    case 12: return launch_variant< true, false, false, true >( a, stream );
+    default: return launch_variant< true, false, true, true >( a, stream );
     }
 }

@@ -66,7 +66,8 @@ extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atla
     vrc_fill_frame( f, *view, *render, geom, t.g, pl, nPlanes, nNodes, W, H, (float)pixelOffX,
                     (float)pixelOffY );
 
-    const bool dda = kernel == 2;
+    const bool dda = kernel == 2 || kernel == 4;
+    const bool fixed = ( kernel == 3 || kernel == 4 ) && !t.clamp;
     if( dda && !t.gridOk )
         return 2;
     uint64_t total = 0;
@@ -75,24 +76,27 @@ extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atla
         for( uint32_t px = 0; px < W; ++px )
         {
             uint32_t n = 0;
+#define PIXEL( FN, CL, FX ) \
+    FN< CL, true, FX, uint8_t >
             if( dda )
             {
                 if( t.clamp )
-                    vrc_pixel_grid_dda< true, true, uint8_t >( f, t.nodes.data(), t.grid.data(),
-                                                               atlas.data(), lut.data(), pb, px, py, n );
+                    vrc_pixel_grid_dda< true, true, false, uint8_t >( f, t.nodes.data(), t.grid.data(), atlas.data(), lut.data(), pb, px, py, n );
+                else if( fixed )
+                    vrc_pixel_grid_dda< false, true, true, uint8_t >( f, t.nodes.data(), t.grid.data(), atlas.data(), lut.data(), pb, px, py, n );
                 else
-                    vrc_pixel_grid_dda< false, true, uint8_t >( f, t.nodes.data(), t.grid.data(),
-                                                                atlas.data(), lut.data(), pb, px, py, n );
+                    vrc_pixel_grid_dda< false, true, false, uint8_t >( f, t.nodes.data(), t.grid.data(), atlas.data(), lut.data(), pb, px, py, n );
             }
             else
             {
                 if( t.clamp )
-                    vrc_pixel_reference_order< true, true, uint8_t >( f, t.nodes.data(), atlas.data(),
-                                                                      lut.data(), pb, px, py, n );
+                    vrc_pixel_reference_order< true, true, false, uint8_t >( f, t.nodes.data(), atlas.data(), lut.data(), pb, px, py, n );
+                else if( fixed )
+                    vrc_pixel_reference_order< false, true, true, uint8_t >( f, t.nodes.data(), atlas.data(), lut.data(), pb, px, py, n );
                 else
-                    vrc_pixel_reference_order< false, true, uint8_t >( f, t.nodes.data(), atlas.data(),
-                                                                       lut.data(), pb, px, py, n );
+                    vrc_pixel_reference_order< false, true, false, uint8_t >( f, t.nodes.data(), atlas.data(), lut.data(), pb, px, py, n );
             }
+#undef PIXEL
             total += n;
         }
     if( samplesOut )

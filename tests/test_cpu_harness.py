@@ -168,3 +168,17 @@ def test_gpu_like_fma_contraction_keeps_parity(name):
     got, n_got, _ = orc.harness_render(s, kernel=2, sanitize="fma")
     scenes.assert_parity(got, want, name)
     assert abs(n_got - n_want) <= 2e-4 * n_want + 8
+
+
+@pytest.mark.parametrize("name", sorted(scenes.SCENES))
+def test_fixed_point_stepping_matches_oracle(name):
+    # VRC_OPT_STEPPING = 1 (the default on the GPU): 8.24 voxel-space increments inside a brick
+    s = scenes.get(name)
+    want, n_want = orc.oracle_render(s, threads=4)
+    for kernel in (3, 4):  # reference order / grid DDA with fixed-point stepping
+        got, n_got, _ = orc.harness_render(s, kernel=kernel)
+        scenes.assert_parity(got, want, "%s k%d" % (name, kernel))
+        assert abs(n_got - n_want) <= 2e-4 * n_want + 8
+    # same sample count as the float chain: the stepping changes positions, never the count
+    _, n_float, _ = orc.harness_render(s, kernel=2)
+    assert n_got == n_float

@@ -78,6 +78,10 @@ def test_scene_parity_both_kernels(vrc, golden, name):
         # idempotence: same inputs, same bits
         again, _, _ = g.render(kernel=vrc.KERNEL_GRID_DDA)
         assert (again == dda).all()
+        # the reference's float position accumulation (VRC_OPT_STEPPING = 0) is kept and tested
+        flt, n_flt, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, stepping=0)
+        scenes.assert_parity(flt, want, name + " dda float stepping vs oracle")
+        assert n_flt == n_dda
 
 
 def test_c1_config_parity(vrc):

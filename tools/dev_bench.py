@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--alpha", type=float, default=0.05)
     ap.add_argument("--ref-order", action="store_true")
     ap.add_argument("--no-tile-order", action="store_true")
+    ap.add_argument("--stepping", type=int, default=1)
     a = ap.parse_args()
     t0 = time.time()
     s = orc.build_scene(voxels=(a.voxels,) * 3, block=a.block, viewport=(a.viewport,) * 2,
@@ -44,6 +45,7 @@ def main():
         nodes = C.cast(s.nodes, C.POINTER(vrc.NodeData))
         vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_COUNT_SAMPLES, 0))
         vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_TILE_ORDER, 0 if a.no_tile_order else 1))
+        vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_STEPPING, a.stepping))
         kernels = [vrc.KERNEL_GRID_DDA] + ([vrc.KERNEL_REFERENCE_ORDER] if a.ref_order else [])
         for k in kernels:
             vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_KERNEL, k))
