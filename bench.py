@@ -89,10 +89,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU fallback")
+    # rehearsal knobs (1-GPU box): BENCH_FORCE_DEVICE=0 puts every rank on one card and
+    # BENCH_BACKEND=gloo replaces RCCL; the judged runs use neither
+    if "BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     W = H = a.viewport
     uri = "mem://#%d,%d,%d,%d" % (a.voxels, a.voxels, a.voxels, a.block)
@@ -107,17 +115,16 @@ def main():
     probe = driver.App(uri, W, H, device=local_rank)
     depth = probe.volume_info()["depth"]
     probe.close()
-    apps = []
-    off = 0
-    for (y0, h) in bands:
-        app = driver.App(uri, W, H, device=local_rank, tile=(0, y0, W, h), synchronous=True,
-                         min_lod=depth - 1, max_lod=depth - 1, gpu_cache_mb=3072)
-        app.set_camera(spin=tuple(a.spin))
-        app.set_colormap(linear_ramp(a.alpha))
-        app.set_stream(stream.cuda_stream)
-        app.set_framebuffer(fb.data_ptr() + off * W * 16)
-        apps.append(app)
-        off += h
+    # one application per rank; its row bands are rendered by ONE kernel launch per frame
+    app = driver.App(uri, W, H, device=local_rank, synchronous=True, min_lod=depth - 1,
+                     max_lod=depth - 1, gpu_cache_mb=3072)
+    if world > 1:
+        app.set_bands(bands)
+    app.set_camera(spin=tuple(a.spin))
+    app.set_colormap(linear_ramp(a.alpha))
+    app.set_stream(stream.cuda_stream)
+    app.set_framebuffer(fb.data_ptr())
+    apps = [app]
 
     gather = sortfirst.TileGather(layout, W, rank, "cuda") if world > 1 else None
 
@@ -211,9 +218,9 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": "vrc_k_raycast<true,false,false>",
                          "kernel_ms_per_frame": kernel_ms_per_frame,
-                         "algorithmic_bytes_per_launch": per_rank_alg / max(1, len(bands)),
+                         "algorithmic_bytes_per_launch": per_rank_alg,
                          "algorithmic_bytes_per_frame_all_ranks": alg_bytes,
-                         "launches_per_frame": len(bands),
+                         "launches_per_frame": 1,
                          "note": "the kernel is VALU-issue bound, not HBM bound (DESIGN.md); "
                                  "traffic: see profiles/ (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"},
         }

@@ -56,6 +56,9 @@ int lvh_app_set_camera( lvh_app* app, const float position[3], const float looka
 int lvh_app_set_modelview( lvh_app* app, const float mv[16] );
 int lvh_app_set_colormap( lvh_app* app, const float rgba256[1024] );
 int lvh_app_set_clip_planes( lvh_app* app, const float* planes, uint32_t n );
+/* sort-first row bands rendered by this process in one launch: bands (y0[i], h[i]) of the full
+ * frame, stacked in that order in its pixel buffer (replaces params.tile; n = 0 -> back to it) */
+int lvh_app_set_bands( lvh_app* app, const uint32_t* y0, const uint32_t* h, uint32_t n );
 int lvh_app_set_option( lvh_app* app, int vrc_option, int64_t value );
 /* render on a caller-owned stream / into caller-owned device memory (tile gather) */
 int lvh_app_set_stream( lvh_app* app, void* hip_stream );

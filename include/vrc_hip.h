@@ -147,6 +147,13 @@ int vrc_pre_render( vrc_ctx* ctx, const vrc_view_data* view );
  * internal buffer. */
 int vrc_set_framebuffer( vrc_ctx* ctx, void* device_rgba, uint32_t width, uint32_t height );
 int vrc_get_framebuffer( vrc_ctx* ctx, void** device_rgba, uint32_t* width, uint32_t* height );
+/* Sort-first row bands in ONE launch: the pixel buffer holds n_rows rows, row i of it being
+ * frame row frame_rows[i] of the frame described by glViewport (whose w,h stay the FULL frame).
+ * Takes effect at the next vrc_pre_render (buffer = glViewport.w x n_rows).  n_rows = 0 returns
+ * to the plain case (buffer = glViewport.w x glViewport.h).  Rays are those of the full frame,
+ * bit for bit.  (Replaces Equalizer's per-channel pixel viewport, livre/eq/Channel.cpp:272-290,
+ * for a non-contiguous set of rows.) */
+int vrc_set_row_map( vrc_ctx* ctx, const uint32_t* frame_rows, uint32_t n_rows );
 /* cuda::Renderer::render (cuda/Renderer.cu:274-297): node table H2D + one rayCast pass that
  * accumulates into the pixel buffer.  nodes are in the host's front-to-back order. */
 int vrc_render( vrc_ctx* ctx, const vrc_view_data* view, const vrc_node_data* nodes,

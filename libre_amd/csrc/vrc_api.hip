@@ -110,6 +110,11 @@ struct vrc_ctx
     bool cachedClamp = false;
     vrc_frame cachedGridFrame; /* only grid* fields are meaningful */
 
+    /* sort-first row map */
+    uint32_t* dRowMap = nullptr;
+    size_t dRowMapCap = 0;
+    std::vector< uint32_t > rowMap;
+
     /* tile schedule */
     uint32_t* dTileOrder = nullptr;
     size_t dTileOrderCap = 0;
@@ -200,6 +205,7 @@ void vrc_ctx_destroy( vrc_ctx* c )
     if( c->dGrid ) (void)hipFree( c->dGrid );
     if( c->hStage ) (void)hipHostFree( c->hStage );
     if( c->dTileOrder ) (void)hipFree( c->dTileOrder );
+    if( c->dRowMap ) (void)hipFree( c->dRowMap );
     if( c->dCounter ) (void)hipFree( c->dCounter );
     if( c->hCounter ) (void)hipHostFree( c->hCounter );
     for( auto& pr : c->evPairs )
@@ -615,13 +621,40 @@ int vrc_update( vrc_ctx* c, const float tf[256 * 4], const float* planes, uint32
 
 static vrc_f4* ctx_fb( vrc_ctx* c ) { return c->fbExt ? c->fbExt : c->fbOwn; }
 
+int vrc_set_row_map( vrc_ctx* c, const uint32_t* rows, uint32_t n )
+{
+    if( !c || ( n && !rows ) )
+        return fail( VRC_EINVAL, "vrc_set_row_map: NULL argument" );
+    VRC_HIP_CHECK( hipSetDevice( c->device ) );
+    if( n == c->rowMap.size() && ( n == 0 || std::memcmp( rows, c->rowMap.data(), n * sizeof( uint32_t ) ) == 0 ) )
+        return VRC_OK;
+    VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
+    if( n > c->dRowMapCap )
+    {
+        if( c->dRowMap ) VRC_HIP_CHECK( hipFree( c->dRowMap ) );
+        c->dRowMap = nullptr;
+        c->dRowMapCap = 0;
+        VRC_HIP_CHECK( hipMalloc( &c->dRowMap, n * sizeof( uint32_t ) ) );
+        c->dRowMapCap = n;
+    }
+    if( n )
+        VRC_HIP_CHECK( hipMemcpy( c->dRowMap, rows, n * sizeof( uint32_t ), hipMemcpyHostToDevice ) );
+    c->rowMap.assign( rows, rows + n );
+    c->tileOrderValid = false;
+    return VRC_OK;
+}
+
 int vrc_pre_render( vrc_ctx* c, const vrc_view_data* view )
 {
     if( !c || !view )
         return fail( VRC_EINVAL, "vrc_pre_render: NULL argument" );
-    const uint32_t w = view->glViewport[2], h = view->glViewport[3];
-    if( w == 0 || h == 0 )
+    const uint32_t w = view->glViewport[2];
+    const uint32_t h = c->rowMap.empty() ? view->glViewport[3] : (uint32_t)c->rowMap.size();
+    if( w == 0 || h == 0 || view->glViewport[3] == 0 )
         return fail( VRC_EINVAL, "vrc_pre_render: empty viewport" );
+    for( uint32_t r : c->rowMap )
+        if( r >= view->glViewport[3] )
+            return fail( VRC_EINVAL, "vrc_pre_render: row map entry outside the frame" );
     VRC_HIP_CHECK( hipSetDevice( c->device ) );
     if( c->fbExt )
     {
@@ -735,7 +768,8 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         return fail( VRC_EINVAL, "vrc_render: pool lives on another device" );
     if( !ctx_fb( c ) || c->fbW == 0 )
         return fail( VRC_EINVAL, "vrc_render: vrc_pre_render has not been called" );
-    if( view->glViewport[2] != c->fbW || view->glViewport[3] != c->fbH )
+    if( view->glViewport[2] != c->fbW ||
+        ( c->rowMap.empty() ? view->glViewport[3] : (uint32_t)c->rowMap.size() ) != c->fbH )
         return fail( VRC_EINVAL, "vrc_render: viewport differs from the pixel buffer" );
     if( render->samplesPerRay == 0 )
         return fail( VRC_EINVAL, "vrc_render: samplesPerRay is 0" );
@@ -819,6 +853,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
             geom.slots[a] = pool->slots[a];
         vrc_fill_frame( f, *view, *render, geom, c->cachedGridFrame, c->planes, c->nPlanes, nNodes,
                         c->fbW, c->fbH, 0.0f, 0.0f );
+        f.rowMap = c->rowMap.empty() ? nullptr : c->dRowMap;
     }
 
     /* tile schedule, recomputed only when the frame constants changed */

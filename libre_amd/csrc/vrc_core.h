@@ -86,6 +86,9 @@ struct vrc_frame
     float cellSize[3];
     float invCellSize[3];
     int32_t gridDim[3];
+    /* sort-first row bands: frame row of every row of the pixel buffer (NULL = identity).  The
+     * buffer then holds height rows picked from a frame of vpH rows (vrc_set_row_map). */
+    const uint32_t* rowMap;
 };
 
 /* Atlas memory layout.  The logical atlas is the reference's 3-D array of slots
@@ -621,7 +624,7 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
                                        vrc_f4* __restrict__ pixelBuffer, uint32_t px, uint32_t py,
                                        uint32_t& nSamples )
 {
-    const vrc_ray r = vrc_setup_ray( f, px, py );
+    const vrc_ray r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
     if( !r.hit )
         return; /* Renderer.cu:129-130, :148-149: pixel left untouched */
     const uint32_t pixelPos = py * f.width + px;
@@ -658,7 +661,7 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
                                 vrc_f4* __restrict__ pixelBuffer, uint32_t px, uint32_t py,
                                 uint32_t& nSamples )
 {
-    const vrc_ray r = vrc_setup_ray( f, px, py );
+    const vrc_ray r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
     if( !r.hit )
         return;
     const uint32_t pixelPos = py * f.width + px;

@@ -176,7 +176,7 @@ __device__ __forceinline__ uint32_t vrc_tile_bucket( const vrc_frame& f, uint32_
     uint32_t px = tx * VRC_TILE + VRC_TILE / 2, py = ty * VRC_TILE + VRC_TILE / 2;
     px = px < f.width ? px : f.width - 1;
     py = py < f.height ? py : f.height - 1;
-    const vrc_ray r = vrc_setup_ray( f, px, py );
+    const vrc_ray r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
     if( !r.hit )
         return 255u;
     const float chord = r.tFarGlobal - fmaxf( r.tNearGlobal, r.tNearPlane );

@@ -51,8 +51,16 @@ inline void vrc_build_tables( const vrc_atlas_geom& p, const vrc_node_data* in, 
             d.aabbMin[a] = s.aabbMin[a];
             d.aabbSize[a] = s.aabbSize[a];
             const double dim = (double)p.atlasDim[a];
-            const double texMinVox = (double)s.textureMin[a] * dim;
-            const double texSizeVox = (double)s.textureSize[a] * dim;
+            double texMinVox = (double)s.textureMin[a] * dim;
+            double texSizeVox = (double)s.textureSize[a] * dim;
+            /* textureMin/Size are float32 fractions of the atlas (CudaTextureObject.cpp:77-82),
+             * so times the atlas size they miss the integer voxel they stand for by ~1e-4, by an
+             * amount that depends on which slot the brick happened to get.  Snap them back:
+             * frames then do not depend on the (thread-timing dependent) slot assignment. */
+            if( std::fabs( texMinVox - std::floor( texMinVox + 0.5 ) ) < 1e-2 )
+                texMinVox = std::floor( texMinVox + 0.5 );
+            if( std::fabs( texSizeVox - std::floor( texSizeVox + 0.5 ) ) < 1e-2 )
+                texSizeVox = std::floor( texSizeVox + 0.5 );
             d.voxPerWorld[a] = (float)( texSizeVox / (double)s.aabbSize[a] );
             long tv = (long)std::floor( texMinVox + 0.5 );
             if( tv < 0 ) tv = 0;
@@ -191,6 +199,7 @@ inline void vrc_fill_frame( vrc_frame& f, const vrc_view_data& view, const vrc_r
     f.nodeCount = nNodes;
     f.sbx = geom.slotDim[0] / VRC_MB;
     f.sby = geom.slotDim[1] / VRC_MB;
+    f.rowMap = nullptr;
 }
 
 #endif

@@ -26,7 +26,7 @@ class FrameStats(C.Structure):  # lvh_frame_stats
 EXPORTS = [
     "lvh_last_error", "lvh_app_create", "lvh_app_destroy", "lvh_app_set_camera",
     "lvh_app_set_modelview", "lvh_app_set_colormap", "lvh_app_set_clip_planes",
-    "lvh_app_set_option", "lvh_app_set_stream", "lvh_app_set_framebuffer", "lvh_app_render_frame",
+    "lvh_app_set_bands", "lvh_app_set_option", "lvh_app_set_stream", "lvh_app_set_framebuffer", "lvh_app_render_frame",
     "lvh_app_get_stats", "lvh_app_wait_uploads", "lvh_app_synchronize", "lvh_app_volume_info",
     "lvh_app_visible_set", "lvh_app_view_matrices", "lvh_app_cache_stats", "lvh_select_visibles",
     "lvh_selftest_cache", "lvh_selftest_plugin_factory", "lvh_selftest_camera",
@@ -52,6 +52,7 @@ def load_library():
     L.lvh_app_set_modelview.argtypes = [vp, C.c_float * 16]
     L.lvh_app_set_colormap.argtypes = [vp, vp]
     L.lvh_app_set_clip_planes.argtypes = [vp, vp, C.c_uint32]
+    L.lvh_app_set_bands.argtypes = [vp, vp, vp, C.c_uint32]
     L.lvh_app_set_option.argtypes = [vp, C.c_int, C.c_int64]
     L.lvh_app_set_stream.argtypes = [vp, vp]
     L.lvh_app_set_framebuffer.argtypes = [vp, vp]
@@ -112,6 +113,14 @@ class App:
     def set_clip_planes(self, planes):
         a = np.ascontiguousarray(planes, dtype=np.float32).reshape(-1, 4)
         check(self.L, self.L.lvh_app_set_clip_planes(self.h, a.ctypes.data if len(a) else None, len(a)))
+
+    def set_bands(self, bands):
+        """bands: list of (y0, h) rows of the full frame rendered by this process (one launch)."""
+        n = len(bands)
+        y0 = (C.c_uint32 * max(1, n))(*[b[0] for b in bands])
+        h = (C.c_uint32 * max(1, n))(*[b[1] for b in bands])
+        check(self.L, self.L.lvh_app_set_bands(self.h, y0, h, n))
+        self.height = sum(b[1] for b in bands) if n else self.height
 
     def set_option(self, option, value):
         check(self.L, self.L.lvh_app_set_option(self.h, option, value))

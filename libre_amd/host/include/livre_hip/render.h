@@ -162,6 +162,10 @@ struct RenderInputs
     RendererParameters vrParameters;
     std::function< void( bool /*allAvailable*/ ) > redrawFilter; /* livre/eq/Channel.cpp:64-90 */
     DataSource& dataSource;
+    /** sort-first row bands (not in the reference, where Equalizer gives a channel one
+     *  rectangle): the frame rows this process renders, stacked in its pixel buffer; empty =
+     *  the whole pixelViewPort.  pixelViewPort/frustum stay those of the full frame. */
+    std::vector< uint32_t > rowMap;
 };
 
 /** livre/core/render/Renderer.h:29-32 */

@@ -30,6 +30,7 @@ struct lvh_app
     RendererParameters vrParameters;
     uint32_t frameId = 0;
     RenderStatistics lastStats;
+    std::vector< uint32_t > rowMap; /* lvh_app_set_bands */
 
     HipRaycastRenderer& renderer()
     {
@@ -39,7 +40,7 @@ struct lvh_app
 
     void tile( uint32_t t[4] ) const
     {
-        if( params.tile[2] == 0 || params.tile[3] == 0 )
+        if( !rowMap.empty() || params.tile[2] == 0 || params.tile[3] == 0 )
         {
             t[0] = t[1] = 0;
             t[2] = params.width;
@@ -78,7 +79,8 @@ struct lvh_app
                              renderSettings,
                              vrParameters,
                              nullptr,
-                             *dataSource };
+                             *dataSource,
+                             rowMap };
     }
 };
 
@@ -182,7 +184,23 @@ int lvh_app_set_framebuffer( lvh_app* app, void* d )
     if( !app ) return fail( "NULL argument" );
     uint32_t t[4];
     app->tile( t );
-    LVH_TRY( app->renderer().setFrameBuffer( d, t[2], t[3] ) )
+    const uint32_t rows = app->rowMap.empty() ? t[3] : uint32_t( app->rowMap.size() );
+    LVH_TRY( app->renderer().setFrameBuffer( d, t[2], rows ) )
+}
+
+int lvh_app_set_bands( lvh_app* app, const uint32_t* y0, const uint32_t* h, uint32_t n )
+{
+    if( !app || ( n && ( !y0 || !h ) ) ) return fail( "NULL argument" );
+    std::vector< uint32_t > rows;
+    for( uint32_t i = 0; i < n; ++i )
+        for( uint32_t r = 0; r < h[i]; ++r )
+        {
+            if( y0[i] + r >= app->params.height )
+                return fail( "lvh_app_set_bands: band outside the frame" );
+            rows.push_back( y0[i] + r );
+        }
+    app->rowMap.swap( rows );
+    return 0;
 }
 
 static void fillStats( lvh_app* app, lvh_frame_stats* s, bool sync )

@@ -293,6 +293,9 @@ void HipRaycastRenderer::preRender( const RenderInputs& renderInputs, const Cons
     else /* the reference leaves the member uninitialised here (quirk Q7); the GL twin uses the flag */
         _computedSamplesPerRay = renderInputs.vrParameters.getSamplesPerRay();
 
+    throwOnVrcError( vrc_set_row_map( _ctx, renderInputs.rowMap.empty() ? nullptr : renderInputs.rowMap.data(),
+                                      uint32_t( renderInputs.rowMap.size() ) ),
+                     "vrc_set_row_map" );
     const vrc_view_data viewData = makeViewData( renderInputs );
     throwOnVrcError( vrc_pre_render( _ctx, &viewData ), "vrc_pre_render" );
 }

@@ -153,3 +153,28 @@ def test_unknown_renderer_and_volume_are_reported(drv):
     with pytest.raises(drv.DriverError):
         a = drv.App("mem://?datatype=uint16#64,64,64,16", 8, 8, synchronous=True)
         a.render_frame()
+
+
+def test_row_bands_in_one_launch_are_rows_of_the_full_frame(drv):
+    # sort-first bands of one rank rendered by a single kernel launch (vrc_set_row_map): the
+    # rays are the full frame's, so the stacked bands equal the frame rows bit for bit
+    W, H = 48, 64
+    kw = dict(synchronous=True, min_lod=2, max_lod=2, gpu_cache_mb=8)
+    with drv.App("hash://#64,64,64,16", W, H, **kw) as full_app:
+        full_app.set_camera(spin=(0.5, 0.35))
+        full_app.set_colormap(orc.linear_ramp_tf(0.05))
+        full, _ = full_app.render_frame()
+    bands = [(8, 8), (40, 16), (24, 8)]
+    with drv.App("hash://#64,64,64,16", W, H, **kw) as app:
+        app.set_bands(bands)
+        app.set_camera(spin=(0.5, 0.35))
+        app.set_colormap(orc.linear_ramp_tf(0.05))
+        fb, st = app.render_frame()
+        assert fb.shape == (32, W, 4) and st.n_passes == 1
+        want = np.concatenate([full[y0:y0 + h] for (y0, h) in bands], axis=0)
+        assert (fb == want).all()
+        # and back to the whole frame
+        app.set_bands([])
+        app.height = H
+        fb2, _ = app.render_frame()
+        assert (fb2 == full).all()
