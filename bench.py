@@ -38,6 +38,11 @@ def parse():
     ap.add_argument("--alpha", type=float, default=0.05, help="TF: rgba[i]=(i,i,i,alpha*i)/255")
     ap.add_argument("--spin", type=float, nargs=2, default=(0.0, 0.0))
     ap.add_argument("--bands", type=int, default=4, help="interleaved row bands per rank (N>1)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="renderer instances per rank, each on its own stream; 0 = auto: 1 on one "
+                         "GPU (the kernel fills the chip; the roofline is that of an undisturbed "
+                         "launch), 3 when the frame is split over several GPUs and each has idle "
+                         "capacity (Equalizer renders ahead too: its default latency is one frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=16, help="oracle threads (GPU box CPU share)")
@@ -107,34 +112,50 @@ def main():
     layout = sortfirst.band_layout(H, world, a.bands)
     bands = layout[rank]
     rows = sum(h for _, h in bands)
-    # per-rank framebuffer: this rank's bands, stacked (device memory owned by torch)
-    fb = torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream()
+    K = a.frames_in_flight if a.frames_in_flight > 0 else (1 if world == 1 else 3)
+    a.warmup = max(a.warmup, K)
+    # per in-flight frame: a pixel buffer of this rank's stacked bands (device memory owned by
+    # torch), a stream and a tile-gather buffer set
+    fbs = [torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(K)]
+    streams = [torch.cuda.Stream() for _ in range(K)]
 
     # leaves only: --min-lod = --max-lod = depth-1 (BASELINE.md "single LOD")
     probe = driver.App(uri, W, H, device=local_rank)
     depth = probe.volume_info()["depth"]
     probe.close()
-    # one application per rank; its row bands are rendered by ONE kernel launch per frame
+    # one application (one atlas, one pair of caches) per rank; its row bands are rendered by
+    # ONE kernel launch per frame; K renderer instances give K frames in flight
     app = driver.App(uri, W, H, device=local_rank, synchronous=True, min_lod=depth - 1,
                      max_lod=depth - 1, gpu_cache_mb=3072)
     if world > 1:
         app.set_bands(bands)
     app.set_camera(spin=tuple(a.spin))
     app.set_colormap(linear_ramp(a.alpha))
-    app.set_stream(stream.cuda_stream)
-    app.set_framebuffer(fb.data_ptr())
-    apps = [app]
-
-    gather = sortfirst.TileGather(layout, W, rank, "cuda") if world > 1 else None
+    app.set_frames_in_flight(K)
+    for k in range(K):
+        app.select_slot(k)
+        app.set_stream(streams[k].cuda_stream)
+        app.set_framebuffer(fbs[k].data_ptr())
+    gathers = [sortfirst.TileGather(layout, W, rank, "cuda") for _ in range(K)] if world > 1 else None
+    counter = [0]
 
     def frame():
-        for app in apps:
+        k = counter[0] % K
+        counter[0] += 1
+        with torch.cuda.stream(streams[k]):
+            app.select_slot(k)
             app.render_frame(readback=False)
-        if gather is not None:  # sort-first assembly: tiles to the display rank over RCCL/xGMI
-            gather.gather(fb)
-            if rank == 0:
-                gather.assemble()
+            if gathers is not None:  # sort-first assembly: tiles to rank 0 over RCCL/xGMI
+                gathers[k].gather(fbs[k])
+                if rank == 0:
+                    gathers[k].assemble()
+
+    def all_slots(fn):
+        out = []
+        for k in range(K):
+            app.select_slot(k)
+            out.append(fn())
+        return out
 
     # first frame: uploads every brick through the 2-thread upload path (not timed below)
     torch.cuda.synchronize()
@@ -144,14 +165,12 @@ def main():
     first_frame_ms = (time.perf_counter() - t0) * 1e3
 
     # samples per frame (deterministic for a fixed view): one counted frame, outside the timing
-    for app in apps:
-        app.set_option(vrc.OPT_COUNT_SAMPLES, 1)
-    samples = 0
-    for app in apps:
+    app.select_slot(0)
+    app.set_option(vrc.OPT_COUNT_SAMPLES, 1)
+    with torch.cuda.stream(streams[0]):
         app.render_frame(readback=False)
-        samples += app.stats().samples
-    for app in apps:
-        app.set_option(vrc.OPT_COUNT_SAMPLES, 0)
+    samples = app.stats().samples
+    app.set_option(vrc.OPT_COUNT_SAMPLES, 0)
     st = torch.tensor([samples], dtype=torch.int64, device="cuda")
     if world > 1:
         dist.all_reduce(st)
@@ -159,8 +178,8 @@ def main():
 
     for _ in range(a.warmup):
         frame()
-    for app in apps:
-        app.stats()  # reset the kernel-time accumulators
+    torch.cuda.synchronize()
+    all_slots(app.stats)  # reset the kernel-time accumulators
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -178,10 +197,9 @@ def main():
 
     # HIP-event kernel time of the timed region (events recorded on the render stream)
     ksum, klaunch = 0.0, 0
-    for app in apps:
-        s = app.stats()
-        ksum += s.kernel_ms_sum
-        klaunch += s.kernel_launches
+    for s_ in all_slots(app.stats):
+        ksum += s_.kernel_ms_sum
+        klaunch += s_.kernel_launches
     kt = torch.tensor([ksum], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
@@ -209,9 +227,10 @@ def main():
             "config": {"workload": "C2: %s uint8, %dx%d viewport, leaves only (%d bricks of %d^3), "
                                    "%d samples/ray, linear-ramp TF alpha=%.3g, default camera"
                                    % (uri, W, H, n_nodes, a.block + 8,
-                                      apps[0].stats().samples_per_ray, a.alpha),
-                       "parallelism": "sort-first, %d rank(s) x %d interleaved row band(s), "
-                                      "RGBA32F gather to rank 0" % (world, len(bands)),
+                                      app.stats().samples_per_ray, a.alpha),
+                       "parallelism": "sort-first, %d rank(s) x %d interleaved row band(s) in one "
+                                      "launch, RGBA32F gather to rank 0, %d frames in flight"
+                                      % (world, len(bands), K),
                        "samples_per_frame": samples_frame,
                        "first_frame_with_upload_ms": first_frame_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
@@ -228,8 +247,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a, samples_frame)
         print(json.dumps(out), flush=True)
 
-    for app in apps:
-        app.close()
+    app.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -60,6 +60,13 @@ int lvh_app_set_clip_planes( lvh_app* app, const float* planes, uint32_t n );
  * frame, stacked in that order in its pixel buffer (replaces params.tile; n = 0 -> back to it) */
 int lvh_app_set_bands( lvh_app* app, const uint32_t* y0, const uint32_t* h, uint32_t n );
 int lvh_app_set_option( lvh_app* app, int vrc_option, int64_t value );
+/* Frames in flight: the application keeps n Renderer("hip") instances (each with its own device
+ * context, stream and pixel buffer) over ONE pipeline (one brick atlas, one pair of caches), as
+ * RenderPipelinePlugin::render( Renderer&, ... ) allows; Equalizer's default latency of one frame
+ * (livre/eq/Client.cpp:210-237 frame loop) corresponds to n = 2.  select_slot chooses the instance
+ * the following set_stream / set_framebuffer / set_option / render_frame / get_stats calls use. */
+int lvh_app_set_frames_in_flight( lvh_app* app, uint32_t n );
+int lvh_app_select_slot( lvh_app* app, uint32_t slot );
 /* render on a caller-owned stream / into caller-owned device memory (tile gather) */
 int lvh_app_set_stream( lvh_app* app, void* hip_stream );
 int lvh_app_set_framebuffer( lvh_app* app, void* device_rgba );

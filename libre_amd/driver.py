@@ -26,7 +26,7 @@ class FrameStats(C.Structure):  # lvh_frame_stats
 EXPORTS = [
     "lvh_last_error", "lvh_app_create", "lvh_app_destroy", "lvh_app_set_camera",
     "lvh_app_set_modelview", "lvh_app_set_colormap", "lvh_app_set_clip_planes",
-    "lvh_app_set_bands", "lvh_app_set_option", "lvh_app_set_stream", "lvh_app_set_framebuffer", "lvh_app_render_frame",
+    "lvh_app_set_bands", "lvh_app_set_frames_in_flight", "lvh_app_select_slot", "lvh_app_set_option", "lvh_app_set_stream", "lvh_app_set_framebuffer", "lvh_app_render_frame",
     "lvh_app_get_stats", "lvh_app_wait_uploads", "lvh_app_synchronize", "lvh_app_volume_info",
     "lvh_app_visible_set", "lvh_app_view_matrices", "lvh_app_cache_stats", "lvh_select_visibles",
     "lvh_selftest_cache", "lvh_selftest_plugin_factory", "lvh_selftest_camera",
@@ -53,6 +53,8 @@ def load_library():
     L.lvh_app_set_colormap.argtypes = [vp, vp]
     L.lvh_app_set_clip_planes.argtypes = [vp, vp, C.c_uint32]
     L.lvh_app_set_bands.argtypes = [vp, vp, vp, C.c_uint32]
+    L.lvh_app_set_frames_in_flight.argtypes = [vp, C.c_uint32]
+    L.lvh_app_select_slot.argtypes = [vp, C.c_uint32]
     L.lvh_app_set_option.argtypes = [vp, C.c_int, C.c_int64]
     L.lvh_app_set_stream.argtypes = [vp, vp]
     L.lvh_app_set_framebuffer.argtypes = [vp, vp]
@@ -121,6 +123,12 @@ class App:
         h = (C.c_uint32 * max(1, n))(*[b[1] for b in bands])
         check(self.L, self.L.lvh_app_set_bands(self.h, y0, h, n))
         self.height = sum(b[1] for b in bands) if n else self.height
+
+    def set_frames_in_flight(self, n):
+        check(self.L, self.L.lvh_app_set_frames_in_flight(self.h, n))
+
+    def select_slot(self, slot):
+        check(self.L, self.L.lvh_app_select_slot(self.h, slot))
 
     def set_option(self, option, value):
         check(self.L, self.L.lvh_app_set_option(self.h, option, value))

@@ -31,10 +31,17 @@ struct lvh_app
     uint32_t frameId = 0;
     RenderStatistics lastStats;
     std::vector< uint32_t > rowMap; /* lvh_app_set_bands */
+    std::vector< std::unique_ptr< Renderer > > extraRenderers; /* frames in flight beyond the first */
+    uint32_t slot = 0;
+    std::string rendererName;
 
+    Renderer& currentRenderer()
+    {
+        return slot == 0 ? pipeline->getRenderer() : *extraRenderers[slot - 1];
+    }
     HipRaycastRenderer& renderer()
     {
-        return static_cast< HipRaycastRenderer& >( pipeline->getRenderer().getPlugin() );
+        return static_cast< HipRaycastRenderer& >( currentRenderer().getPlugin() );
     }
     HipRaycastPipeline& hipPipeline() { return static_cast< HipRaycastPipeline& >( pipeline->getPlugin() ); }
 
@@ -102,6 +109,7 @@ int lvh_app_create( const char* uri, const char* rendererName, const lvh_params*
         setHipDevice( p->device );
         app->dataSource.reset( new DataSource( std::string( uri ) ) );
         app->pipeline.reset( new RenderPipeline( rendererName ) );
+        app->rendererName = rendererName;
         RendererParameters& v = app->vrParameters;
         v.synchronousMode = p->synchronous != 0;
         v.samplesPerRay = p->samples_per_ray;
@@ -169,6 +177,32 @@ int lvh_app_set_clip_planes( lvh_app* app, const float* planes, uint32_t n )
         return fail( e.what() );          \
     }
 
+int lvh_app_set_frames_in_flight( lvh_app* app, uint32_t n )
+{
+    if( !app || n == 0 || n > 8 ) return fail( "lvh_app_set_frames_in_flight: 1..8 expected" );
+    try
+    {
+        while( app->extraRenderers.size() + 1 < n )
+            app->extraRenderers.emplace_back( new Renderer( app->rendererName ) );
+        while( app->extraRenderers.size() + 1 > n )
+            app->extraRenderers.pop_back();
+        if( app->slot >= n )
+            app->slot = 0;
+        return 0;
+    }
+    catch( const std::exception& e )
+    {
+        return fail( e.what() );
+    }
+}
+
+int lvh_app_select_slot( lvh_app* app, uint32_t slot )
+{
+    if( !app || slot > app->extraRenderers.size() ) return fail( "lvh_app_select_slot: no such slot" );
+    app->slot = slot;
+    return 0;
+}
+
 int lvh_app_set_option( lvh_app* app, int option, int64_t value )
 {
     if( !app ) return fail( "NULL argument" );
@@ -221,7 +255,7 @@ int lvh_app_render_frame( lvh_app* app, float* host, lvh_frame_stats* stats )
     try
     {
         const RenderInputs in = app->inputs();
-        app->lastStats = app->pipeline->render( in );
+        app->lastStats = app->pipeline->getPlugin().render( app->currentRenderer(), in );
         ++app->frameId;
         if( host )
             app->renderer().readFrame( host );

@@ -178,3 +178,24 @@ def test_row_bands_in_one_launch_are_rows_of_the_full_frame(drv):
         app.height = H
         fb2, _ = app.render_frame()
         assert (fb2 == full).all()
+
+
+def test_frames_in_flight_share_one_atlas(drv):
+    # K renderer instances over one pipeline (RenderPipelinePlugin::render takes the Renderer):
+    # every slot produces the same frame, bricks are uploaded once
+    with drv.App("hash://#64,64,64,16", 40, 40, synchronous=True, min_lod=2, max_lod=2,
+                 gpu_cache_mb=8) as app:
+        app.set_camera(spin=(0.5, 0.35))
+        app.set_colormap(orc.linear_ramp_tf(0.05))
+        app.set_frames_in_flight(3)
+        frames = []
+        for k in (0, 1, 2, 1, 0):
+            app.select_slot(k)
+            fb, st = app.render_frame()
+            frames.append(fb)
+        for fb in frames[1:]:
+            assert (fb == frames[0]).all()
+        tex, data = app.cache_stats()
+        assert tex["misses"] == 64 and tex["count"] == 64  # one upload per brick in total
+        with pytest.raises(drv.DriverError):
+            app.select_slot(3)
