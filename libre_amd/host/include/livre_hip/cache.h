@@ -6,6 +6,7 @@
 #ifndef LIVRE_HIP_CACHE_H
 #define LIVRE_HIP_CACHE_H
 
+#include <atomic>
 #include <deque>
 #include <exception>
 #include <sstream>
@@ -102,6 +103,15 @@ public:
     {
         if( cacheId == INVALID_CACHE_ID )
             return ObjectPtr();
+        {   /* hit: read lock only (Cache.ipp:149-155 also takes the read lock first) */
+            std::shared_lock< std::shared_timed_mutex > lock( _mutex );
+            const auto it = _cacheMap.find( cacheId );
+            if( it != _cacheMap.end() && it->second->obj )
+            {
+                _hits.fetch_add( 1, std::memory_order_relaxed );
+                return it->second->obj;
+            }
+        }
         std::shared_ptr< Entry > entry;
         {
             std::unique_lock< std::shared_timed_mutex > lock( _mutex );
@@ -111,7 +121,7 @@ public:
             entry = it->second;
             if( entry->obj )
             {
-                _statistics.notifyHit();
+                _hits.fetch_add( 1, std::memory_order_relaxed );
                 return entry->obj;
             }
             applyPolicy();
@@ -166,6 +176,7 @@ public:
         return _cacheMap.size();
     }
     const CacheStatistics& getStatistics() const { return _statistics; }
+    size_t getHits() const { return _hits.load(); }
 
     void purge()
     {
@@ -230,6 +241,7 @@ private:
 
     const size_t _maxMemBytes;
     CacheStatistics _statistics;
+    std::atomic< size_t > _hits{ 0 };
     mutable std::shared_timed_mutex _mutex;
     std::unordered_map< CacheId, std::shared_ptr< Entry > > _cacheMap;
     std::deque< CacheId > _lru;

@@ -209,6 +209,11 @@ public:
     virtual void update() {}
     /** DataSourcePlugin.cpp:55-81 */
     virtual LODNode internalNodeToLODNode( const NodeId& nodeId ) const;
+    /** true (default) when internalNodeToLODNode is plain arithmetic: getNode then computes the
+     *  node instead of going through the memoising map + read/write lock of
+     *  DataSourcePlugin.cpp:29-48 (same result; the per-frame path calls getNode thousands of
+     *  times).  A plugin with an expensive lookup (file-backed trees) returns false. */
+    virtual bool nodeLookupIsCheap() const { return true; }
 
 protected:
     VolumeInformation _volumeInfo;

@@ -54,11 +54,15 @@ public:
     Vector3f getTexPosition() const { return _texturePos; }
     Vector3f getTexSize() const { return _textureSize; }
     HipTexturePool& getTexturePool() const { return _texturePool; }
+    /** world box of the brick, kept from construction so the per-frame render path does not
+     *  look the node up again (not in the reference, which calls DataSource::getNode) */
+    const Boxf& getWorldBox() const { return _worldBox; }
 
 private:
     size_t _size;
     HipTexturePool& _texturePool;
     Vector3f _slotPosition, _texturePos, _textureSize;
+    Boxf _worldBox;
 };
 typedef std::shared_ptr< const HipTextureObject > ConstHipTextureObjectPtr;
 typedef Cache< HipTextureObject > HipTextureCache;

@@ -326,6 +326,8 @@ DataSourcePlugin::DataSourcePlugin() : _lodNodeMap( 128 ) {}
 
 LODNode DataSourcePlugin::getNode( const NodeId& nodeId ) const
 {
+    if( nodeLookupIsCheap() )
+        return internalNodeToLODNode( nodeId );
     {
         std::shared_lock< std::shared_timed_mutex > lock( _mutex );
         const auto it = _lodNodeMap.find( nodeId.getId() );

@@ -194,6 +194,7 @@ HipTextureObject::HipTextureObject( const CacheId& cacheId, const DataCache& dat
     const VolumeInformation& volInfo = dataSource.getVolumeInfo();
     _size = _texturePool.getSlotMemSize();
     const LODNode lodNode = dataSource.getNode( NodeId( cacheId ) );
+    _worldBox = lodNode.getWorldBox();
     _slotPosition = _texturePool.copyToSlot( static_cast< const uint8_t* >( data->getDataPtr() ),
                                              lodNode.getBlockSize() + volInfo.overlap * 2u );
     if( _slotPosition == INVALID_SLOT_POSITION )
@@ -310,7 +311,10 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
     std::vector< std::pair< float, ConstCacheObjectPtr > > keyed;
     keyed.reserve( renderData.size() );
     for( const auto& obj : renderData )
-        keyed.push_back( { nodeDistance( renderInputs.dataSource, frustum, NodeId( obj->getId() ) ), obj } );
+    {
+        const Boxf& box = static_cast< const HipTextureObject& >( *obj ).getWorldBox();
+        keyed.push_back( { ( frustum.getMVMatrix() * box.getCenter() ).length(), obj } );
+    }
     std::stable_sort( keyed.begin(), keyed.end(),
                       []( const std::pair< float, ConstCacheObjectPtr >& a,
                           const std::pair< float, ConstCacheObjectPtr >& b ) { return a.first < b.first; } );
@@ -323,8 +327,7 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
     {
         const ConstHipTextureObjectPtr hipObject =
             std::static_pointer_cast< const HipTextureObject >( kv.second );
-        const LODNode lodNode = renderInputs.dataSource.getNode( NodeId( hipObject->getId() ) );
-        const Boxf& aabb = lodNode.getWorldBox();
+        const Boxf& aabb = hipObject->getWorldBox();
         vrc_node_data nd;
         const Vector3f tp = hipObject->getTexPosition(), ts = hipObject->getTexSize(),
                        mn = aabb.getMin(), sz = aabb.getSize();
@@ -522,22 +525,27 @@ struct HipRaycastPipeline::Impl
     void renderSync( RenderStatistics& statistics, Renderer& renderer, const RenderInputs& in )
     {
         NodeIds nodeIds = visibleSet( in );
-        const Frustum& frustum = in.frameInfo.frustum;
-        std::vector< std::pair< float, NodeId > > keyed;
-        keyed.reserve( nodeIds.size() );
-        for( const NodeId& id : nodeIds )
-            keyed.push_back( { nodeDistance( in.dataSource, frustum, id ), id } );
-        std::stable_sort( keyed.begin(), keyed.end(),
-                          []( const std::pair< float, NodeId >& a, const std::pair< float, NodeId >& b ) {
-                              return a.first < b.first;
-                          } );
-        for( size_t i = 0; i < keyed.size(); ++i )
-            nodeIds[i] = keyed[i].second;
-
         const uint32_t maxNodesPerPass =
             uint32_t( _texturePool->getTextureMem() / _texturePool->getSlotMemSize() );
         const uint32_t numberOfPasses =
             uint32_t( std::ceil( float( nodeIds.size() ) / float( maxNodesPerPass ) ) );
+        if( numberOfPasses > 1 )
+        {
+            /* CudaRaycastPipeline.cpp:146-147: front-to-back order decides which bricks go into
+             * which pass.  With a single pass the order is irrelevant here (the renderer sorts
+             * the cache objects itself, CudaRaycastRenderer.cpp:160-163), so it is skipped. */
+            const Frustum& frustum = in.frameInfo.frustum;
+            std::vector< std::pair< float, NodeId > > keyed;
+            keyed.reserve( nodeIds.size() );
+            for( const NodeId& id : nodeIds )
+                keyed.push_back( { nodeDistance( in.dataSource, frustum, id ), id } );
+            std::stable_sort( keyed.begin(), keyed.end(),
+                              []( const std::pair< float, NodeId >& a, const std::pair< float, NodeId >& b ) {
+                                  return a.first < b.first;
+                              } );
+            for( size_t i = 0; i < keyed.size(); ++i )
+                nodeIds[i] = keyed[i].second;
+        }
         _lastPasses = numberOfPasses;
         for( uint32_t i = 0; i < numberOfPasses; ++i )
         {

@@ -198,12 +198,20 @@ bool DFSTraversal::traverse( const NodeId& nodeId, uint32_t depth, NodeVisitor& 
         _state.setVisitChild( true );
         return false;
     }
-    for( const NodeId& child : nodeId.getChildren() )
-    {
-        traverse( child, depth - 1, visitor );
-        if( !_state.getVisitNeighbours() )
-            break;
-    }
+    /* children in the order of NodeId::getChildren (x outer, y, z inner), without the vector */
+    const Vector3ui childPos = nodeId.getPosition() * 2u;
+    bool stop = false;
+    for( uint32_t x = 0; x < 2 && !stop; ++x )
+        for( uint32_t y = 0; y < 2 && !stop; ++y )
+            for( uint32_t z = 0; z < 2 && !stop; ++z )
+            {
+                traverse( NodeId( nodeId.getLevel() + 1,
+                                  Vector3ui( childPos[0] + x, childPos[1] + y, childPos[2] + z ),
+                                  nodeId.getTimeStep() ),
+                          depth - 1, visitor );
+                if( !_state.getVisitNeighbours() )
+                    stop = true;
+            }
     _state.setVisitNeighbours( true );
     const bool ret = _state.getBreakTraversal();
     _state.setBreakTraversal( false );
