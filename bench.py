@@ -206,6 +206,13 @@ def main():
     kernel_ms_per_frame = float(kt.item()) / a.steps  # slowest rank's kernels per frame
 
     if rank == 0:
+        # measured HBM traffic per launch, from the committed rocprofv3 PMC passes (bench.py cannot
+        # run the profiler on itself); only quoted for the workload it was measured on
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_traffic_c2.json")
+        if (world == 1 and a.voxels == 1024 and a.block == 128 and a.viewport == 1024
+                and tuple(a.spin) == (0.0, 0.0) and os.path.exists(tpath)):
+            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         n_nodes = (a.voxels // a.block) ** 3
         # interior voxels of marched bricks + one RGBA32F write + node table + TF.
         # With N ranks every rank marches (nearly) every brick for its rows: bricks count N times.
@@ -234,14 +241,16 @@ def main():
                        "samples_per_frame": samples_frame,
                        "first_frame_with_upload_ms": first_frame_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "vrc_k_raycast<true,false,false>",
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "vrc_k_raycast<true,false,false,true>",
                          "kernel_ms_per_frame": kernel_ms_per_frame,
                          "algorithmic_bytes_per_launch": per_rank_alg,
                          "algorithmic_bytes_per_frame_all_ranks": alg_bytes,
                          "launches_per_frame": 1,
-                         "note": "the kernel is VALU-issue bound, not HBM bound (DESIGN.md); "
-                                 "traffic: see profiles/ (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"},
+                         "note": "the kernel is bound by the texture-addresser (byte gathers, "
+                                 "TA_BUSY ~90 %) with VALU issue close behind, not by HBM "
+                                 "(DESIGN.md section 4); traffic = FETCH_SIZE + WRITE_SIZE bytes per "
+                                 "launch from profiles/r1_traffic_c2.json"},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, samples_frame)

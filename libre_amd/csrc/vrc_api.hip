@@ -860,7 +860,8 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     a.tileOrder = nullptr;
     if( c->optTileOrder )
     {
-        const size_t nTiles = (size_t)( ( c->fbW + 7 ) / 8 ) * ( ( c->fbH + 7 ) / 8 );
+        const size_t nTiles = (size_t)( ( c->fbW + VRC_TILE_W - 1 ) / VRC_TILE_W ) *
+                              ( ( c->fbH + VRC_TILE_H - 1 ) / VRC_TILE_H );
         if( nTiles > c->dTileOrderCap )
         {
             VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );

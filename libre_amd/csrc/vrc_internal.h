@@ -8,6 +8,12 @@
 
 #include "vrc_core.h"
 
+/* pixel tile of one wave64 */
+#ifndef VRC_TILE_W
+#define VRC_TILE_W 8u
+#endif
+#define VRC_TILE_H ( 64u / VRC_TILE_W )
+
 /* tf: 256 float4 (device).  lut: 257 float4 (device): (rgb*alpha', alpha'), entry 256 = 0. */
 hipError_t vrc_launch_build_lut( const float* tf, vrc_f4* lut, vrc_lut_params p,
                                  hipStream_t stream );

@@ -17,7 +17,7 @@
  */
 #include "vrc_internal.h"
 
-#define VRC_TILE 8u
+/* pixel tile of one wave: VRC_TILE_W x VRC_TILE_H = 64 (vrc_internal.h) */
 #define VRC_WG 64u
 
 /* classified-sample table (vrc_core.h: vrc_lut_entry): 256 entries per frame instead of a TF
@@ -173,7 +173,7 @@ __device__ __forceinline__ uint32_t vrc_tile_bucket( const vrc_frame& f, uint32_
                                                      uint32_t tilesX, float invDiag )
 {
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
-    uint32_t px = tx * VRC_TILE + VRC_TILE / 2, py = ty * VRC_TILE + VRC_TILE / 2;
+    uint32_t px = tx * VRC_TILE_W + VRC_TILE_W / 2, py = ty * VRC_TILE_H + VRC_TILE_H / 2;
     px = px < f.width ? px : f.width - 1;
     py = py < f.height ? py : f.height - 1;
     const vrc_ray r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
@@ -219,8 +219,8 @@ __global__ __launch_bounds__( 1024 ) void vrc_k_tile_order( const vrc_frame f,
 
 hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, hipStream_t stream )
 {
-    const uint32_t tilesX = ( f.width + VRC_TILE - 1 ) / VRC_TILE;
-    const uint32_t tilesY = ( f.height + VRC_TILE - 1 ) / VRC_TILE;
+    const uint32_t tilesX = ( f.width + VRC_TILE_W - 1 ) / VRC_TILE_W;
+    const uint32_t tilesY = ( f.height + VRC_TILE_H - 1 ) / VRC_TILE_H;
     hipLaunchKernelGGL( vrc_k_tile_order, dim3( 1 ), dim3( 1024 ), 0, stream, f, tilesX,
                         tilesX * tilesY, order );
     return hipGetLastError();
@@ -257,16 +257,16 @@ __global__ __launch_bounds__( VRC_WG, VRC_MIN_WAVES ) void vrc_k_raycast(
      * "Workgroup dispatch") every XCD gets the same mix and the long tiles start first. */
     const uint32_t tile = tileOrder ? tileOrder[blockIdx.x] : blockIdx.x;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
-#if defined( VRC_LANES_ROWMAJOR )
-    const uint32_t lx = lane & 7u, ly = lane >> 3;
+#if defined( VRC_LANES_ROWMAJOR ) || VRC_TILE_W != 8
+    const uint32_t lx = lane % VRC_TILE_W, ly = lane / VRC_TILE_W;
 #else
     /* Morton lane order: every 4 consecutive lanes (the unit the texture addresser works on)
      * are a 2x2 pixel quad, so their voxels usually share one 64-byte segment */
     const uint32_t lx = ( lane & 1u ) | ( ( lane >> 1 ) & 2u ) | ( ( lane >> 2 ) & 4u );
     const uint32_t ly = ( ( lane >> 1 ) & 1u ) | ( ( lane >> 2 ) & 2u ) | ( ( lane >> 3 ) & 4u );
 #endif
-    const uint32_t px = tx * VRC_TILE + lx;
-    const uint32_t py = ty * VRC_TILE + ly;
+    const uint32_t px = tx * VRC_TILE_W + lx;
+    const uint32_t py = ty * VRC_TILE_H + ly;
 
     uint32_t nSamples = 0;
     if( px < f.width && py < f.height )
@@ -293,8 +293,8 @@ __global__ __launch_bounds__( VRC_WG, VRC_MIN_WAVES ) void vrc_k_raycast(
 template < bool DDA, bool CLAMP, bool COUNT, bool FIXED >
 static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream )
 {
-    const uint32_t tilesX = ( a.frame.width + VRC_TILE - 1 ) / VRC_TILE;
-    const uint32_t tilesY = ( a.frame.height + VRC_TILE - 1 ) / VRC_TILE;
+    const uint32_t tilesX = ( a.frame.width + VRC_TILE_W - 1 ) / VRC_TILE_W;
+    const uint32_t tilesY = ( a.frame.height + VRC_TILE_H - 1 ) / VRC_TILE_H;
     const uint32_t nTiles = tilesX * tilesY;
     if( nTiles == 0 )
         return hipSuccess;
