@@ -81,8 +81,8 @@ typedef struct
 } vrc_stats;
 
 /* ---- options (vrc_set_option) ---------------------------------------------------------- */
-#define VRC_OPT_KERNEL 1          /* VRC_KERNEL_AUTO (default) | _REFERENCE_ORDER | _GRID_DDA */
-#define VRC_OPT_FILTER 2          /* 0 nearest (reference parity, default) | 1 trilinear (extension) */
+#define VRC_OPT_KERNEL 1          /* VRC_KERNEL_AUTO (default) | _REFERENCE_ORDER | _GRID_DDA | _LDS */
+#define VRC_OPT_FILTER 2          /* VRC_FILTER_NEAREST (reference parity, default) | VRC_FILTER_TRILINEAR */
 #define VRC_OPT_TF_FRAC_BITS 3    /* 8 (default, CUDA 1.8 fixed-point lerp weight) | 0 exact float */
 #define VRC_OPT_COUNT_SAMPLES 4   /* 0 (default) | 1: count composited samples (slower kernel) */
 #define VRC_OPT_TILE_ORDER 5      /* 1 (default): heaviest-first tile schedule | 0: row-major tiles */
@@ -90,9 +90,15 @@ typedef struct
                                    * voxel-space increments | 0 the reference's float world-space
                                    * accumulation (cuda/Renderer.cu:208: pos += step) */
 
+#define VRC_FILTER_NEAREST 0   /* cuda/TexturePool.cu:167 (cudaFilterModePoint): the reference */
+#define VRC_FILTER_TRILINEAR 1 /* extension: texel centres at i+0.5, float weights, transfer function
+                                * and opacity correction evaluated per sample on the interpolated density */
+
 #define VRC_KERNEL_AUTO 0
 #define VRC_KERNEL_REFERENCE_ORDER 1 /* O(nodes) loop per ray in host order, cuda/Renderer.cu:172-227 */
 #define VRC_KERNEL_GRID_DDA 2        /* 3-D DDA over the brick grid; needs a grid-aligned node set */
+#define VRC_KERNEL_LDS 3             /* grid DDA + voxels staged through LDS per wave and round (needs
+                                      * overlap >= 1); what AUTO picks for the trilinear filter */
 
 /* ---- context ---------------------------------------------------------------------------- */
 /* cuda::Renderer::Renderer() (cuda/Renderer.cu:234-238); device is explicit (fixes Q11) */

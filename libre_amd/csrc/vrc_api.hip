@@ -90,6 +90,7 @@ struct vrc_ctx
     bool lutValid = false;
     uint64_t lutTfVersion = 0;
     vrc_lut_params lutParams = { 0, 0, 0, 0 };
+    bool lutLinear = false;
 
     /* pixel buffer (cuda::PixelBufferObject) */
     vrc_f4* fbOwn = nullptr;
@@ -160,7 +161,7 @@ int vrc_ctx_create( int device, vrc_ctx** out )
     std::memset( c->planes, 0, sizeof( c->planes ) );
     hipError_t e = hipStreamCreateWithFlags( &c->ownStream, hipStreamNonBlocking );
     if( e == hipSuccess ) e = hipMalloc( &c->dTf, 256 * 4 * sizeof( float ) );
-    if( e == hipSuccess ) e = hipMalloc( &c->dLut, 257 * sizeof( vrc_f4 ) );
+    if( e == hipSuccess ) e = hipMalloc( &c->dLut, VRC_TFP_ENTRIES * sizeof( vrc_f4 ) );
     if( e == hipSuccess ) e = hipHostMalloc( &c->hTf, 256 * 4 * sizeof( float ) );
     if( e == hipSuccess ) e = hipMalloc( &c->dCounter, sizeof( unsigned long long ) );
     if( e == hipSuccess ) e = hipHostMalloc( &c->hCounter, sizeof( unsigned long long ) );
@@ -234,14 +235,13 @@ int vrc_set_option( vrc_ctx* c, int option, int64_t value )
     switch( option )
     {
     case VRC_OPT_KERNEL:
-        if( value < VRC_KERNEL_AUTO || value > VRC_KERNEL_GRID_DDA )
+        if( value < VRC_KERNEL_AUTO || value > VRC_KERNEL_LDS )
             return fail( VRC_EINVAL, "vrc_set_option: bad kernel variant" );
         c->optKernel = value;
         return VRC_OK;
     case VRC_OPT_FILTER:
-        if( value != 0 )
-            return fail( VRC_EUNSUPPORTED,
-                         "vrc_set_option: only nearest filtering (0) is implemented" );
+        if( value != VRC_FILTER_NEAREST && value != VRC_FILTER_TRILINEAR )
+            return fail( VRC_EINVAL, "vrc_set_option: filter is 0 (nearest) or 1 (trilinear)" );
         c->optFilter = value;
         return VRC_OK;
     case VRC_OPT_TF_FRAC_BITS:
@@ -471,9 +471,8 @@ static int pool_upload( vrc_pool* p, const void* src, bool srcIsDevice, const ui
             }
             const uint32_t base = vrc_slot_base( lay, o[0] / p->slotDim[0], o[1] / p->slotDim[1],
                                                  o[2] / p->slotDim[2] );
-            e = vrc_launch_repack_brick( devSrc, (uint8_t*)p->dAtlas + (size_t)base * p->elemBytes,
-                                         p->elemBytes, size, p->slotDim[0] / VRC_MB,
-                                         p->slotDim[1] / VRC_MB, p->uploadStream );
+            uint8_t* const slotPtr = (uint8_t*)p->dAtlas + (size_t)base * p->elemBytes;
+            e = vrc_launch_repack_brick( devSrc, slotPtr, p->elemBytes, size, p->slotDim, p->uploadStream );
         }
         if( e == hipSuccess )
             e = hipEventRecord( st.done, p->uploadStream );
@@ -785,11 +784,13 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     lp.rangeMax = render->dataSourceRange[1];
     lp.alphaCorrection = (float)render->maxSamplesPerRay / (float)render->samplesPerRay;
     lp.fracBits = (int)c->optTfFracBits;
-    if( !c->lutValid || c->lutTfVersion != c->tfVersion ||
+    const bool linear = c->optFilter == VRC_FILTER_TRILINEAR;
+    if( !c->lutValid || c->lutTfVersion != c->tfVersion || c->lutLinear != linear ||
         std::memcmp( &lp, &c->lutParams, sizeof( lp ) ) != 0 )
     {
-        VRC_HIP_CHECK( vrc_launch_build_lut( c->dTf, c->dLut, lp, c->stream ) );
+        VRC_HIP_CHECK( vrc_launch_build_lut( c->dTf, c->dLut, lp, linear, c->stream ) );
         c->lutParams = lp;
+        c->lutLinear = linear;
         c->lutTfVersion = c->tfVersion;
         c->lutValid = true;
     }
@@ -838,6 +839,13 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         useDda = false;
     else if( c->optKernel == VRC_KERNEL_GRID_DDA && !c->cachedGridOk )
         return fail( VRC_EINVAL, "vrc_render: node set is not grid-aligned; GRID_DDA unavailable" );
+    /* LDS-staged kernel: brick-grid DDA + unclamped sampler (overlap >= 1).  AUTO takes it for
+     * the trilinear filter (eight taps per sample), the gather kernel for point sampling. */
+    const bool ldsEligible = c->cachedGridOk && !c->cachedClamp;
+    if( c->optKernel == VRC_KERNEL_LDS && !ldsEligible )
+        return fail( VRC_EINVAL, "vrc_render: the LDS kernel needs a grid-aligned node set with overlap >= 1" );
+    const bool useLds = c->optKernel == VRC_KERNEL_LDS ||
+                        ( c->optKernel == VRC_KERNEL_AUTO && linear && ldsEligible );
 
     vrc_raycast_args a;
     std::memset( &a, 0, sizeof( a ) );
@@ -890,6 +898,8 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     a.clamp = c->cachedClamp;
     a.gridDda = useDda;
     a.fixedStepping = c->optStepping != 0;
+    a.linear = linear;
+    a.classifier = vrc_make_classifier( lp );
 
     /* order the march after every brick upload issued so far (fixes quirk Q9) */
     {
@@ -913,13 +923,14 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     }
     const auto& evp = c->evPairs[c->evUsed++];
     VRC_HIP_CHECK( hipEventRecord( evp.first, c->stream ) );
-    VRC_HIP_CHECK( vrc_launch_raycast( a, c->stream ) );
+    VRC_HIP_CHECK( useLds ? vrc_launch_raycast_lds( a, c->stream ) : vrc_launch_raycast( a, c->stream ) );
     VRC_HIP_CHECK( hipEventRecord( evp.second, c->stream ) );
     if( c->optCount )
         VRC_HIP_CHECK( hipMemcpyAsync( c->hCounter, c->dCounter, sizeof( unsigned long long ),
                                        hipMemcpyDeviceToHost, c->stream ) );
     c->timed = true;
-    c->stats.kernel_variant = useDda ? VRC_KERNEL_GRID_DDA : VRC_KERNEL_REFERENCE_ORDER;
+    c->stats.kernel_variant =
+        useLds ? VRC_KERNEL_LDS : ( useDda ? VRC_KERNEL_GRID_DDA : VRC_KERNEL_REFERENCE_ORDER );
     for( int i = 0; i < 3; ++i )
         c->stats.grid_dims[i] = useDda ? (uint32_t)f.gridDim[i] : 0u;
     return VRC_OK;

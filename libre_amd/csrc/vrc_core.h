@@ -616,11 +616,204 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
 }
 
 /* ------------------------------------------------------------------------------------------
+ * EXTENSION: trilinear volume filter (VRC_OPT_FILTER = 1).  Not in the reference, whose 3-D
+ * sampler is point-sampled (cuda/TexturePool.cu:167); named by the build's north star.  The
+ * integrator is the reference's, statement for statement, with the fetch replaced by a
+ * trilinear one (texel centres at i + 0.5, exact float weights, clamp addressing) -- the
+ * oracle's fetch_trilinear.  The density is then continuous, so the transfer function is
+ * evaluated per sample (post-classification, Renderer.cu:215-218) instead of through the
+ * 257-entry classified table:
+ *   tf = tex1D(tfTex, d*mult+add), alpha' = 1 - pow(1 - min(tf.a, 255/256), alphaCorrection).
+ * tfp is the transfer function padded by one entry on both sides (tfp[j] = tf[clamp(j-1)],
+ * 258 entries) so the two lerp operands need no index clamps.
+ * ---------------------------------------------------------------------------------------- */
+#define VRC_TFP_ENTRIES 258u
+
+struct vrc_classifier
+{
+    float mult, add;       /* u*256 - 0.5 = d*mult + add */
+    float alphaCorrection;
+    float q, invq;         /* TF lerp weight quantisation (2^fracBits), q = 0: exact */
+};
+
+VRC_HD vrc_classifier vrc_make_classifier( vrc_lut_params p )
+{
+    vrc_classifier k;
+    const float multiplyer = 1.0f / ( p.rangeMax - p.rangeMin );
+    const float addedValue = -p.rangeMin / ( p.rangeMax - p.rangeMin );
+    k.mult = multiplyer * 256.0f;
+    k.add = addedValue * 256.0f - 0.5f;
+    k.alphaCorrection = p.alphaCorrection;
+    k.q = p.fracBits > 0 ? (float)( 1 << p.fracBits ) : 0.0f;
+    k.invq = p.fracBits > 0 ? 1.0f / (float)( 1 << p.fracBits ) : 0.0f;
+    return k;
+}
+
+VRC_HD vrc_f4 vrc_classify( const vrc_f4* tfp, float d, const vrc_classifier& k )
+{
+    VRC_FAST_FP
+    float xB = d * k.mult + k.add;
+    xB = fminf( fmaxf( xB, -1.0f ), 255.99998f );
+    const float fl = floorf( xB );
+    float a = xB - fl;
+    if( k.q > 0.0f )
+        a = floorf( a * k.q + 0.5f ) * k.invq;
+    const int j = (int)fl + 1;
+    const vrc_f4 t0 = tfp[j], t1 = tfp[j + 1];
+    const float b = 1.0f - a;
+    const float cw = b * t0.w + a * t1.w;
+    const float corr = 1.0f - fminf( cw, 1.0f - 1.0f / 256.0f );
+#if defined( __HIP_DEVICE_COMPILE__ )
+    const float alpha = 1.0f - __builtin_amdgcn_exp2f( k.alphaCorrection * __builtin_amdgcn_logf( corr ) );
+#else
+    const float alpha = 1.0f - powf( corr, k.alphaCorrection );
+#endif
+    vrc_f4 e;
+    e.x = ( b * t0.x + a * t1.x ) * alpha;
+    e.y = ( b * t0.y + a * t1.y ) * alpha;
+    e.z = ( b * t0.z + a * t1.z ) * alpha;
+    e.w = alpha;
+    return e;
+}
+
+/* the eight taps of one sample: per-axis address parts (micro-blocked slot layout, see
+ * vrc_voxel_address) of floor(c) and floor(c)+1, and the weights */
+struct vrc_taps
+{
+    uint32_t ax[2], ay[2], az[2];
+    float wx, wy, wz;
+};
+
+template < bool CLAMP >
+VRC_HD vrc_taps vrc_trilinear_taps( const vrc_sampler& s, float lx, float ly, float lz )
+{
+    vrc_taps t;
+    /* texel centres at i + 0.5 */
+    float cx = lx - 0.5f, cy = ly - 0.5f, cz = lz - 0.5f;
+    const float fx = floorf( cx ), fy = floorf( cy ), fz = floorf( cz );
+    t.wx = cx - fx;
+    t.wy = cy - fy;
+    t.wz = cz - fz;
+    int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+    if( CLAMP )
+    {
+        const int hx = (int)s.hix, hy = (int)s.hiy, hz = (int)s.hiz;
+        x0 = x0 < 0 ? 0 : ( x0 > hx ? hx : x0 );
+        x1 = x1 < 0 ? 0 : ( x1 > hx ? hx : x1 );
+        y0 = y0 < 0 ? 0 : ( y0 > hy ? hy : y0 );
+        y1 = y1 < 0 ? 0 : ( y1 > hy ? hy : y1 );
+        z0 = z0 < 0 ? 0 : ( z0 > hz ? hz : z0 );
+        z1 = z1 < 0 ? 0 : ( z1 > hz ? hz : z1 );
+    }
+    const uint32_t ux[2] = { (uint32_t)x0, (uint32_t)x1 }, uy[2] = { (uint32_t)y0, (uint32_t)y1 },
+                   uz[2] = { (uint32_t)z0, (uint32_t)z1 };
+#pragma unroll
+    for( int i = 0; i < 2; ++i )
+    {
+        t.ax[i] = vrc_mul24( ux[i] >> VRC_MB_SHIFT, 504u ) + ux[i];
+        t.ay[i] = vrc_mul24( uy[i] >> VRC_MB_SHIFT, s.cyy ) + ( uy[i] << 3 );
+        t.az[i] = vrc_mul24( uz[i] >> VRC_MB_SHIFT, s.czz ) + ( uz[i] << 6 ) + s.slotBase;
+    }
+    return t;
+}
+
+VRC_HD float vrc_trilerp( const float v[8], float wx, float wy, float wz )
+{
+    VRC_FAST_FP
+    /* the oracle's order: x, then y, then z; a*(1-w) + b*w */
+    const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+    const float c00 = v[0] * ux + v[1] * wx;
+    const float c10 = v[2] * ux + v[3] * wx;
+    const float c01 = v[4] * ux + v[5] * wx;
+    const float c11 = v[6] * ux + v[7] * wx;
+    const float c0 = c00 * uy + c10 * wy;
+    const float c1 = c01 * uy + c11 * wy;
+    return c0 * uz + c1 * wz;
+}
+
+/* gather form of the trilinear march: eight byte gathers per sample, groups of
+ * VRC_LGROUP samples, general branch-free form throughout (a sample the reference loop would
+ * not reach reads element 0 and is blended with weight 0).  Sample positions follow the
+ * reference's float accumulation.  The LDS-staged kernel (vrc_kernels.hip) is the fast
+ * path for overlap >= 1; this form also serves the clamped sampler. */
+#ifndef VRC_LGROUP
+#define VRC_LGROUP 4
+#endif
+
+template < bool CLAMP, bool COUNT, typename ATLAS_T >
+VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n, vrc_segment s,
+                                      const ATLAS_T* __restrict__ atlas, const vrc_f4* tfp,
+                                      const vrc_classifier& cls, vrc_f4& color,
+                                      uint32_t& nSamples )
+{
+    const float stepSize = f.stepSize;
+    const vrc_sampler sm = vrc_make_sampler( n, f );
+    float travel = s.dist;
+    vrc_f3 pos = s.pos;
+    bool done = false;
+    while( travel > 0.0f && !done )
+    {
+        vrc_taps t[VRC_LGROUP];
+        bool valid[VRC_LGROUP];
+#pragma unroll
+        for( int k = 0; k < VRC_LGROUP; ++k )
+        {
+            VRC_FAST_FP
+            valid[k] = travel > 0.0f;
+            const float lx = ( pos.x - sm.minx ) * sm.kx + sm.ox;
+            const float ly = ( pos.y - sm.miny ) * sm.ky + sm.oy;
+            const float lz = ( pos.z - sm.minz ) * sm.kz + sm.oz;
+            t[k] = vrc_trilinear_taps< CLAMP >( sm, lx, ly, lz );
+            pos.x += s.step.x;
+            pos.y += s.step.y;
+            pos.z += s.step.z;
+            travel -= stepSize;
+        }
+        float v[VRC_LGROUP][8];
+#pragma unroll
+        for( int k = 0; k < VRC_LGROUP; ++k )
+#pragma unroll
+            for( int c = 0; c < 8; ++c )
+            {
+                const uint32_t e = t[k].ax[c & 1] + t[k].ay[( c >> 1 ) & 1] + t[k].az[c >> 2];
+                v[k][c] = (float)atlas[valid[k] ? e : 0u];
+            }
+#pragma unroll
+        for( int k = 0; k < VRC_LGROUP; ++k )
+        {
+            const float d = vrc_trilerp( v[k], t[k].wx, t[k].wy, t[k].wz );
+            const vrc_f4 e = vrc_classify( tfp, d, cls );
+            const bool active = valid[k] && !done;
+            vrc_composite( color, e, !active );
+            if( COUNT )
+                nSamples += active ? 1u : 0u;
+            done = done || ( active && color.w > VRC_EARLY_EXIT );
+        }
+    }
+    return done;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Reference-order pixel: the O(nodeCount) loop of Renderer.cu:172-227, nodes in host order.
  * ---------------------------------------------------------------------------------------- */
-template < bool CLAMP, bool COUNT, bool FIXED, typename ATLAS_T >
+/* lut: the classified table (257 entries), or with LINEAR the padded transfer function
+ * (VRC_TFP_ENTRIES) that cls classifies per sample */
+template < bool CLAMP, bool COUNT, bool FIXED, bool LINEAR, typename ATLAS_T >
+VRC_HD bool vrc_march_brick( const vrc_frame& f, const vrc_dev_node& n, const vrc_segment& s,
+                             const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
+                             const vrc_classifier& cls, vrc_f4& color, uint32_t& nSamples )
+{
+    if( LINEAR )
+        return vrc_march_segment_linear< CLAMP, COUNT, ATLAS_T >( f, n, s, atlas, lut, cls, color,
+                                                                  nSamples );
+    return vrc_march_segment< CLAMP, COUNT, FIXED, ATLAS_T >( f, n, s, atlas, lut, color, nSamples );
+}
+
+template < bool CLAMP, bool COUNT, bool FIXED, bool LINEAR, typename ATLAS_T >
 VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
                                        const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
+                                       const vrc_classifier& cls,
                                        vrc_f4* __restrict__ pixelBuffer, uint32_t px, uint32_t py,
                                        uint32_t& nSamples )
 {
@@ -642,7 +835,8 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
                 break;
             continue;
         }
-        if( vrc_march_segment< CLAMP, COUNT, FIXED, ATLAS_T >( f, n, s, atlas, lut, color, nSamples ) )
+        if( vrc_march_brick< CLAMP, COUNT, FIXED, LINEAR, ATLAS_T >( f, n, s, atlas, lut, cls, color,
+                                                                     nSamples ) )
             break;
     }
     pixelBuffer[pixelPos] = color; /* Renderer.cu:229 */
@@ -654,10 +848,11 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
  * For a regular single-LOD grid the along-ray order equals the reference's host order for
  * every pair of bricks that share a ray ("brick order").
  * ---------------------------------------------------------------------------------------- */
-template < bool CLAMP, bool COUNT, bool FIXED, typename ATLAS_T >
+template < bool CLAMP, bool COUNT, bool FIXED, bool LINEAR, typename ATLAS_T >
 VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
                                 const int32_t* __restrict__ gridTable,
                                 const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
+                                const vrc_classifier& cls,
                                 vrc_f4* __restrict__ pixelBuffer, uint32_t px, uint32_t py,
                                 uint32_t& nSamples )
 {
@@ -712,8 +907,8 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
                 bool stop;
                 if( vrc_brick_segment( r, n, f.stepSize, &s, &stop ) )
                 {
-                    if( vrc_march_segment< CLAMP, COUNT, FIXED, ATLAS_T >( f, n, s, atlas, lut, color,
-                                                                    nSamples ) )
+                    if( vrc_march_brick< CLAMP, COUNT, FIXED, LINEAR, ATLAS_T >( f, n, s, atlas, lut,
+                                                                                 cls, color, nSamples ) )
                         break;
                 }
                 else if( stop )

@@ -14,14 +14,16 @@
 #endif
 #define VRC_TILE_H ( 64u / VRC_TILE_W )
 
-/* tf: 256 float4 (device).  lut: 257 float4 (device): (rgb*alpha', alpha'), entry 256 = 0. */
-hipError_t vrc_launch_build_lut( const float* tf, vrc_f4* lut, vrc_lut_params p,
+/* tf: 256 float4 (device).  lut: VRC_TFP_ENTRIES float4 (device): the classified table
+ * (rgb*alpha', alpha') with entries 256.. = 0, or with linear the padded transfer function. */
+hipError_t vrc_launch_build_lut( const float* tf, vrc_f4* lut, vrc_lut_params p, bool linear,
                                  hipStream_t stream );
 
 /* row-major brick (size voxels, elemBytes per voxel) -> micro-blocked slot (slot = device
- * pointer to the slot's first element; sbx/sby = micro-blocks per slot row/column) */
+ * pointer to the slot's first element; slotDim = padded slot size in voxels).  A brick smaller
+ * than the slot gets its border voxels replicated into the padding. */
 hipError_t vrc_launch_repack_brick( const void* srcRowMajor, void* slot, uint32_t elemBytes,
-                                    const uint32_t size[3], uint32_t sbx, uint32_t sby,
+                                    const uint32_t size[3], const uint32_t slotDim[3],
                                     hipStream_t stream );
 
 /* inverse, for tests: logical atlas region -> row-major */
@@ -42,11 +44,16 @@ struct vrc_raycast_args
     bool clamp;
     bool gridDda;
     bool fixedStepping; /* VRC_OPT_STEPPING */
+    bool linear;        /* VRC_OPT_FILTER = 1: lut holds the padded transfer function */
+    vrc_classifier classifier;
 };
 
 /* heaviest-first tile schedule for the frame (order: one uint32 per 8x8 tile) */
 hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, hipStream_t stream );
 
 hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream );
+
+/* LDS-staged form (vrc_kernels_lds.hip): needs gridTable, !clamp, 8x8 tiles */
+hipError_t vrc_launch_raycast_lds( const vrc_raycast_args& a, hipStream_t stream );
 
 #endif

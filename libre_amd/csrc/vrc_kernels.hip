@@ -23,9 +23,21 @@
 /* classified-sample table (vrc_core.h: vrc_lut_entry): 256 entries per frame instead of a TF
  * fetch + pow per sample */
 __global__ void vrc_k_build_lut( const float* __restrict__ tf, vrc_f4* __restrict__ lut,
-                                 vrc_lut_params p )
+                                 vrc_lut_params p, int linear )
 {
     const uint32_t d = threadIdx.x;
+    if( linear )
+    {
+        /* trilinear filter: densities are continuous, the kernel classifies per sample from
+         * the transfer function padded by one entry on both sides (vrc_classify) */
+        for( uint32_t k = d; k < VRC_TFP_ENTRIES; k += blockDim.x )
+        {
+            const uint32_t i = k == 0u ? 0u : ( k - 1u > 255u ? 255u : k - 1u );
+            const vrc_f4 e = { tf[i * 4u], tf[i * 4u + 1u], tf[i * 4u + 2u], tf[i * 4u + 3u] };
+            lut[k] = e;
+        }
+        return;
+    }
     if( d < 256u )
         lut[d] = vrc_lut_entry( tf, d, p );
     if( d == 0 )
@@ -33,13 +45,15 @@ __global__ void vrc_k_build_lut( const float* __restrict__ tf, vrc_f4* __restric
         /* entry 256: the no-op sample (vrc_march_segment) */
         const vrc_f4 z = { 0.f, 0.f, 0.f, 0.f };
         lut[256] = z;
+        lut[257] = z;
     }
 }
 
-hipError_t vrc_launch_build_lut( const float* tf, vrc_f4* lut, vrc_lut_params p,
+hipError_t vrc_launch_build_lut( const float* tf, vrc_f4* lut, vrc_lut_params p, bool linear,
                                  hipStream_t stream )
 {
-    hipLaunchKernelGGL( vrc_k_build_lut, dim3( 1 ), dim3( 256 ), 0, stream, tf, lut, p );
+    hipLaunchKernelGGL( vrc_k_build_lut, dim3( 1 ), dim3( 256 ), 0, stream, tf, lut, p,
+                        linear ? 1 : 0 );
     return hipGetLastError();
 }
 
@@ -82,6 +96,28 @@ __global__ void vrc_k_repack_generic( const T* __restrict__ src, T* __restrict__
     }
 }
 
+/* brick smaller than its (8-voxel padded) slot: the slot padding gets the brick's border
+ * voxels, i.e. clamp addressing at the brick border is baked into the data -- what the
+ * clamped trilinear taps one voxel past the brick must read (cudaAddressModeClamp on a
+ * texture that ends with the brick, cuda/TexturePool.cu:163-170) */
+template < typename T >
+__global__ void vrc_k_repack_padded( const T* __restrict__ src, T* __restrict__ slot, uint32_t sx,
+                                     uint32_t sy, uint32_t sz, uint32_t dx, uint32_t dy,
+                                     uint32_t dz )
+{
+    const size_t total = (size_t)dx * dy * dz;
+    const uint32_t sbx = dx >> VRC_MB_SHIFT, sby = dy >> VRC_MB_SHIFT;
+    for( size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x )
+    {
+        const uint32_t x = (uint32_t)( i % dx );
+        const uint32_t y = (uint32_t)( ( i / dx ) % dy );
+        const uint32_t z = (uint32_t)( i / ( (size_t)dx * dy ) );
+        const uint32_t cx = x < sx ? x : sx - 1u, cy = y < sy ? y : sy - 1u, cz = z < sz ? z : sz - 1u;
+        slot[vrc_slot_local_index( x, y, z, sbx, sby )] = src[( (size_t)cz * sy + cy ) * sx + cx];
+    }
+}
+
 template < typename T >
 __global__ void vrc_k_read_region( const T* __restrict__ atlas, T* __restrict__ dst,
                                    uint32_t sx, uint32_t sy, uint32_t sz, uint32_t ox,
@@ -109,12 +145,30 @@ static uint32_t grid_for( size_t total, uint32_t block )
 }
 
 hipError_t vrc_launch_repack_brick( const void* src, void* slot, uint32_t elemBytes,
-                                    const uint32_t size[3], uint32_t sbx, uint32_t sby,
+                                    const uint32_t size[3], const uint32_t slotDim[3],
                                     hipStream_t stream )
 {
     const size_t total = (size_t)size[0] * size[1] * size[2];
     if( total == 0 )
         return hipSuccess;
+    const uint32_t sbx = slotDim[0] >> VRC_MB_SHIFT, sby = slotDim[1] >> VRC_MB_SHIFT;
+    if( size[0] != slotDim[0] || size[1] != slotDim[1] || size[2] != slotDim[2] )
+    {
+        const size_t all = (size_t)slotDim[0] * slotDim[1] * slotDim[2];
+        const dim3 g( grid_for( all, 256 ) ), b( 256 );
+        if( elemBytes == 1 )
+            hipLaunchKernelGGL( vrc_k_repack_padded< uint8_t >, g, b, 0, stream, (const uint8_t*)src,
+                                (uint8_t*)slot, size[0], size[1], size[2], slotDim[0], slotDim[1], slotDim[2] );
+        else if( elemBytes == 2 )
+            hipLaunchKernelGGL( vrc_k_repack_padded< uint16_t >, g, b, 0, stream, (const uint16_t*)src,
+                                (uint16_t*)slot, size[0], size[1], size[2], slotDim[0], slotDim[1], slotDim[2] );
+        else if( elemBytes == 4 )
+            hipLaunchKernelGGL( vrc_k_repack_padded< uint32_t >, g, b, 0, stream, (const uint32_t*)src,
+                                (uint32_t*)slot, size[0], size[1], size[2], slotDim[0], slotDim[1], slotDim[2] );
+        else
+            return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if( elemBytes == 1 && ( size[0] % 8u ) == 0 && ( ( (uintptr_t)src ) % 8u ) == 0 &&
         ( ( (uintptr_t)slot ) % 8u ) == 0 && total / 8 < 0xFFFFFFFFull )
     {
@@ -232,21 +286,22 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, hipStream
 #ifndef VRC_MIN_WAVES
 #define VRC_MIN_WAVES 4
 #endif
-template < bool DDA, bool CLAMP, bool COUNT, bool FIXED >
+template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, bool LINEAR >
 __global__ __launch_bounds__( VRC_WG, VRC_MIN_WAVES ) void vrc_k_raycast(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ gridTable, const uint8_t* __restrict__ atlas,
-    const vrc_f4* __restrict__ lutGlobal, vrc_f4* __restrict__ pixelBuffer,
-    unsigned long long* __restrict__ sampleCounter, const uint32_t* __restrict__ tileOrder,
-    const uint32_t tilesX, const uint32_t nTiles )
+    const vrc_f4* __restrict__ lutGlobal, const vrc_classifier cls,
+    vrc_f4* __restrict__ pixelBuffer, unsigned long long* __restrict__ sampleCounter,
+    const uint32_t* __restrict__ tileOrder, const uint32_t tilesX, const uint32_t nTiles )
 {
-    __shared__ vrc_f4 lut[257];
+    /* classified table (257 entries) or, with LINEAR, the padded transfer function (258) */
+    __shared__ vrc_f4 lut[VRC_TFP_ENTRIES];
     const uint32_t lane = threadIdx.x;
 #pragma unroll
     for( uint32_t i = 0; i < 256u / VRC_WG; ++i )
         lut[lane + i * VRC_WG] = lutGlobal[lane + i * VRC_WG];
-    if( lane == 0 )
-        lut[256] = lutGlobal[256];
+    if( lane < VRC_TFP_ENTRIES - 256u )
+        lut[256u + lane] = lutGlobal[256u + lane];
     __syncthreads();
 
     /* Workgroup -> tile.  Ray lengths vary by more than 2x over the image and whole tiles miss
@@ -272,11 +327,11 @@ __global__ __launch_bounds__( VRC_WG, VRC_MIN_WAVES ) void vrc_k_raycast(
     if( px < f.width && py < f.height )
     {
         if( DDA )
-            vrc_pixel_grid_dda< CLAMP, COUNT, FIXED, uint8_t >( f, nodes, gridTable, atlas, lut,
-                                                                pixelBuffer, px, py, nSamples );
+            vrc_pixel_grid_dda< CLAMP, COUNT, FIXED, LINEAR, uint8_t >(
+                f, nodes, gridTable, atlas, lut, cls, pixelBuffer, px, py, nSamples );
         else
-            vrc_pixel_reference_order< CLAMP, COUNT, FIXED, uint8_t >( f, nodes, atlas, lut,
-                                                                       pixelBuffer, px, py, nSamples );
+            vrc_pixel_reference_order< CLAMP, COUNT, FIXED, LINEAR, uint8_t >(
+                f, nodes, atlas, lut, cls, pixelBuffer, px, py, nSamples );
     }
     if( COUNT )
     {
@@ -290,7 +345,7 @@ __global__ __launch_bounds__( VRC_WG, VRC_MIN_WAVES ) void vrc_k_raycast(
     }
 }
 
-template < bool DDA, bool CLAMP, bool COUNT, bool FIXED >
+template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, bool LINEAR >
 static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream )
 {
     const uint32_t tilesX = ( a.frame.width + VRC_TILE_W - 1 ) / VRC_TILE_W;
@@ -298,31 +353,48 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
     const uint32_t nTiles = tilesX * tilesY;
     if( nTiles == 0 )
         return hipSuccess;
-    hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED > ), dim3( nTiles ), dim3( VRC_WG ),
-                        0, stream, a.frame, a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut,
-                        a.pixelBuffer, a.sampleCounter, a.tileOrder, tilesX, nTiles );
+    hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, LINEAR > ), dim3( nTiles ),
+                        dim3( VRC_WG ), 0, stream, a.frame, a.nodes, a.gridTable,
+                        (const uint8_t*)a.atlas, a.lut, a.classifier, a.pixelBuffer,
+                        a.sampleCounter, a.tileOrder, tilesX, nTiles );
     return hipGetLastError();
 }
 
 hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
 {
     const bool count = a.sampleCounter != nullptr;
+    if( a.linear )
+    {
+        /* trilinear extension: gather form (float stepping) */
+        const int key = ( a.gridDda ? 4 : 0 ) | ( a.clamp ? 2 : 0 ) | ( count ? 1 : 0 );
+        switch( key )
+        {
+        case 0: return launch_variant< false, false, false, false, true >( a, stream );
+        case 1: return launch_variant< false, false, true, false, true >( a, stream );
+        case 2: return launch_variant< false, true, false, false, true >( a, stream );
+        case 3: return launch_variant< false, true, true, false, true >( a, stream );
+        case 4: return launch_variant< true, false, false, false, true >( a, stream );
+        case 5: return launch_variant< true, false, true, false, true >( a, stream );
+        case 6: return launch_variant< true, true, false, false, true >( a, stream );
+        default: return launch_variant< true, true, true, false, true >( a, stream );
+        }
+    }
     /* the clamped sampler (overlap 0) always uses the float position chain */
     const bool fixed = a.fixedStepping && !a.clamp;
     const int key = ( fixed ? 8 : 0 ) | ( a.gridDda ? 4 : 0 ) | ( a.clamp ? 2 : 0 ) | ( count ? 1 : 0 );
     switch( key )
     {
-    case 0: return launch_variant< false, false, false, false >( a, stream );
-    case 1: return launch_variant< false, false, true, false >( a, stream );
-    case 2: return launch_variant< false, true, false, false >( a, stream );
-    case 3: return launch_variant< false, true, true, false >( a, stream );
-    case 4: return launch_variant< true, false, false, false >( a, stream );
-    case 5: return launch_variant< true, false, true, false >( a, stream );
-    case 6: return launch_variant< true, true, false, false >( a, stream );
-    case 7: return launch_variant< true, true, true, false >( a, stream );
-    case 8: return launch_variant< false, false, false, true >( a, stream );
-    case 9: return launch_variant< false, false, true, true >( a, stream );
-    case 12: return launch_variant< true, false, false, true >( a, stream );
-    default: return launch_variant< true, false, true, true >( a, stream );
+    case 0: return launch_variant< false, false, false, false, false >( a, stream );
+    case 1: return launch_variant< false, false, true, false, false >( a, stream );
+    case 2: return launch_variant< false, true, false, false, false >( a, stream );
+    case 3: return launch_variant< false, true, true, false, false >( a, stream );
+    case 4: return launch_variant< true, false, false, false, false >( a, stream );
+    case 5: return launch_variant< true, false, true, false, false >( a, stream );
+    case 6: return launch_variant< true, true, false, false, false >( a, stream );
+    case 7: return launch_variant< true, true, true, false, false >( a, stream );
+    case 8: return launch_variant< false, false, false, true, false >( a, stream );
+    case 9: return launch_variant< false, false, true, true, false >( a, stream );
+    case 12: return launch_variant< true, false, false, true, false >( a, stream );
+    default: return launch_variant< true, false, true, true, false >( a, stream );
     }
 }

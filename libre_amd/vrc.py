@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvrc_hip.so")
 
 VRC_OK, VRC_EINVAL, VRC_EHIP, VRC_EFULL, VRC_ENOMEM, VRC_EUNSUPPORTED = range(6)
 OPT_KERNEL, OPT_FILTER, OPT_TF_FRAC_BITS, OPT_COUNT_SAMPLES, OPT_TILE_ORDER, OPT_STEPPING = range(1, 7)
-KERNEL_AUTO, KERNEL_REFERENCE_ORDER, KERNEL_GRID_DDA = 0, 1, 2
+FILTER_NEAREST, FILTER_TRILINEAR = 0, 1
+KERNEL_AUTO, KERNEL_REFERENCE_ORDER, KERNEL_GRID_DDA, KERNEL_LDS = 0, 1, 2, 3
 
 f32x3 = C.c_float * 3
 u32x3 = C.c_uint32 * 3

@@ -66,37 +66,50 @@ extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atla
     vrc_fill_frame( f, *view, *render, geom, t.g, pl, nPlanes, nNodes, W, H, (float)pixelOffX,
                     (float)pixelOffY );
 
-    const bool dda = kernel == 2 || kernel == 4;
+    /* kernel: 1 reference order, 2 grid DDA, 3/4 the same with fixed-point stepping,
+     * 5/6 the same with the trilinear filter (extension) */
+    const bool linear = kernel == 5 || kernel == 6;
+    const bool dda = kernel == 2 || kernel == 4 || kernel == 6;
     const bool fixed = ( kernel == 3 || kernel == 4 ) && !t.clamp;
     if( dda && !t.gridOk )
         return 2;
+    const vrc_classifier cls = vrc_make_classifier( lp );
+    std::vector< vrc_f4 > tfp( VRC_TFP_ENTRIES );
+    for( uint32_t k = 0; k < VRC_TFP_ENTRIES; ++k )
+    {
+        const uint32_t i = k == 0 ? 0u : ( k - 1u > 255u ? 255u : k - 1u );
+        tfp[k] = vrc_f4{ tf[i * 4], tf[i * 4 + 1], tf[i * 4 + 2], tf[i * 4 + 3] };
+    }
+    const vrc_f4* table = linear ? tfp.data() : lut.data();
     uint64_t total = 0;
     vrc_f4* pb = reinterpret_cast< vrc_f4* >( pixelBuffer );
     for( uint32_t py = 0; py < H; ++py )
         for( uint32_t px = 0; px < W; ++px )
         {
             uint32_t n = 0;
-#define PIXEL( FN, CL, FX ) \
-    FN< CL, true, FX, uint8_t >
+#define PIXEL( FN, CL, FX, LN ) \
+    FN< CL, true, FX, LN, uint8_t >
+#define ARGS_DDA f, t.nodes.data(), t.grid.data(), atlas.data(), table, cls, pb, px, py, n
+#define ARGS_REF f, t.nodes.data(), atlas.data(), table, cls, pb, px, py, n
             if( dda )
             {
-                if( t.clamp )
-                    vrc_pixel_grid_dda< true, true, false, uint8_t >( f, t.nodes.data(), t.grid.data(), atlas.data(), lut.data(), pb, px, py, n );
-                else if( fixed )
-                    vrc_pixel_grid_dda< false, true, true, uint8_t >( f, t.nodes.data(), t.grid.data(), atlas.data(), lut.data(), pb, px, py, n );
-                else
-                    vrc_pixel_grid_dda< false, true, false, uint8_t >( f, t.nodes.data(), t.grid.data(), atlas.data(), lut.data(), pb, px, py, n );
+                if( linear && t.clamp ) PIXEL( vrc_pixel_grid_dda, true, false, true )( ARGS_DDA );
+                else if( linear ) PIXEL( vrc_pixel_grid_dda, false, false, true )( ARGS_DDA );
+                else if( t.clamp ) PIXEL( vrc_pixel_grid_dda, true, false, false )( ARGS_DDA );
+                else if( fixed ) PIXEL( vrc_pixel_grid_dda, false, true, false )( ARGS_DDA );
+                else PIXEL( vrc_pixel_grid_dda, false, false, false )( ARGS_DDA );
             }
             else
             {
-                if( t.clamp )
-                    vrc_pixel_reference_order< true, true, false, uint8_t >( f, t.nodes.data(), atlas.data(), lut.data(), pb, px, py, n );
-                else if( fixed )
-                    vrc_pixel_reference_order< false, true, true, uint8_t >( f, t.nodes.data(), atlas.data(), lut.data(), pb, px, py, n );
-                else
-                    vrc_pixel_reference_order< false, true, false, uint8_t >( f, t.nodes.data(), atlas.data(), lut.data(), pb, px, py, n );
+                if( linear && t.clamp ) PIXEL( vrc_pixel_reference_order, true, false, true )( ARGS_REF );
+                else if( linear ) PIXEL( vrc_pixel_reference_order, false, false, true )( ARGS_REF );
+                else if( t.clamp ) PIXEL( vrc_pixel_reference_order, true, false, false )( ARGS_REF );
+                else if( fixed ) PIXEL( vrc_pixel_reference_order, false, true, false )( ARGS_REF );
+                else PIXEL( vrc_pixel_reference_order, false, false, false )( ARGS_REF );
             }
 #undef PIXEL
+#undef ARGS_DDA
+#undef ARGS_REF
             total += n;
         }
     if( samplesOut )

@@ -187,3 +187,32 @@ def test_fixed_point_stepping_matches_oracle(name):
     # same sample count as the float chain: the stepping changes positions, never the count
     _, n_float, _ = orc.harness_render(s, kernel=2)
     assert n_got == n_float
+
+
+@pytest.mark.parametrize("name", sorted(scenes.SCENES))
+def test_trilinear_extension_matches_oracle(name):
+    # VRC_OPT_FILTER = 1: the reference integrator with a trilinear fetch and per-sample
+    # classification (extension; the oracle's fetch_trilinear is the definition)
+    s = scenes.get(name)
+    want, n_want = orc.oracle_render(s, threads=4, filter_mode=1)
+    for kernel in (5, 6):  # reference order / grid DDA
+        got, n_got, _ = orc.harness_render(s, kernel=kernel)
+        scenes.assert_parity(got, want, "%s k%d" % (name, kernel))
+        assert abs(n_got - n_want) <= 2e-4 * n_want + 8
+
+
+def test_trilinear_differs_from_nearest_on_noise():
+    # the parity tolerance must be able to tell the two filters apart
+    s = scenes.get("hash64_ert")
+    near, _ = orc.oracle_render(s, threads=4)
+    lin, _ = orc.oracle_render(s, threads=4, filter_mode=1)
+    assert np.abs(near - lin).max() > 10 * scenes.MAX_ABS
+
+
+def test_trilinear_nucleon_clamped_sampler():
+    s = scenes.nucleon_scene()
+    want, n_want = orc.oracle_render(s, threads=4, filter_mode=1)
+    for kernel in (5, 6):
+        got, n_got, _ = orc.harness_render(s, kernel=kernel)
+        scenes.assert_parity(got, want, "nucleon linear k%d" % kernel)
+        assert n_got == n_want

@@ -84,6 +84,65 @@ def test_scene_parity_both_kernels(vrc, golden, name):
         assert n_flt == n_dda
 
 
+@pytest.mark.parametrize("name", sorted(scenes.SCENES))
+def test_trilinear_extension_parity(vrc, name):
+    # VRC_OPT_FILTER = 1 against the oracle's fetch_trilinear (extension; the reference is
+    # point-sampled)
+    s = scenes.get(name)
+    want, n_want = orc.oracle_render(s, threads=8, filter_mode=1)
+    with _gpu(s) as g:
+        for k in (vrc.KERNEL_REFERENCE_ORDER, vrc.KERNEL_GRID_DDA):
+            got, n_got, st = g.render(kernel=k, filter_mode=vrc.FILTER_TRILINEAR)
+            assert st.kernel_variant == k
+            scenes.assert_parity(got, want, name + " trilinear k%d" % k)
+            assert abs(n_got - n_want) <= 2e-4 * n_want + 8
+        # switching back rebuilds the classified table
+        near, _, _ = g.render(kernel=vrc.KERNEL_GRID_DDA)
+        scenes.assert_parity(near, orc.oracle_render(s, threads=8)[0], name + " nearest after trilinear")
+
+
+@pytest.mark.parametrize("name", sorted(scenes.SCENES))
+def test_lds_staged_kernel_parity(vrc, name):
+    # VRC_KERNEL_LDS: same sample sequence as the gather kernel with fixed-point stepping,
+    # voxels read from LDS-staged boxes; point-sampled and trilinear
+    s = scenes.get(name)
+    want, n_want = orc.oracle_render(s, threads=8)
+    want_lin, n_want_lin = orc.oracle_render(s, threads=8, filter_mode=1)
+    with _gpu(s) as g:
+        got, n_got, st = g.render(kernel=vrc.KERNEL_LDS)
+        assert st.kernel_variant == vrc.KERNEL_LDS
+        scenes.assert_parity(got, want, name + " lds nearest")
+        assert abs(n_got - n_want) <= 2e-4 * n_want + 8
+        dda, n_dda, _ = g.render(kernel=vrc.KERNEL_GRID_DDA)
+        assert n_got == n_dda  # identical sample sequence ...
+        assert np.abs(got - dda).max() <= 1e-6  # ... and (up to blend order: none) identical frame
+        lin, n_lin, st = g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_LDS
+        scenes.assert_parity(lin, want_lin, name + " lds trilinear")
+        assert abs(n_lin - n_want_lin) <= 2e-4 * n_want_lin + 8
+        auto, _, st = g.render(filter_mode=vrc.FILTER_TRILINEAR, count=False)
+        assert st.kernel_variant == vrc.KERNEL_LDS  # AUTO + trilinear
+        assert (auto == lin).all()
+
+
+def test_lds_kernel_refuses_clamped_sampler(vrc):
+    s = scenes.nucleon_scene()
+    with _gpu(s) as g:
+        with pytest.raises(Exception):
+            g.render(kernel=vrc.KERNEL_LDS)
+        got, _, st = g.render(filter_mode=vrc.FILTER_TRILINEAR)  # AUTO falls back to the gather form
+        assert st.kernel_variant == vrc.KERNEL_GRID_DDA
+
+
+def test_trilinear_nucleon_clamped(vrc):
+    s = scenes.nucleon_scene()
+    want, n_want = orc.oracle_render(s, threads=8, filter_mode=1)
+    with _gpu(s) as g:
+        got, n_got, _ = g.render(filter_mode=vrc.FILTER_TRILINEAR)
+    scenes.assert_parity(got, want, "nucleon trilinear")
+    assert n_got == n_want
+
+
 def test_c1_config_parity(vrc):
     # mem://#128,128,128,32, 512^2 viewport, 512 samples/ray, 64 leaf bricks
     s = orc.build_scene(voxels=(128, 128, 128), block=32, viewport=(512, 512))
@@ -191,7 +250,8 @@ def test_error_paths(vrc):
     # render before pre_render
     assert L.vrc_render(ctx, view, nodes, s.n_nodes, render, pool) == vrc.VRC_EINVAL
     assert L.vrc_update(ctx, None, None, 7) == vrc.VRC_EINVAL
-    assert L.vrc_set_option(ctx, vrc.OPT_FILTER, 1) == vrc.VRC_EUNSUPPORTED
+    assert L.vrc_set_option(ctx, vrc.OPT_FILTER, 2) == vrc.VRC_EINVAL
+    assert L.vrc_set_option(ctx, vrc.OPT_KERNEL, 4) == vrc.VRC_EINVAL
     assert L.vrc_set_option(ctx, 999, 1) == vrc.VRC_EINVAL
     vrc.check(L, L.vrc_pre_render(ctx, view))
     # empty node list renders nothing (CudaRaycastRenderer.cpp:157-158)

@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--ref-order", action="store_true")
     ap.add_argument("--no-tile-order", action="store_true")
     ap.add_argument("--stepping", type=int, default=1)
+    ap.add_argument("--kernels", type=int, nargs="*", default=None,
+                    help="VRC_KERNEL_* codes to time (default: 2 = grid DDA gather kernel)")
+    ap.add_argument("--filters", type=int, nargs="*", default=[0], help="0 nearest, 1 trilinear")
     a = ap.parse_args()
     t0 = time.time()
     s = orc.build_scene(voxels=(a.voxels,) * 3, block=a.block, viewport=(a.viewport,) * 2,
@@ -47,8 +50,11 @@ def main():
         vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_TILE_ORDER, 0 if a.no_tile_order else 1))
         vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_STEPPING, a.stepping))
         kernels = [vrc.KERNEL_GRID_DDA] + ([vrc.KERNEL_REFERENCE_ORDER] if a.ref_order else [])
-        for k in kernels:
+        if a.kernels:
+            kernels = a.kernels
+        for k, flt in [(k, flt) for flt in a.filters for k in kernels]:
             vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_KERNEL, k))
+            vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_FILTER, flt))
             ms = []
             stt = vrc.Stats()
             for i in range(a.steps + 2):
@@ -59,8 +65,8 @@ def main():
                     ms.append(stt.kernel_ms)
             ms = np.array(ms)
             A = a.voxels ** 3 + a.viewport ** 2 * 16 + s.n_nodes * 48 + 4096
-            print("kernel %d: median %.3f ms min %.3f ms -> %.1f Msamples/s, %.1f fps, algorithmic %.1f GB/s"
-                  % (k, np.median(ms), ms.min(), n / np.median(ms) / 1e3, 1e3 / np.median(ms),
+            print("kernel %d filter %d: median %.3f ms min %.3f ms -> %.1f Msamples/s, %.1f fps, algorithmic %.1f GB/s"
+                  % (k, flt, np.median(ms), ms.min(), n / np.median(ms) / 1e3, 1e3 / np.median(ms),
                      A / np.median(ms) / 1e6), flush=True)
 
 

@@ -6,7 +6,7 @@ import os
 import sys
 
 
-def main(d, kernel_filter="vrc_k_raycast"):
+def main(d, kernel_filter="vrc_k_raycast", variant="true, false, false"):
     out = []
     for f in glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")):
         out.append("== kernel stats (rocprofv3 --kernel-trace --stats)")
@@ -21,7 +21,7 @@ def main(d, kernel_filter="vrc_k_raycast"):
             agg = collections.defaultdict(list)
             meta = None
             for r in csv.DictReader(open(f)):
-                if kernel_filter in r["Kernel_Name"] and "true, false, false" in r["Kernel_Name"]:
+                if kernel_filter in r["Kernel_Name"] and variant in r["Kernel_Name"]:
                     agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                     meta = r
             for k, v in sorted(agg.items()):
@@ -33,4 +33,4 @@ def main(d, kernel_filter="vrc_k_raycast"):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], *(sys.argv[2:3]))
+    main(sys.argv[1], *(sys.argv[2:4]))
