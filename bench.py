@@ -44,6 +44,7 @@ def parse():
                          "launch), 3 when the frame is split over several GPUs and each has idle "
                          "capacity (Equalizer renders ahead too: its default latency is one frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the trilinear-extension measurement")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=16, help="oracle threads (GPU box CPU share)")
     return ap.parse_args()
@@ -205,6 +206,34 @@ def main():
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
     kernel_ms_per_frame = float(kt.item()) / a.steps  # slowest rank's kernels per frame
 
+    # extension, outside the judged number: the trilinear filter (north star) on the same
+    # workload, kernel time from the library's HIP events
+    trilinear = None
+    if world == 1 and not a.no_extras:
+        app.select_slot(0)
+        app.set_option(vrc.OPT_FILTER, vrc.FILTER_TRILINEAR)
+        app.set_option(vrc.OPT_COUNT_SAMPLES, 1)
+        with torch.cuda.stream(streams[0]):
+            app.render_frame(readback=False)
+        tri_samples = app.stats().samples
+        app.set_option(vrc.OPT_COUNT_SAMPLES, 0)
+        with torch.cuda.stream(streams[0]):
+            for _ in range(5):
+                app.render_frame(readback=False)
+            torch.cuda.synchronize()
+            app.stats()
+            for _ in range(20):
+                app.render_frame(readback=False)
+        torch.cuda.synchronize()
+        st_ = app.stats()
+        tri_ms = st_.kernel_ms_sum / max(1, st_.kernel_launches)
+        trilinear = {"kernel": "vrc_k_raycast_lds<false,true> (voxels staged through LDS per wave)",
+                     "kernel_ms_per_frame": tri_ms, "samples_per_frame": int(tri_samples),
+                     "Msamples_per_s": tri_samples / tri_ms / 1e3,
+                     "lds_request_rate_GBps": tri_samples * 8 / tri_ms / 1e6,
+                     "note": "8 taps x 1 B per sample, labelled L2/LDS request rate (SURVEY 8d), not HBM"}
+        app.set_option(vrc.OPT_FILTER, vrc.FILTER_NEAREST)
+
     if rank == 0:
         # measured HBM traffic per launch, from the committed rocprofv3 PMC passes (bench.py cannot
         # run the profiler on itself); only quoted for the workload it was measured on
@@ -239,7 +268,8 @@ def main():
                                       "launch, RGBA32F gather to rank 0, %d frames in flight"
                                       % (world, len(bands), K),
                        "samples_per_frame": samples_frame,
-                       "first_frame_with_upload_ms": first_frame_ms},
+                       "first_frame_with_upload_ms": first_frame_ms,
+                       "extension_trilinear": trilinear},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "vrc_k_raycast<true,false,false,true>",

@@ -6,8 +6,9 @@
  *   - one wave64 = one 8x8 pixel tile, one workgroup = one wave, so the hardware
  *     dispatcher load-balances tiles (ray lengths differ by >2x across the image) and
  *     no barrier is needed after the table is staged;
- *   - workgroup -> tile mapping is XCD-aware: the 8 XCDs each take a contiguous band of
- *     tile rows, so neighbouring tiles (which share atlas micro-blocks) hit the same L2;
+ *   - workgroup -> tile mapping: tiles heaviest-first (vrc_k_tile_order); the dispatcher
+ *     deals workgroups round-robin over the 8 XCDs, so every XCD gets the same mix (a
+ *     contiguous band per XCD was measured slower: there is next to no inter-tile reuse);
  *   - the atlas is read as 8x8x8-voxel micro-blocks (one z-slice of a block = one 64-byte
  *     segment), so the 64 fetches of a wave step land in a handful of cache lines;
  *   - TF lookup + opacity correction are folded into a 256-entry classified table staged
