@@ -876,13 +876,16 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
             if( c->dTileOrder ) VRC_HIP_CHECK( hipFree( c->dTileOrder ) );
             c->dTileOrder = nullptr;
             c->dTileOrderCap = 0;
-            VRC_HIP_CHECK( hipMalloc( &c->dTileOrder, nTiles * sizeof( uint32_t ) ) );
+            /* order[nTiles] | scratch[VRC_TILE_SCRATCH_WORDS] | bucket[nTiles] (bytes) */
+            VRC_HIP_CHECK( hipMalloc( &c->dTileOrder, ( nTiles + VRC_TILE_SCRATCH_WORDS ) * sizeof( uint32_t ) + nTiles ) );
             c->dTileOrderCap = nTiles;
             c->tileOrderValid = false;
         }
         if( !c->tileOrderValid || std::memcmp( &c->tileOrderFrame, &f, sizeof( f ) ) != 0 )
         {
-            VRC_HIP_CHECK( vrc_launch_tile_order( f, c->dTileOrder, c->stream ) );
+            VRC_HIP_CHECK( vrc_launch_tile_order( f, c->dTileOrder, c->dTileOrder + c->dTileOrderCap,
+                                                  (uint8_t*)( c->dTileOrder + c->dTileOrderCap + VRC_TILE_SCRATCH_WORDS ),
+                                                  c->stream ) );
             std::memcpy( &c->tileOrderFrame, &f, sizeof( f ) );
             c->tileOrderValid = true;
         }

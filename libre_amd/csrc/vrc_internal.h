@@ -48,8 +48,11 @@ struct vrc_raycast_args
     vrc_classifier classifier;
 };
 
-/* heaviest-first tile schedule for the frame (order: one uint32 per 8x8 tile) */
-hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, hipStream_t stream );
+/* heaviest-first tile schedule for the frame (order: one uint32 per 8x8 tile; scratch:
+ * VRC_TILE_SCRATCH_WORDS uint32; bucket: one byte per tile) */
+#define VRC_TILE_SCRATCH_WORDS 260u
+hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t* scratch,
+                                  uint8_t* bucket, hipStream_t stream );
 
 hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream );
 

@@ -220,9 +220,9 @@ hipError_t vrc_launch_read_region( const void* atlas, void* dst, uint32_t elemBy
 }
 
 /* ------------------------------------------------------------------------------------------
- * tile schedule: order the 8x8 tiles by estimated work, heaviest first.  One workgroup:
- * cost = chord of the tile-centre ray through the (clipped) volume box, counting sort over
- * 256 cost buckets in LDS.  Re-run only when the view changes (~10 us).
+ * tile schedule: order the 8x8 tiles by estimated work, heaviest first: cost = chord of the
+ * tile-centre ray through the (clipped) volume box, counting sort over 256 cost buckets in
+ * two passes over all CUs.  Re-run only when the view changes.
  * ---------------------------------------------------------------------------------------- */
 __device__ __forceinline__ uint32_t vrc_tile_bucket( const vrc_frame& f, uint32_t tile,
                                                      uint32_t tilesX, float invDiag )
@@ -239,45 +239,92 @@ __device__ __forceinline__ uint32_t vrc_tile_bucket( const vrc_frame& f, uint32_
     return 255u - (uint32_t)( q * 255.0f );
 }
 
-__global__ __launch_bounds__( 1024 ) void vrc_k_tile_order( const vrc_frame f,
-                                                            const uint32_t tilesX,
+/* pass 1: cost bucket of every tile, histogram; the last workgroup to finish turns the
+ * histogram into bucket start offsets.  scratch: [0..255] histogram/offsets, [256] counter
+ * of finished workgroups (zeroed by the launcher). */
+__global__ __launch_bounds__( 256 ) void vrc_k_tile_bucket( const vrc_frame f, const uint32_t tilesX,
                                                             const uint32_t nTiles,
-                                                            uint32_t* __restrict__ order )
+                                                            uint8_t* __restrict__ bucket,
+                                                            uint32_t* __restrict__ scratch )
 {
     __shared__ uint32_t hist[256];
+    __shared__ bool last;
     const float dx = f.aabbMax[0] - f.aabbMin[0], dy = f.aabbMax[1] - f.aabbMin[1],
                 dz = f.aabbMax[2] - f.aabbMin[2];
     const float invDiag = 1.0f / sqrtf( dx * dx + dy * dy + dz * dz );
-    if( threadIdx.x < 256 )
-        hist[threadIdx.x] = 0;
+    hist[threadIdx.x] = 0;
     __syncthreads();
-    for( uint32_t t = threadIdx.x; t < nTiles; t += blockDim.x )
-        atomicAdd( &hist[vrc_tile_bucket( f, t, tilesX, invDiag )], 1u );
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if( t < nTiles )
+    {
+        const uint32_t b = vrc_tile_bucket( f, t, tilesX, invDiag );
+        bucket[t] = (uint8_t)b;
+        atomicAdd( &hist[b], 1u );
+    }
+    __syncthreads();
+    if( hist[threadIdx.x] )
+        atomicAdd( &scratch[threadIdx.x], hist[threadIdx.x] );
+    __threadfence();
     __syncthreads();
     if( threadIdx.x == 0 )
-    {
-        uint32_t acc = 0;
-        for( int b = 0; b < 256; ++b )
-        {
-            const uint32_t c = hist[b];
-            hist[b] = acc;
-            acc += c;
-        }
-    }
+        last = atomicAdd( &scratch[256], 1u ) == gridDim.x - 1u;
     __syncthreads();
-    for( uint32_t t = threadIdx.x; t < nTiles; t += blockDim.x )
+    if( !last )
+        return;
+    /* exclusive scan of the 256 bucket counts (all workgroups' adds are visible: fence above) */
+    hist[threadIdx.x] = __hip_atomic_load( &scratch[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+    __syncthreads();
+    for( uint32_t off = 1; off < 256u; off <<= 1 )
     {
-        const uint32_t pos = atomicAdd( &hist[vrc_tile_bucket( f, t, tilesX, invDiag )], 1u );
-        order[pos] = t;
+        const uint32_t v = threadIdx.x >= off ? hist[threadIdx.x - off] : 0u;
+        __syncthreads();
+        hist[threadIdx.x] += v;
+        __syncthreads();
     }
+    scratch[threadIdx.x] = threadIdx.x ? hist[threadIdx.x - 1u] : 0u;
 }
 
-hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, hipStream_t stream )
+/* pass 2: scatter the tiles to their bucket ranges (order inside a bucket is arbitrary).  A
+ * workgroup reserves its share of every bucket with one global atomic per bucket; the ranks
+ * inside the share come from LDS atomics (most tiles fall into a few buckets: one global
+ * atomic per tile serialises in L2, measured 33 us). */
+__global__ __launch_bounds__( 256 ) void vrc_k_tile_scatter( const uint32_t nTiles,
+                                                             const uint8_t* __restrict__ bucket,
+                                                             uint32_t* __restrict__ scratch,
+                                                             uint32_t* __restrict__ order )
+{
+    __shared__ uint32_t cnt[256], base[256];
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    uint32_t b = 0, rank = 0;
+    if( t < nTiles )
+    {
+        b = bucket[t];
+        rank = atomicAdd( &cnt[b], 1u );
+    }
+    __syncthreads();
+    if( cnt[threadIdx.x] )
+        base[threadIdx.x] = atomicAdd( &scratch[threadIdx.x], cnt[threadIdx.x] );
+    __syncthreads();
+    if( t < nTiles )
+        order[base[b] + rank] = t;
+}
+
+hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t* scratch,
+                                  uint8_t* bucket, hipStream_t stream )
 {
     const uint32_t tilesX = ( f.width + VRC_TILE_W - 1 ) / VRC_TILE_W;
     const uint32_t tilesY = ( f.height + VRC_TILE_H - 1 ) / VRC_TILE_H;
-    hipLaunchKernelGGL( vrc_k_tile_order, dim3( 1 ), dim3( 1024 ), 0, stream, f, tilesX,
-                        tilesX * tilesY, order );
+    const uint32_t nTiles = tilesX * tilesY;
+    if( nTiles == 0 )
+        return hipSuccess;
+    hipError_t e = hipMemsetAsync( scratch, 0, VRC_TILE_SCRATCH_WORDS * sizeof( uint32_t ), stream );
+    if( e != hipSuccess )
+        return e;
+    const dim3 grid( ( nTiles + 255u ) / 256u ), block( 256 );
+    hipLaunchKernelGGL( vrc_k_tile_bucket, grid, block, 0, stream, f, tilesX, nTiles, bucket, scratch );
+    hipLaunchKernelGGL( vrc_k_tile_scatter, grid, block, 0, stream, nTiles, bucket, scratch, order );
     return hipGetLastError();
 }
 
