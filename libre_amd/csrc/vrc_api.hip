@@ -37,7 +37,7 @@ int fail( int code, const std::string& msg )
             return fail( VRC_EHIP, std::string( #expr ) + ": " + hipGetErrorString( _e ) ); \
     } while( 0 )
 
-constexpr int kStagingSlots = 4;
+constexpr int kStagingSlots = 8;
 } // namespace
 
 struct vrc_pool

@@ -1,5 +1,8 @@
 /* data.cpp -- mathTypes + NodeId + VolumeInformation + LODNode + DataSource plumbing.
  * Mirrors the reference files cited per function (path:line from the reference root). */
+#include <sys/mman.h>
+#include <cstdlib>
+#include <new>
 #include "livre_hip/data.h"
 
 #include <algorithm>
@@ -7,6 +10,29 @@
 
 namespace livre
 {
+/* ---- AllocMemoryUnit --------------------------------------------------------------------- */
+AllocMemoryUnit::AllocMemoryUnit( size_t size ) : _data( nullptr ), _size( size )
+{
+    const size_t huge = size_t( 2 ) << 20;
+    void* p = nullptr;
+    if( size >= huge )
+    {
+        if( posix_memalign( &p, huge, ( size + huge - 1 ) / huge * huge ) != 0 )
+            p = nullptr;
+#if defined( MADV_HUGEPAGE )
+        if( p )
+            (void)madvise( p, ( size + huge - 1 ) / huge * huge, MADV_HUGEPAGE );
+#endif
+    }
+    else
+        p = std::malloc( size ? size : 1 );
+    if( !p )
+        throw std::bad_alloc();
+    _data = static_cast< uint8_t* >( p );
+}
+
+AllocMemoryUnit::~AllocMemoryUnit() { std::free( _data ); }
+
 /* ---- matrices --------------------------------------------------------------------------- */
 /* vmmlib Matrix4(eye, lookAt, up) (gluLookAt); pinned by tests/eq/settings/cameraSettings.cpp:99-117 */
 Matrix4f::Matrix4f( const Vector3f& eye, const Vector3f& lookAt, const Vector3f& up )

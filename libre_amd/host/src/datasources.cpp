@@ -4,6 +4,7 @@
  *   hash:// build-defined seeded-noise volume ("Volume N" of SURVEY 8d), bricked like mem://
  * Registered at load time through static PluginRegisterer objects, as the reference does
  * (MemoryDataSource.cpp:46, RawDataSource.cpp:50). */
+#include <algorithm>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -70,16 +71,14 @@ static MemoryUnitPtr computeData( const LODNode& node, size_t dataSize, float sp
                        127 * std::sin( ( float( node.getNodeId().getTimeStep() ) + 1 ) / 200.f ) );
     std::shared_ptr< AllocMemoryUnit > memoryUnit( new AllocMemoryUnit( dataSize ) );
     T* dst = memoryUnit->getData< T >();
-    for( size_t i = 0; i < nVoxels; ++i )
-    {
-        if( sparsity < 1.f )
+    if( sparsity < 1.f )
+        for( size_t i = 0; i < nVoxels; ++i )
         {
             const int32_t random = rand() % 1000000 + 1;
             dst[i] = random < 1000000.0f * sparsity ? value : T( 0 );
         }
-        else
-            dst[i] = value;
-    }
+    else
+        std::fill_n( dst, nVoxels, value );
     return memoryUnit;
 }
 

@@ -5,7 +5,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <queue>
 #include <thread>
 
@@ -22,8 +25,23 @@ const Vector3f INVALID_SLOT_POSITION( -1.0f ); /* CudaTextureObject.cpp:36-39 */
 const uint32_t maxSamplesPerRay = 32;  /* CudaRaycastRenderer.cpp:65 (the opacity-correction reference) */
 const uint32_t minSamplesPerRay = 512; /* CudaRaycastRenderer.cpp:66 */
 const uint32_t SH_UINT = 0u, SH_INT = 1u, SH_FLOAT = 2u;
-const size_t nUploadThreads = 2;      /* CudaRaycastPipeline.cpp:60-63 */
-const size_t nAsyncUploadThreads = 1;
+const size_t nAsyncUploadThreads = 1; /* CudaRaycastPipeline.cpp:60-63 */
+
+/** data loaders feeding the texture uploader: 2 in the reference (CudaRaycastPipeline.cpp:60-63);
+ * here half the host cores, between 2 and 8, or LIVRE_HIP_UPLOAD_THREADS (one loader moves
+ * ~7 GB/s of mem:// bricks, the upload path behind them takes ~35 GB/s) */
+size_t configuredUploadThreads()
+{
+    const char* v = std::getenv( "LIVRE_HIP_UPLOAD_THREADS" );
+    if( v && *v )
+    {
+        const long n = std::strtol( v, nullptr, 10 );
+        if( n >= 1 && n <= 64 )
+            return size_t( n );
+    }
+    const size_t hw = std::thread::hardware_concurrency();
+    return std::min< size_t >( 8, std::max< size_t >( 2, hw / 2 ) );
+}
 
 PluginRegisterer< HipRaycastRenderer, const std::string& > rendererRegisterer;
 PluginRegisterer< HipRaycastPipeline, const std::string& > pipelineRegisterer;
@@ -440,7 +458,12 @@ ConstCacheObjects generateRenderingSet( const HipTextureCache& cache, const Node
 /* ---- HipRaycastPipeline: CudaRaycastPipeline.cpp:66-358 -------------------------------------- */
 struct HipRaycastPipeline::Impl
 {
-    Impl() : _uploadExecutor( nUploadThreads ), _asyncUploadExecutor( nAsyncUploadThreads ), _lastPasses( 0 ) {}
+    Impl()
+        : nUploadThreads( configuredUploadThreads() ), _uploadExecutor( nUploadThreads ),
+          _asyncUploadExecutor( nAsyncUploadThreads ), _lastPasses( 0 )
+    {
+    }
+    const size_t nUploadThreads;
 
     /* VisibleSetGeneratorFilter.cpp:42-75 */
     NodeIds visibleSet( const RenderInputs& in ) const
@@ -454,45 +477,45 @@ struct HipRaycastPipeline::Impl
         return visitor.getVisibles();
     }
 
-    /* CudaRenderUploadFilter.cpp:57-119: cache hits directly, misses through nUploadThreads
-     * data loaders feeding the texture uploader */
-    ConstCacheObjects upload( const NodeIds& nodeIds, const RenderInputs& in, Executor& executor )
+    /* DataUploadFilter.cpp:35-49 then CudaTextureUploadFilter.cpp:43-60, for a list of cache
+     * misses, on nUploadThreads loaders; element k of the result belongs to ids[k] (empty if
+     * the brick could not be made resident) */
+    std::vector< ConstCacheObjectPtr > loadParallel( const NodeIds& ids, DataSource& dataSource )
     {
-        ConstCacheObjects cacheObjects;
-        NodeIds notAvailable;
-        for( const NodeId& nodeId : nodeIds )
-        {
-            const auto obj = _hipCache->load( nodeId.getId(), *_dataCache, in.dataSource, *_texturePool );
-            if( obj )
-                cacheObjects.push_back( obj );
-            else
-                notAvailable.push_back( nodeId );
-        }
-        if( notAvailable.empty() )
-            return cacheObjects;
-
-        const size_t perThread = std::max< size_t >( 1, notAvailable.size() / nUploadThreads );
-        std::mutex resultMutex;
-        std::vector< ConstCacheObjectPtr > loaded( notAvailable.size() );
+        std::vector< ConstCacheObjectPtr > loaded( ids.size() );
+        if( ids.empty() )
+            return loaded;
+        const size_t perThread = std::max< size_t >( 1, ids.size() / nUploadThreads );
         std::atomic< size_t > pending( 0 );
         std::mutex doneMutex;
         std::condition_variable doneCv;
         for( size_t i = 0; i < nUploadThreads; ++i )
         {
             const size_t begin = perThread * i;
-            if( begin >= notAvailable.size() )
+            if( begin >= ids.size() )
                 continue;
-            const size_t end = ( i == nUploadThreads - 1 ) ? notAvailable.size()
-                                                             : std::min( begin + perThread, notAvailable.size() );
+            const size_t end = ( i == nUploadThreads - 1 ) ? ids.size() : std::min( begin + perThread, ids.size() );
             ++pending;
-            executor.schedule( [&, begin, end] {
+            _uploadExecutor.schedule( [&, begin, end] {
+                double tData = 0.0, tTex = 0.0;
+                const bool trace = std::getenv( "LIVRE_HIP_TRACE" ) != nullptr;
                 for( size_t k = begin; k < end; ++k )
                 {
-                    const CacheId id = notAvailable[k].getId();
-                    /* DataUploadFilter.cpp:35-49 then CudaTextureUploadFilter.cpp:43-60 */
-                    if( _dataCache->load( id, in.dataSource ) )
-                        loaded[k] = _hipCache->load( id, *_dataCache, in.dataSource, *_texturePool );
+                    const CacheId id = ids[k].getId();
+                    const auto t0 = std::chrono::steady_clock::now();
+                    const bool have = bool( _dataCache->load( id, dataSource ) );
+                    const auto t1 = std::chrono::steady_clock::now();
+                    if( have )
+                        loaded[k] = _hipCache->load( id, *_dataCache, dataSource, *_texturePool );
+                    if( trace )
+                    {
+                        tData += std::chrono::duration< double, std::milli >( t1 - t0 ).count();
+                        tTex += std::chrono::duration< double, std::milli >( std::chrono::steady_clock::now() - t1 ).count();
+                    }
                 }
+                if( trace )
+                    std::fprintf( stderr, "[livre_hip] loader: %zu bricks, data source + CPU cache %.1f ms, texture upload %.1f ms\n",
+                                  end - begin, tData, tTex );
                 {
                     std::lock_guard< std::mutex > lock( doneMutex );
                     --pending;
@@ -508,13 +531,40 @@ struct HipRaycastPipeline::Impl
          * free (the policy evicts until used < max, i.e. one slot; the reference has the same
          * window, Cache.ipp:132-144 + TexturePool.cu:180-181); the loser's load comes back
          * empty.  Retry those serially: with a single loader the policy always leaves a slot. */
-        for( size_t k = 0; k < notAvailable.size(); ++k )
+        for( size_t k = 0; k < ids.size(); ++k )
             if( !loaded[k] )
             {
-                const CacheId id = notAvailable[k].getId();
-                if( _dataCache->load( id, in.dataSource ) )
-                    loaded[k] = _hipCache->load( id, *_dataCache, in.dataSource, *_texturePool );
+                const CacheId id = ids[k].getId();
+                if( _dataCache->load( id, dataSource ) )
+                    loaded[k] = _hipCache->load( id, *_dataCache, dataSource, *_texturePool );
             }
+        return loaded;
+    }
+
+    /* CudaRenderUploadFilter.cpp:57-119: cache hits directly, misses through nUploadThreads
+     * data loaders feeding the texture uploader */
+    ConstCacheObjects upload( const NodeIds& nodeIds, const RenderInputs& in )
+    {
+        ConstCacheObjects cacheObjects;
+        NodeIds notAvailable;
+        for( const NodeId& nodeId : nodeIds )
+        {
+            /* texture-cache hit, or the brick is in the CPU cache and only needs its upload
+             * (CudaRenderUploadFilter.cpp:70-84 asks cache.load() for both and lets the
+             * constructor throw when the data is missing; a C++ throw costs ~150 us in a
+             * process with hundreds of loaded DSOs, so the miss is tested for instead) */
+            ConstCacheObjectPtr obj = _hipCache->get( nodeId.getId() );
+            if( !obj && _dataCache->get( nodeId.getId() ) )
+                obj = _hipCache->load( nodeId.getId(), *_dataCache, in.dataSource, *_texturePool );
+            if( obj )
+                cacheObjects.push_back( obj );
+            else
+                notAvailable.push_back( nodeId );
+        }
+        if( notAvailable.empty() )
+            return cacheObjects;
+
+        const std::vector< ConstCacheObjectPtr > loaded = loadParallel( notAvailable, in.dataSource );
         for( const auto& obj : loaded )
             if( obj )
                 cacheObjects.push_back( obj );
@@ -558,8 +608,15 @@ struct HipRaycastPipeline::Impl
             const size_t endIndex = std::min( size_t( i + 1 ) * maxNodesPerPass, nodeIds.size() );
             const NodeIds nodesPerPass( nodeIds.begin() + startIndex, nodeIds.begin() + endIndex );
             /* createAndExecuteSyncPass, CudaRaycastPipeline.cpp:208-234 */
-            const ConstCacheObjects objects = upload( nodesPerPass, in, _uploadExecutor );
+            const auto tU0 = std::chrono::steady_clock::now();
+            const ConstCacheObjects objects = upload( nodesPerPass, in );
+            const auto tU1 = std::chrono::steady_clock::now();
             renderer.render( in, objects, renderStages );
+            if( std::getenv( "LIVRE_HIP_TRACE" ) )
+                std::fprintf( stderr, "[livre_hip] pass %u: upload %.2f ms, render call %.2f ms (%zu bricks)\n", i,
+                              std::chrono::duration< double, std::milli >( tU1 - tU0 ).count(),
+                              std::chrono::duration< double, std::milli >( std::chrono::steady_clock::now() - tU1 ).count(),
+                              objects.size() );
             if( numberOfPasses > 1 )
             {
                 /* a multipass frame re-uses the slots: the bricks of this pass must be
@@ -592,13 +649,13 @@ struct HipRaycastPipeline::Impl
                  * everything else the task touches is owned by this Impl */
                 DataSource* ds = &in.dataSource;
                 _asyncUploadExecutor.schedule( [this, visibles, ds] {
+                    /* the upload pipeline of the reference's async executor: the misses go
+                     * through the same nUploadThreads loaders as a synchronous pass */
+                    NodeIds missing;
                     for( const NodeId& id : visibles )
-                    {
-                        if( _hipCache->get( id.getId() ) )
-                            continue;
-                        if( _dataCache->load( id.getId(), *ds ) )
-                            _hipCache->load( id.getId(), *_dataCache, *ds, *_texturePool );
-                    }
+                        if( !_hipCache->get( id.getId() ) )
+                            missing.push_back( id );
+                    loadParallel( missing, *ds );
                     _asyncBusy = false;
                 } );
             }
