@@ -255,6 +255,43 @@ def main():
                               "visible set re-derived every frame"}
         app.set_camera(spin=tuple(a.spin))
 
+    # SURVEY 8(d) defines fps with the frame read back to pinned host memory: three frames in
+    # flight, each on its own stream: kernel, then the 16 MiB device -> pinned copy behind it
+    readback = None
+    if world == 1 and not a.no_extras:
+        KR = 3
+        r_streams = [torch.cuda.Stream() for _ in range(KR)]
+        r_fbs = [torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(KR)]
+        r_host = [torch.zeros((rows, W, 4), dtype=torch.float32).pin_memory() for _ in range(KR)]
+        app.set_frames_in_flight(KR)
+        for k in range(KR):
+            app.select_slot(k)
+            app.set_stream(r_streams[k].cuda_stream)
+            app.set_framebuffer(r_fbs[k].data_ptr())
+
+        def rb_frame(i):
+            k = i % KR
+            with torch.cuda.stream(r_streams[k]):
+                app.select_slot(k)
+                app.render_frame(readback=False)
+                r_host[k].copy_(r_fbs[k], non_blocking=True)
+
+        for i in range(2 * KR):
+            rb_frame(i)
+        torch.cuda.synchronize()
+        n_rb = 100
+        t0 = time.perf_counter()
+        for i in range(n_rb):
+            rb_frame(i)
+        torch.cuda.synchronize()
+        dt_rb = time.perf_counter() - t0
+        readback = {"frames_per_s": n_rb / dt_rb, "frames": n_rb, "frames_in_flight": KR,
+                    "bytes_per_frame": rows * W * 16,
+                    "d2h_GBps": n_rb * rows * W * 16 / dt_rb / 1e9,
+                    "note": "kernel + RGBA32F frame copied to pinned host memory, 3 frames in flight"}
+        ok = bool(torch.isfinite(r_host[0]).all()) and float(r_host[0][..., 3].max()) > 0.0
+        readback["frame_ok"] = ok
+
     if rank == 0:
         # measured HBM traffic per launch, from the committed rocprofv3 PMC passes (bench.py cannot
         # run the profiler on itself); only quoted for the workload it was measured on
@@ -290,7 +327,8 @@ def main():
                                       % (world, len(bands), K),
                        "samples_per_frame": samples_frame,
                        "first_frame_with_upload_ms": first_frame_ms,
-                       "extension_trilinear": trilinear, "moving_camera": moving},
+                       "extension_trilinear": trilinear, "moving_camera": moving,
+                       "with_readback_to_pinned_host": readback},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "vrc_k_raycast<true,false,false,true>",
