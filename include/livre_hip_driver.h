@@ -60,6 +60,10 @@ int lvh_app_set_clip_planes( lvh_app* app, const float* planes, uint32_t n );
  * frame, stacked in that order in its pixel buffer (replaces params.tile; n = 0 -> back to it) */
 int lvh_app_set_bands( lvh_app* app, const uint32_t* y0, const uint32_t* h, uint32_t n );
 int lvh_app_set_option( lvh_app* app, int vrc_option, int64_t value );
+/* RenderInputs::dataSourceRange for volumes that are not uint8 (the reference forces (0,255),
+ * livre/eq/Channel.cpp:284, and its CUDA renderer ignores the field; 16-bit volumes are an
+ * extension here and default to (0,65535)) */
+int lvh_app_set_data_range( lvh_app* app, float lo, float hi );
 /* Frames in flight: the application keeps n Renderer("hip") instances (each with its own device
  * context, stream and pixel buffer) over ONE pipeline (one brick atlas, one pair of caches), as
  * RenderPipelinePlugin::render( Renderer&, ... ) allows; Equalizer's default latency of one frame

@@ -277,18 +277,18 @@ int vrc_pool_create( vrc_ctx* c, size_t bytesPerVoxel, int isSigned, int isFloat
                      size_t nComponents, const uint32_t maxBlock[3], size_t maxBytes,
                      vrc_pool** out )
 {
-    (void)isSigned;
     if( !c || !out || !maxBlock )
         return fail( VRC_EINVAL, "vrc_pool_create: NULL argument" );
     *out = nullptr;
     /* cuda/TexturePool.cu:66-67 */
     if( nComponents == 0 || nComponents > 4 )
         return fail( VRC_EUNSUPPORTED, "Channel number cannot be 0 or larger than 4" );
-    /* the reference kernel only ever fetches unsigned char (Renderer.cu:211, quirk Q2);
-     * this layer renders 1-byte single-channel volumes and says so for the rest */
-    if( bytesPerVoxel != 1 || nComponents != 1 || isFloat )
+    /* the reference kernel only ever fetches unsigned char (Renderer.cu:211, quirk Q2); this
+     * layer renders unsigned 8-bit (the reference path) and, as an extension, unsigned 16-bit
+     * single-channel volumes, and says so for the rest instead of mis-rendering them */
+    if( ( bytesPerVoxel != 1 && bytesPerVoxel != 2 ) || nComponents != 1 || isFloat || isSigned )
         return fail( VRC_EUNSUPPORTED,
-                     "vrc_pool_create: only 1-byte single-channel volumes are implemented" );
+                     "vrc_pool_create: only unsigned 8/16-bit single-channel volumes are implemented" );
     if( maxBlock[0] == 0 || maxBlock[1] == 0 || maxBlock[2] == 0 )
         return fail( VRC_EINVAL, "vrc_pool_create: zero block size" );
     VRC_HIP_CHECK( hipSetDevice( c->device ) );
@@ -785,12 +785,15 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     lp.alphaCorrection = (float)render->maxSamplesPerRay / (float)render->samplesPerRay;
     lp.fracBits = (int)c->optTfFracBits;
     const bool linear = c->optFilter == VRC_FILTER_TRILINEAR;
-    if( !c->lutValid || c->lutTfVersion != c->tfVersion || c->lutLinear != linear ||
+    /* samples classified one by one (padded transfer function in the table buffer) whenever the
+     * 257-entry classified table cannot be used: continuous or 16-bit densities */
+    const bool classify = linear || pool->elemBytes != 1;
+    if( !c->lutValid || c->lutTfVersion != c->tfVersion || c->lutLinear != classify ||
         std::memcmp( &lp, &c->lutParams, sizeof( lp ) ) != 0 )
     {
-        VRC_HIP_CHECK( vrc_launch_build_lut( c->dTf, c->dLut, lp, linear, c->stream ) );
+        VRC_HIP_CHECK( vrc_launch_build_lut( c->dTf, c->dLut, lp, classify, c->stream ) );
         c->lutParams = lp;
-        c->lutLinear = linear;
+        c->lutLinear = classify;
         c->lutTfVersion = c->tfVersion;
         c->lutValid = true;
     }
@@ -841,9 +844,9 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         return fail( VRC_EINVAL, "vrc_render: node set is not grid-aligned; GRID_DDA unavailable" );
     /* LDS-staged kernel: brick-grid DDA + unclamped sampler (overlap >= 1).  AUTO takes it for
      * the trilinear filter (eight taps per sample), the gather kernel for point sampling. */
-    const bool ldsEligible = c->cachedGridOk && !c->cachedClamp;
+    const bool ldsEligible = c->cachedGridOk && !c->cachedClamp && pool->elemBytes == 1;
     if( c->optKernel == VRC_KERNEL_LDS && !ldsEligible )
-        return fail( VRC_EINVAL, "vrc_render: the LDS kernel needs a grid-aligned node set with overlap >= 1" );
+        return fail( VRC_EINVAL, "vrc_render: the LDS kernel needs a grid-aligned node set of 8-bit bricks with overlap >= 1" );
     const bool useLds = c->optKernel == VRC_KERNEL_LDS ||
                         ( c->optKernel == VRC_KERNEL_AUTO && linear && ldsEligible );
 
@@ -902,6 +905,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     a.gridDda = useDda;
     a.fixedStepping = c->optStepping != 0;
     a.linear = linear;
+    a.elemBytes = pool->elemBytes;
     a.classifier = vrc_make_classifier( lp );
 
     /* order the march after every brick upload issued so far (fixes quirk Q9) */

@@ -741,7 +741,7 @@ VRC_HD float vrc_trilerp( const float v[8], float wx, float wy, float wz )
 #define VRC_LGROUP 4
 #endif
 
-template < bool CLAMP, bool COUNT, typename ATLAS_T >
+template < bool CLAMP, bool COUNT, bool TRILINEAR, typename ATLAS_T >
 VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n, vrc_segment s,
                                       const ATLAS_T* __restrict__ atlas, const vrc_f4* tfp,
                                       const vrc_classifier& cls, vrc_f4& color,
@@ -754,36 +754,57 @@ VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n,
     bool done = false;
     while( travel > 0.0f && !done )
     {
-        vrc_taps t[VRC_LGROUP];
         bool valid[VRC_LGROUP];
-#pragma unroll
-        for( int k = 0; k < VRC_LGROUP; ++k )
+        float d[VRC_LGROUP];
+        if( TRILINEAR )
         {
-            VRC_FAST_FP
-            valid[k] = travel > 0.0f;
-            const float lx = ( pos.x - sm.minx ) * sm.kx + sm.ox;
-            const float ly = ( pos.y - sm.miny ) * sm.ky + sm.oy;
-            const float lz = ( pos.z - sm.minz ) * sm.kz + sm.oz;
-            t[k] = vrc_trilinear_taps< CLAMP >( sm, lx, ly, lz );
-            pos.x += s.step.x;
-            pos.y += s.step.y;
-            pos.z += s.step.z;
-            travel -= stepSize;
-        }
-        float v[VRC_LGROUP][8];
+            vrc_taps t[VRC_LGROUP];
 #pragma unroll
-        for( int k = 0; k < VRC_LGROUP; ++k )
-#pragma unroll
-            for( int c = 0; c < 8; ++c )
+            for( int k = 0; k < VRC_LGROUP; ++k )
             {
-                const uint32_t e = t[k].ax[c & 1] + t[k].ay[( c >> 1 ) & 1] + t[k].az[c >> 2];
-                v[k][c] = (float)atlas[valid[k] ? e : 0u];
+                VRC_FAST_FP
+                valid[k] = travel > 0.0f;
+                const float lx = ( pos.x - sm.minx ) * sm.kx + sm.ox;
+                const float ly = ( pos.y - sm.miny ) * sm.ky + sm.oy;
+                const float lz = ( pos.z - sm.minz ) * sm.kz + sm.oz;
+                t[k] = vrc_trilinear_taps< CLAMP >( sm, lx, ly, lz );
+                pos.x += s.step.x;
+                pos.y += s.step.y;
+                pos.z += s.step.z;
+                travel -= stepSize;
             }
+            float v[VRC_LGROUP][8];
+#pragma unroll
+            for( int k = 0; k < VRC_LGROUP; ++k )
+#pragma unroll
+                for( int c = 0; c < 8; ++c )
+                {
+                    const uint32_t e = t[k].ax[c & 1] + t[k].ay[( c >> 1 ) & 1] + t[k].az[c >> 2];
+                    v[k][c] = (float)atlas[valid[k] ? e : 0u];
+                }
+#pragma unroll
+            for( int k = 0; k < VRC_LGROUP; ++k )
+                d[k] = vrc_trilerp( v[k], t[k].wx, t[k].wy, t[k].wz );
+        }
+        else
+        {
+            /* point sampling of a volume the classified table cannot index (16-bit voxels) */
+            uint32_t idx[VRC_LGROUP];
+#pragma unroll
+            for( int k = 0; k < VRC_LGROUP; ++k )
+            {
+                valid[k] = travel > 0.0f;
+                travel -= stepSize;
+            }
+            vrc_group_indices< CLAMP, VRC_LGROUP >( sm, pos, s.step, idx );
+#pragma unroll
+            for( int k = 0; k < VRC_LGROUP; ++k )
+                d[k] = (float)atlas[valid[k] ? idx[k] : 0u];
+        }
 #pragma unroll
         for( int k = 0; k < VRC_LGROUP; ++k )
         {
-            const float d = vrc_trilerp( v[k], t[k].wx, t[k].wy, t[k].wz );
-            const vrc_f4 e = vrc_classify( tfp, d, cls );
+            const vrc_f4 e = vrc_classify( tfp, d[k], cls );
             const bool active = valid[k] && !done;
             vrc_composite( color, e, !active );
             if( COUNT )
@@ -797,20 +818,27 @@ VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n,
 /* ------------------------------------------------------------------------------------------
  * Reference-order pixel: the O(nodeCount) loop of Renderer.cu:172-227, nodes in host order.
  * ---------------------------------------------------------------------------------------- */
-/* lut: the classified table (257 entries), or with LINEAR the padded transfer function
- * (VRC_TFP_ENTRIES) that cls classifies per sample */
-template < bool CLAMP, bool COUNT, bool FIXED, bool LINEAR, typename ATLAS_T >
+/* MODE: how a sample is fetched and classified.
+ *   VRC_MODE_TABLE      point sample of a u8 volume through the classified table (257 entries):
+ *                       the reference path;
+ *   VRC_MODE_TRILINEAR  trilinear fetch, per-sample classification (lut = padded transfer function);
+ *   VRC_MODE_POINT      point sample, per-sample classification (16-bit voxels). */
+#define VRC_MODE_TABLE 0
+#define VRC_MODE_TRILINEAR 1
+#define VRC_MODE_POINT 2
+
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T >
 VRC_HD bool vrc_march_brick( const vrc_frame& f, const vrc_dev_node& n, const vrc_segment& s,
                              const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
                              const vrc_classifier& cls, vrc_f4& color, uint32_t& nSamples )
 {
-    if( LINEAR )
-        return vrc_march_segment_linear< CLAMP, COUNT, ATLAS_T >( f, n, s, atlas, lut, cls, color,
-                                                                  nSamples );
+    if( MODE != VRC_MODE_TABLE )
+        return vrc_march_segment_linear< CLAMP, COUNT, MODE == VRC_MODE_TRILINEAR, ATLAS_T >(
+            f, n, s, atlas, lut, cls, color, nSamples );
     return vrc_march_segment< CLAMP, COUNT, FIXED, ATLAS_T >( f, n, s, atlas, lut, color, nSamples );
 }
 
-template < bool CLAMP, bool COUNT, bool FIXED, bool LINEAR, typename ATLAS_T >
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T >
 VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
                                        const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
                                        const vrc_classifier& cls,
@@ -835,7 +863,7 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
                 break;
             continue;
         }
-        if( vrc_march_brick< CLAMP, COUNT, FIXED, LINEAR, ATLAS_T >( f, n, s, atlas, lut, cls, color,
+        if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T >( f, n, s, atlas, lut, cls, color,
                                                                      nSamples ) )
             break;
     }
@@ -848,7 +876,7 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
  * For a regular single-LOD grid the along-ray order equals the reference's host order for
  * every pair of bricks that share a ray ("brick order").
  * ---------------------------------------------------------------------------------------- */
-template < bool CLAMP, bool COUNT, bool FIXED, bool LINEAR, typename ATLAS_T >
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T >
 VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
                                 const int32_t* __restrict__ gridTable,
                                 const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
@@ -907,7 +935,7 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
                 bool stop;
                 if( vrc_brick_segment( r, n, f.stepSize, &s, &stop ) )
                 {
-                    if( vrc_march_brick< CLAMP, COUNT, FIXED, LINEAR, ATLAS_T >( f, n, s, atlas, lut,
+                    if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T >( f, n, s, atlas, lut,
                                                                                  cls, color, nSamples ) )
                         break;
                 }

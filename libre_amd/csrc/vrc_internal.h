@@ -44,7 +44,9 @@ struct vrc_raycast_args
     bool clamp;
     bool gridDda;
     bool fixedStepping; /* VRC_OPT_STEPPING */
-    bool linear;        /* VRC_OPT_FILTER = 1: lut holds the padded transfer function */
+    bool linear;        /* VRC_OPT_FILTER = 1 (trilinear) */
+    uint32_t elemBytes; /* voxel size: 1 (u8) or 2 (u16; classified per sample).  lut holds the padded
+                         * transfer function whenever samples are classified one by one */
     vrc_classifier classifier;
 };
 

@@ -334,15 +334,16 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t*
 #ifndef VRC_MIN_WAVES
 #define VRC_MIN_WAVES 4
 #endif
-template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, bool LINEAR >
+template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T >
 __global__ __launch_bounds__( VRC_WG, VRC_MIN_WAVES ) void vrc_k_raycast(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
-    const int32_t* __restrict__ gridTable, const uint8_t* __restrict__ atlas,
+    const int32_t* __restrict__ gridTable, const ATLAS_T* __restrict__ atlas,
     const vrc_f4* __restrict__ lutGlobal, const vrc_classifier cls,
     vrc_f4* __restrict__ pixelBuffer, unsigned long long* __restrict__ sampleCounter,
     const uint32_t* __restrict__ tileOrder, const uint32_t tilesX, const uint32_t nTiles )
 {
-    /* classified table (257 entries) or, with LINEAR, the padded transfer function (258) */
+    /* classified table (257 entries) or, for the per-sample classification modes, the padded
+     * transfer function (258) */
     __shared__ vrc_f4 lut[VRC_TFP_ENTRIES];
     const uint32_t lane = threadIdx.x;
 #pragma unroll
@@ -375,10 +376,10 @@ __global__ __launch_bounds__( VRC_WG, VRC_MIN_WAVES ) void vrc_k_raycast(
     if( px < f.width && py < f.height )
     {
         if( DDA )
-            vrc_pixel_grid_dda< CLAMP, COUNT, FIXED, LINEAR, uint8_t >(
+            vrc_pixel_grid_dda< CLAMP, COUNT, FIXED, MODE, ATLAS_T >(
                 f, nodes, gridTable, atlas, lut, cls, pixelBuffer, px, py, nSamples );
         else
-            vrc_pixel_reference_order< CLAMP, COUNT, FIXED, LINEAR, uint8_t >(
+            vrc_pixel_reference_order< CLAMP, COUNT, FIXED, MODE, ATLAS_T >(
                 f, nodes, atlas, lut, cls, pixelBuffer, px, py, nSamples );
     }
     if( COUNT )
@@ -393,7 +394,7 @@ __global__ __launch_bounds__( VRC_WG, VRC_MIN_WAVES ) void vrc_k_raycast(
     }
 }
 
-template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, bool LINEAR >
+template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T >
 static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream )
 {
     const uint32_t tilesX = ( a.frame.width + VRC_TILE_W - 1 ) / VRC_TILE_W;
@@ -401,48 +402,57 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
     const uint32_t nTiles = tilesX * tilesY;
     if( nTiles == 0 )
         return hipSuccess;
-    hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, LINEAR > ), dim3( nTiles ),
+    hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, MODE, ATLAS_T > ), dim3( nTiles ),
                         dim3( VRC_WG ), 0, stream, a.frame, a.nodes, a.gridTable,
-                        (const uint8_t*)a.atlas, a.lut, a.classifier, a.pixelBuffer,
+                        (const ATLAS_T*)a.atlas, a.lut, a.classifier, a.pixelBuffer,
                         a.sampleCounter, a.tileOrder, tilesX, nTiles );
     return hipGetLastError();
+}
+
+/* per-sample classification modes (float stepping): trilinear or point, u8 or u16 voxels */
+template < int MODE, typename ATLAS_T >
+static hipError_t launch_classify( const vrc_raycast_args& a, bool count, hipStream_t stream )
+{
+    const int key = ( a.gridDda ? 4 : 0 ) | ( a.clamp ? 2 : 0 ) | ( count ? 1 : 0 );
+    switch( key )
+    {
+    case 0: return launch_variant< false, false, false, false, MODE, ATLAS_T >( a, stream );
+    case 1: return launch_variant< false, false, true, false, MODE, ATLAS_T >( a, stream );
+    case 2: return launch_variant< false, true, false, false, MODE, ATLAS_T >( a, stream );
+    case 3: return launch_variant< false, true, true, false, MODE, ATLAS_T >( a, stream );
+    case 4: return launch_variant< true, false, false, false, MODE, ATLAS_T >( a, stream );
+    case 5: return launch_variant< true, false, true, false, MODE, ATLAS_T >( a, stream );
+    case 6: return launch_variant< true, true, false, false, MODE, ATLAS_T >( a, stream );
+    default: return launch_variant< true, true, true, false, MODE, ATLAS_T >( a, stream );
+    }
 }
 
 hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
 {
     const bool count = a.sampleCounter != nullptr;
+    if( a.elemBytes == 2 )
+        return a.linear ? launch_classify< VRC_MODE_TRILINEAR, uint16_t >( a, count, stream )
+                        : launch_classify< VRC_MODE_POINT, uint16_t >( a, count, stream );
+    if( a.elemBytes != 1 )
+        return hipErrorInvalidValue;
     if( a.linear )
-    {
-        /* trilinear extension: gather form (float stepping) */
-        const int key = ( a.gridDda ? 4 : 0 ) | ( a.clamp ? 2 : 0 ) | ( count ? 1 : 0 );
-        switch( key )
-        {
-        case 0: return launch_variant< false, false, false, false, true >( a, stream );
-        case 1: return launch_variant< false, false, true, false, true >( a, stream );
-        case 2: return launch_variant< false, true, false, false, true >( a, stream );
-        case 3: return launch_variant< false, true, true, false, true >( a, stream );
-        case 4: return launch_variant< true, false, false, false, true >( a, stream );
-        case 5: return launch_variant< true, false, true, false, true >( a, stream );
-        case 6: return launch_variant< true, true, false, false, true >( a, stream );
-        default: return launch_variant< true, true, true, false, true >( a, stream );
-        }
-    }
+        return launch_classify< VRC_MODE_TRILINEAR, uint8_t >( a, count, stream );
     /* the clamped sampler (overlap 0) always uses the float position chain */
     const bool fixed = a.fixedStepping && !a.clamp;
     const int key = ( fixed ? 8 : 0 ) | ( a.gridDda ? 4 : 0 ) | ( a.clamp ? 2 : 0 ) | ( count ? 1 : 0 );
     switch( key )
     {
-    case 0: return launch_variant< false, false, false, false, false >( a, stream );
-    case 1: return launch_variant< false, false, true, false, false >( a, stream );
-    case 2: return launch_variant< false, true, false, false, false >( a, stream );
-    case 3: return launch_variant< false, true, true, false, false >( a, stream );
-    case 4: return launch_variant< true, false, false, false, false >( a, stream );
-    case 5: return launch_variant< true, false, true, false, false >( a, stream );
-    case 6: return launch_variant< true, true, false, false, false >( a, stream );
-    case 7: return launch_variant< true, true, true, false, false >( a, stream );
-    case 8: return launch_variant< false, false, false, true, false >( a, stream );
-    case 9: return launch_variant< false, false, true, true, false >( a, stream );
-    case 12: return launch_variant< true, false, false, true, false >( a, stream );
-    default: return launch_variant< true, false, true, true, false >( a, stream );
+    case 0: return launch_variant< false, false, false, false, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 1: return launch_variant< false, false, true, false, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 2: return launch_variant< false, true, false, false, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 3: return launch_variant< false, true, true, false, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 4: return launch_variant< true, false, false, false, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 5: return launch_variant< true, false, true, false, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 6: return launch_variant< true, true, false, false, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 7: return launch_variant< true, true, true, false, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 8: return launch_variant< false, false, false, true, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 9: return launch_variant< false, false, true, true, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 12: return launch_variant< true, false, false, true, VRC_MODE_TABLE, uint8_t >( a, stream );
+    default: return launch_variant< true, false, true, true, VRC_MODE_TABLE, uint8_t >( a, stream );
     }
 }

@@ -34,6 +34,7 @@ struct lvh_app
     std::vector< std::unique_ptr< Renderer > > extraRenderers; /* frames in flight beyond the first */
     uint32_t slot = 0;
     std::string rendererName;
+    float dataRange[2] = { 0.0f, 0.0f }; /* lvh_app_set_data_range; empty = the voxel type's range */
 
     Renderer& currentRenderer()
     {
@@ -72,6 +73,16 @@ struct lvh_app
         return perspectiveFrustum( tl, tr, tb, tt, nearPlane, farPlane );
     }
 
+    /** (0,255) is hard-coded at Channel.cpp:284; 16-bit volumes (extension) get the type's
+     *  range unless lvh_app_set_data_range gave one */
+    Vector2f dataSourceRange() const
+    {
+        if( dataRange[1] > dataRange[0] )
+            return Vector2f( dataRange[0], dataRange[1] );
+        const size_t bytes = dataSource->getVolumeInfo().getBytesPerVoxel();
+        return bytes == 2 ? Vector2f( 0.0f, 65535.0f ) : Vector2f( 0.0f, 255.0f );
+    }
+
     RenderInputs inputs()
     {
         uint32_t t[4];
@@ -79,7 +90,7 @@ struct lvh_app
         const Frustum frustum( camera.getModelViewMatrix(), projection() );
         return RenderInputs{ FrameInfo( frustum, 0, frameId ),
                              Range{ { 0.0f, 1.0f } },
-                             Vector2f( 0.0f, 255.0f ), /* hard-coded at Channel.cpp:284 */
+                             dataSourceRange(),
                              PixelViewport( 0, 0, int32_t( t[2] ), int32_t( t[3] ) ),
                              Viewport( float( t[0] ) / params.width, float( t[1] ) / params.height,
                                        float( t[2] ) / params.width, float( t[3] ) / params.height ),
@@ -207,6 +218,14 @@ int lvh_app_set_option( lvh_app* app, int option, int64_t value )
 {
     if( !app ) return fail( "NULL argument" );
     LVH_TRY( app->renderer().setOption( option, value ) )
+}
+int lvh_app_set_data_range( lvh_app* app, float lo, float hi )
+{
+    if( !app ) return fail( "NULL argument" );
+    if( !( hi > lo ) ) return fail( "empty data range" );
+    app->dataRange[0] = lo;
+    app->dataRange[1] = hi;
+    return 0;
 }
 int lvh_app_set_stream( lvh_app* app, void* s )
 {

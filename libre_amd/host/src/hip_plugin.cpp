@@ -368,6 +368,13 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
     rData.datatype = getShaderDataType( volInfo );
     rData.dataSourceRange[0] = 0.0f; /* hard-coded (0,255), CudaRaycastRenderer.cpp:205 */
     rData.dataSourceRange[1] = 255.0f;
+    if( volInfo.getBytesPerVoxel() != 1 )
+    {
+        /* extension (16-bit voxels): the range the GL twin takes from the render inputs,
+         * GLRaycastRenderer.cpp:311-312 */
+        rData.dataSourceRange[0] = renderInputs.dataSourceRange[0];
+        rData.dataSourceRange[1] = renderInputs.dataSourceRange[1];
+    }
     throwOnVrcError( vrc_render( _ctx, &viewData, nodeDatas.data(), uint32_t( nodeDatas.size() ),
                                  &rData, pool ),
                      "vrc_render" );

@@ -582,17 +582,22 @@ static int tex_index( float u, uint32_t n )
     return (int)f;
 }
 
-static float fetch_nearest( const uint8_t* atlas, const uint32_t dim[3], f3 t )
+static float texel( const uint8_t* atlas, int voxelBytes, size_t i )
+{
+    return voxelBytes == 2 ? (float)( (const uint16_t*)atlas )[i] : (float)atlas[i];
+}
+
+static float fetch_nearest( const uint8_t* atlas, int voxelBytes, const uint32_t dim[3], f3 t )
 {
     const int x = tex_index( t.x, dim[0] );
     const int y = tex_index( t.y, dim[1] );
     const int z = tex_index( t.z, dim[2] );
-    return (float)atlas[( (size_t)z * dim[1] + (size_t)y ) * dim[0] + (size_t)x];
+    return texel( atlas, voxelBytes, ( (size_t)z * dim[1] + (size_t)y ) * dim[0] + (size_t)x );
 }
 
 /* EXTENSION (not in the reference, which is point-sampled): trilinear fetch with exact
- * float weights, texel centres at i + 0.5, clamp addressing.  Returns a value in [0,255]. */
-static float fetch_trilinear( const uint8_t* atlas, const uint32_t dim[3], f3 t )
+ * float weights, texel centres at i + 0.5, clamp addressing.  Returns the raw voxel scale. */
+static float fetch_trilinear( const uint8_t* atlas, int voxelBytes, const uint32_t dim[3], f3 t )
 {
     const float c[3] = { t.x * (float)dim[0] - 0.5f, t.y * (float)dim[1] - 0.5f,
                          t.z * (float)dim[2] - 0.5f };
@@ -610,7 +615,7 @@ static float fetch_trilinear( const uint8_t* atlas, const uint32_t dim[3], f3 t 
         i0[a] = lo;
         i1[a] = hi;
     }
-#define AT( X, Y, Z ) (float)atlas[( (size_t)( Z ) * dim[1] + (size_t)( Y ) ) * dim[0] + (size_t)( X )]
+#define AT( X, Y, Z ) texel( atlas, voxelBytes, ( (size_t)( Z ) * dim[1] + (size_t)( Y ) ) * dim[0] + (size_t)( X ) )
     const float c00 = AT( i0[0], i0[1], i0[2] ) * ( 1.0f - w[0] ) + AT( i1[0], i0[1], i0[2] ) * w[0];
     const float c10 = AT( i0[0], i1[1], i0[2] ) * ( 1.0f - w[0] ) + AT( i1[0], i1[1], i0[2] ) * w[0];
     const float c01 = AT( i0[0], i0[1], i1[2] ) * ( 1.0f - w[0] ) + AT( i1[0], i0[1], i1[2] ) * w[0];
@@ -738,8 +743,9 @@ static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
             const f3 texPos = { ( ( pos.x - boxMin.x ) / boxSize.x ) * texSize.x + texMin.x,
                                 ( ( pos.y - boxMin.y ) / boxSize.y ) * texSize.y + texMin.y,
                                 ( ( pos.z - boxMin.z ) / boxSize.z ) * texSize.z + texMin.z };
-            const float density = j->opt.filter ? fetch_trilinear( j->atlas, j->atlasDim, texPos )
-                                                : fetch_nearest( j->atlas, j->atlasDim, texPos );
+            const float density = j->opt.filter
+                                      ? fetch_trilinear( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos )
+                                      : fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
             float transferFn[4];
             orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, transferFn );
             orc_composite( transferFn, color, alphaCorrection );
@@ -813,6 +819,7 @@ uint64_t orc_raycast( const uint8_t* atlas, const uint32_t atlasDim[3], float* p
         job.opt.rowBegin = 0;
         job.opt.rowEnd = height;
         job.opt.rowStride = 1;
+        job.opt.voxelBytes = 1;
     }
     if( job.opt.rowStride == 0 ) job.opt.rowStride = 1;
     if( job.opt.rowEnd == 0 || job.opt.rowEnd > height ) job.opt.rowEnd = height;

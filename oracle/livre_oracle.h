@@ -89,6 +89,9 @@ typedef struct
     int filter;      /* 0 = nearest (reference, cuda/TexturePool.cu:167); 1 = trilinear (extension) */
     int nThreads;    /* row-parallel worker threads (>=1) */
     uint32_t rowBegin, rowEnd, rowStride; /* rows [rowBegin,rowEnd) step rowStride are rendered */
+    int voxelBytes;  /* 0 or 1 = uint8 atlas (the reference kernel, Renderer.cu:211); 2 = uint16 atlas
+                      * (EXTENSION: the reference CUDA kernel fetches unsigned char only; the value
+                      * is mapped through RenderData.dataSourceRange as Renderer.cu:162-164 does) */
 } orc_options;
 
 /* ---- NodeId: livre/core/data/NodeId.h:38-49, livre/core/types.h:191-195, mathTypes.h:82 */

@@ -16,8 +16,10 @@ extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atla
                                const vrc_view_data* view, uint32_t nNodes,
                                const vrc_node_data* nodes, const vrc_render_data* render,
                                int fracBits, int kernel, int pixelOffX, int pixelOffY,
-                               uint64_t* samplesOut, int* gridOkOut )
+                               uint64_t* samplesOut, int* gridOkOut, int voxelBytes )
 {
+    if( voxelBytes != 1 && voxelBytes != 2 )
+        return 3;
     vrc_atlas_geom geom;
     for( int a = 0; a < 3; ++a )
     {
@@ -35,12 +37,20 @@ extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atla
     }
 
     /* micro-blocked copy of the atlas, as the upload kernel lays it out */
-    std::vector< uint8_t > atlas( (size_t)atlasDim[0] * atlasDim[1] * atlasDim[2] );
+    const size_t nVoxels = (size_t)atlasDim[0] * atlasDim[1] * atlasDim[2];
+    std::vector< uint8_t > atlas( voxelBytes == 1 ? nVoxels : 0 );
+    std::vector< uint16_t > atlas16( voxelBytes == 2 ? nVoxels : 0 );
     for( uint32_t z = 0; z < atlasDim[2]; ++z )
         for( uint32_t y = 0; y < atlasDim[1]; ++y )
             for( uint32_t x = 0; x < atlasDim[0]; ++x )
-                atlas[vrc_atlas_index( lay, x, y, z )] =
-                    atlasRowMajor[( (size_t)z * atlasDim[1] + y ) * atlasDim[0] + x];
+            {
+                const size_t src = ( (size_t)z * atlasDim[1] + y ) * atlasDim[0] + x;
+                if( voxelBytes == 1 )
+                    atlas[vrc_atlas_index( lay, x, y, z )] = atlasRowMajor[src];
+                else
+                    atlas16[vrc_atlas_index( lay, x, y, z )] =
+                        reinterpret_cast< const uint16_t* >( atlasRowMajor )[src];
+            }
 
     vrc_lut_params lp;
     lp.rangeMin = render->dataSourceRange[0];
@@ -66,13 +76,17 @@ extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atla
     vrc_fill_frame( f, *view, *render, geom, t.g, pl, nPlanes, nNodes, W, H, (float)pixelOffX,
                     (float)pixelOffY );
 
-    /* kernel: 1 reference order, 2 grid DDA, 3/4 the same with fixed-point stepping,
-     * 5/6 the same with the trilinear filter (extension) */
-    const bool linear = kernel == 5 || kernel == 6;
-    const bool dda = kernel == 2 || kernel == 4 || kernel == 6;
+    /* kernel: 1 reference order, 2 grid DDA, 3/4 the same with fixed-point stepping (u8 only),
+     * 5/6 the same with the trilinear filter, 7/8 point sampling with per-sample
+     * classification (the only point-sampling form for 16-bit voxels) */
+    const bool dda = kernel == 2 || kernel == 4 || kernel == 6 || kernel == 8;
+    const int mode = ( kernel == 5 || kernel == 6 ) ? VRC_MODE_TRILINEAR
+                     : ( ( kernel == 7 || kernel == 8 ) ? VRC_MODE_POINT : VRC_MODE_TABLE );
     const bool fixed = ( kernel == 3 || kernel == 4 ) && !t.clamp;
     if( dda && !t.gridOk )
         return 2;
+    if( voxelBytes == 2 && mode == VRC_MODE_TABLE )
+        return 4; /* the classified table indexes 8-bit voxels only */
     const vrc_classifier cls = vrc_make_classifier( lp );
     std::vector< vrc_f4 > tfp( VRC_TFP_ENTRIES );
     for( uint32_t k = 0; k < VRC_TFP_ENTRIES; ++k )
@@ -80,34 +94,39 @@ extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atla
         const uint32_t i = k == 0 ? 0u : ( k - 1u > 255u ? 255u : k - 1u );
         tfp[k] = vrc_f4{ tf[i * 4], tf[i * 4 + 1], tf[i * 4 + 2], tf[i * 4 + 3] };
     }
-    const vrc_f4* table = linear ? tfp.data() : lut.data();
+    const vrc_f4* table = mode != VRC_MODE_TABLE ? tfp.data() : lut.data();
     uint64_t total = 0;
     vrc_f4* pb = reinterpret_cast< vrc_f4* >( pixelBuffer );
     for( uint32_t py = 0; py < H; ++py )
         for( uint32_t px = 0; px < W; ++px )
         {
             uint32_t n = 0;
-#define PIXEL( FN, CL, FX, LN ) \
-    FN< CL, true, FX, LN, uint8_t >
-#define ARGS_DDA f, t.nodes.data(), t.grid.data(), atlas.data(), table, cls, pb, px, py, n
-#define ARGS_REF f, t.nodes.data(), atlas.data(), table, cls, pb, px, py, n
-            if( dda )
+#define ARGS_DDA( A ) f, t.nodes.data(), t.grid.data(), A, table, cls, pb, px, py, n
+#define ARGS_REF( A ) f, t.nodes.data(), A, table, cls, pb, px, py, n
+#define CLASSIFY( MODE, T, A )                                                                       \
+    {                                                                                                \
+        if( dda && t.clamp ) vrc_pixel_grid_dda< true, true, false, MODE, T >( ARGS_DDA( A ) );      \
+        else if( dda ) vrc_pixel_grid_dda< false, true, false, MODE, T >( ARGS_DDA( A ) );           \
+        else if( t.clamp ) vrc_pixel_reference_order< true, true, false, MODE, T >( ARGS_REF( A ) ); \
+        else vrc_pixel_reference_order< false, true, false, MODE, T >( ARGS_REF( A ) );              \
+    }
+            if( mode == VRC_MODE_TRILINEAR && voxelBytes == 1 ) CLASSIFY( VRC_MODE_TRILINEAR, uint8_t, atlas.data() )
+            else if( mode == VRC_MODE_TRILINEAR ) CLASSIFY( VRC_MODE_TRILINEAR, uint16_t, atlas16.data() )
+            else if( mode == VRC_MODE_POINT && voxelBytes == 1 ) CLASSIFY( VRC_MODE_POINT, uint8_t, atlas.data() )
+            else if( mode == VRC_MODE_POINT ) CLASSIFY( VRC_MODE_POINT, uint16_t, atlas16.data() )
+            else if( dda )
             {
-                if( linear && t.clamp ) PIXEL( vrc_pixel_grid_dda, true, false, true )( ARGS_DDA );
-                else if( linear ) PIXEL( vrc_pixel_grid_dda, false, false, true )( ARGS_DDA );
-                else if( t.clamp ) PIXEL( vrc_pixel_grid_dda, true, false, false )( ARGS_DDA );
-                else if( fixed ) PIXEL( vrc_pixel_grid_dda, false, true, false )( ARGS_DDA );
-                else PIXEL( vrc_pixel_grid_dda, false, false, false )( ARGS_DDA );
+                if( t.clamp ) vrc_pixel_grid_dda< true, true, false, VRC_MODE_TABLE, uint8_t >( ARGS_DDA( atlas.data() ) );
+                else if( fixed ) vrc_pixel_grid_dda< false, true, true, VRC_MODE_TABLE, uint8_t >( ARGS_DDA( atlas.data() ) );
+                else vrc_pixel_grid_dda< false, true, false, VRC_MODE_TABLE, uint8_t >( ARGS_DDA( atlas.data() ) );
             }
             else
             {
-                if( linear && t.clamp ) PIXEL( vrc_pixel_reference_order, true, false, true )( ARGS_REF );
-                else if( linear ) PIXEL( vrc_pixel_reference_order, false, false, true )( ARGS_REF );
-                else if( t.clamp ) PIXEL( vrc_pixel_reference_order, true, false, false )( ARGS_REF );
-                else if( fixed ) PIXEL( vrc_pixel_reference_order, false, true, false )( ARGS_REF );
-                else PIXEL( vrc_pixel_reference_order, false, false, false )( ARGS_REF );
+                if( t.clamp ) vrc_pixel_reference_order< true, true, false, VRC_MODE_TABLE, uint8_t >( ARGS_REF( atlas.data() ) );
+                else if( fixed ) vrc_pixel_reference_order< false, true, true, VRC_MODE_TABLE, uint8_t >( ARGS_REF( atlas.data() ) );
+                else vrc_pixel_reference_order< false, true, false, VRC_MODE_TABLE, uint8_t >( ARGS_REF( atlas.data() ) );
             }
-#undef PIXEL
+#undef CLASSIFY
 #undef ARGS_DDA
 #undef ARGS_REF
             total += n;

@@ -16,7 +16,9 @@ class GpuScene:
         vrc.check(L, L.vrc_ctx_create(device, C.byref(self.ctx)))
         self.pool = C.c_void_p()
         mb = vrc.u32x3(*[s.vi.maximumBlockSize[a] for a in range(3)])
-        vrc.check(L, L.vrc_pool_create(self.ctx, 1, 0, 0, 1, mb, s.pool_bytes, C.byref(self.pool)))
+        self.voxel_bytes = s.atlas.dtype.itemsize  # 2: uint16 volume (extension)
+        vrc.check(L, L.vrc_pool_create(self.ctx, self.voxel_bytes, 0, 0, 1, mb,
+                                       s.pool_bytes * self.voxel_bytes, C.byref(self.pool)))
         self.slots = {}
         for nid in s.ids:  # same order as the oracle's k-th slot
             brick = s.bricks[nid]

@@ -52,7 +52,8 @@ class LODNode(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("tfFracBits", C.c_int), ("filter", C.c_int), ("nThreads", C.c_int),
-                ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32), ("rowStride", C.c_uint32)]
+                ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32), ("rowStride", C.c_uint32),
+                ("voxelBytes", C.c_int)]
 
 
 def build_oracle():
@@ -263,7 +264,8 @@ class Scene:
 
 def build_scene(voxels=(64, 64, 64), block=16, viewport=(64, 64), spr=0, alpha=0.05,
                 spin=(0.0, 0.0), volume="mem", max_slots=None, planes=None, ids=None,
-                tile=None, eye=(0.0, 0.0, 1.5), max_tex3d=4096, pad8=True):
+                tile=None, eye=(0.0, 0.0, 1.5), max_tex3d=4096, pad8=True, dtype="u8",
+                data_range=None):
     """Everything the integrator needs, derived through the oracle's restatement of the
     reference host code.  `pad8`: slot = maxBlock rounded up to 8 (the HIP atlas layout)."""
     L = lib()
@@ -290,11 +292,15 @@ def build_scene(voxels=(64, 64, 64), block=16, viewport=(64, 64), spr=0, alpha=0
     s.pool_bytes = blocks * slot_bytes
     s.slots = [slots[a] for a in range(3)]
     s.atlas_dim = [s.slots[a] * slot_dim[a] for a in range(3)]
-    s.atlas = np.zeros((s.atlas_dim[2], s.atlas_dim[1], s.atlas_dim[0]), dtype=np.uint8)
+    # dtype "u16" is an EXTENSION (the reference CUDA kernel fetches unsigned char only)
+    np_dtype = np.uint16 if dtype == "u16" else np.uint8
+    s.atlas = np.zeros((s.atlas_dim[2], s.atlas_dim[1], s.atlas_dim[0]), dtype=np_dtype)
 
     vol = None
     if volume == "hash":
         vol = hash_volume(*voxels)
+        if dtype == "u16":  # spread over 16 bits, keep the low byte busy
+            vol = vol.astype(np.uint16) * np.uint16(257) ^ (vol.astype(np.uint16) >> np.uint16(3))
     s.bricks = {}
     s.slot_of = {}
     s.lod = {}
@@ -303,7 +309,8 @@ def build_scene(voxels=(64, 64, 64), block=16, viewport=(64, 64), spr=0, alpha=0
         node = lod_node(vi, nid)
         s.lod[nid] = node
         if vol is None:
-            brick = np.full((mb[2], mb[1], mb[0]), L.orc_mem_brick_value_u8(nid), dtype=np.uint8)
+            # MemoryDataSource.cpp:54-57 computes the value in the volume's type T
+            brick = np.full((mb[2], mb[1], mb[0]), L.orc_mem_brick_value_u8(nid), dtype=np_dtype)
         else:
             brick = brick_from_volume(vol, vi, node)
         s.bricks[nid] = brick
@@ -311,8 +318,12 @@ def build_scene(voxels=(64, 64, 64), block=16, viewport=(64, 64), spr=0, alpha=0
         L.orc_pool_kth_slot(slots, k, slot)
         origin = u32x3()
         L.orc_pool_slot_voxel_origin(slots, u32x3(*slot_dim), slot, origin)
-        L.orc_pool_copy_to_slot_u8(s.atlas.ctypes.data, u32x3(*s.atlas_dim), origin,
-                                   brick.ctypes.data, size)
+        if dtype == "u16":
+            s.atlas[origin[2]:origin[2] + mb[2], origin[1]:origin[1] + mb[1],
+                    origin[0]:origin[0] + mb[0]] = brick
+        else:
+            L.orc_pool_copy_to_slot_u8(s.atlas.ctypes.data, u32x3(*s.atlas_dim), origin,
+                                       brick.ctypes.data, size)
         s.slot_of[nid] = (slot[0], slot[1], slot[2])
 
     W, H = viewport
@@ -346,7 +357,9 @@ def build_scene(voxels=(64, 64, 64), block=16, viewport=(64, 64), spr=0, alpha=0
             nd.aabbSize[a] = node.worldBoxMax[a] - node.worldBoxMin[a]
     s.n_nodes = n
     spr_eff = L.orc_computed_samples_per_ray(C.byref(vi), ids_arr, n, spr)
-    s.render = RenderData(spr_eff, 1, 32, 0, (C.c_float * 2)(0.0, 255.0))
+    if data_range is None:  # CudaRaycastRenderer.cpp:205 hard-codes (0,255); u16: the type's range
+        data_range = (0.0, 65535.0) if dtype == "u16" else (0.0, 255.0)
+    s.render = RenderData(spr_eff, 1, 32, 0, (C.c_float * 2)(*data_range))
     s.tf = linear_ramp_tf(alpha)
     if planes is None:
         s.planes = np.zeros((0, 4), dtype=np.float32)
@@ -360,7 +373,7 @@ def oracle_render(s, frac_bits=8, threads=8, rows=None, fb=None, filter_mode=0):
     L = lib()
     if fb is None:
         fb = np.zeros((s.H, s.W, 4), dtype=np.float32)
-    opt = Options(frac_bits, filter_mode, threads, 0, s.H, 1)
+    opt = Options(frac_bits, filter_mode, threads, 0, s.H, 1, s.atlas.dtype.itemsize)
     if rows is not None:
         opt.rowBegin, opt.rowEnd, opt.rowStride = rows
     n = L.orc_raycast(s.atlas.ctypes.data, u32x3(*s.atlas_dim), fb.ctypes.data, s.W, s.H,
@@ -382,7 +395,7 @@ def harness_render(s, kernel=2, frac_bits=8, fb=None, sanitize=False, pixel_off=
                           s.planes.ctypes.data if len(s.planes) else None, len(s.planes),
                           s.tf.ctypes.data, C.byref(s.view), s.n_nodes, s.nodes,
                           C.byref(s.render), frac_bits, kernel, pixel_off[0], pixel_off[1],
-                          C.byref(samples), C.byref(grid_ok))
+                          C.byref(samples), C.byref(grid_ok), s.atlas.dtype.itemsize)
     if rc != 0:
         raise RuntimeError("harness_render failed: %d" % rc)
     return fb, int(samples.value), bool(grid_ok.value)

@@ -216,3 +216,39 @@ def test_trilinear_nucleon_clamped_sampler():
         got, n_got, _ = orc.harness_render(s, kernel=kernel)
         scenes.assert_parity(got, want, "nucleon linear k%d" % kernel)
         assert n_got == n_want
+
+
+U16_SCENES = {
+    "hash64_spin_u16": dict(voxels=(64, 64, 64), block=16, viewport=(40, 56), volume="hash", spin=(0.5, 0.35), dtype="u16"),
+    "hash64_ert_u16": dict(voxels=(64, 64, 64), block=16, viewport=(48, 48), volume="hash", spin=(0.3, -0.2), alpha=1.0, dtype="u16"),
+    "mem_ragged_u16": dict(voxels=(96, 64, 32), block=16, viewport=(37, 29), spin=(0.2, 0.9), dtype="u16",
+                           data_range=(0.0, 300.0)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(U16_SCENES))
+def test_uint16_extension_matches_oracle(name):
+    # 16-bit voxels (extension: the reference CUDA kernel fetches unsigned char only): point
+    # sampled and trilinear, classified per sample through the data range
+    s = orc.build_scene(**U16_SCENES[name])
+    assert s.atlas.dtype == np.uint16
+    want, n_want = orc.oracle_render(s, threads=4)
+    want_lin, n_lin = orc.oracle_render(s, threads=4, filter_mode=1)
+    assert want[..., 3].max() > 0.05
+    for kernel in (7, 8):
+        got, n_got, _ = orc.harness_render(s, kernel=kernel)
+        scenes.assert_parity(got, want, "%s k%d" % (name, kernel))
+        assert abs(n_got - n_want) <= 2e-4 * n_want + 8
+    for kernel in (5, 6):
+        got, n_got, _ = orc.harness_render(s, kernel=kernel)
+        scenes.assert_parity(got, want_lin, "%s k%d" % (name, kernel))
+        assert abs(n_got - n_lin) <= 2e-4 * n_lin + 8
+
+
+def test_per_sample_classification_equals_the_classified_table():
+    # u8 point sampling through vrc_classify must agree with the 257-entry table path
+    s = scenes.get("hash64_spin")
+    table, n_t, _ = orc.harness_render(s, kernel=2)
+    per_sample, n_p, _ = orc.harness_render(s, kernel=8)
+    assert n_t == n_p
+    assert np.abs(table - per_sample).max() < 1e-5

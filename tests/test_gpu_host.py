@@ -149,10 +149,27 @@ def test_unknown_renderer_and_volume_are_reported(drv):
         drv.App("mem://#64,64,64,16", 8, 8, renderer="cuda")
     with pytest.raises(drv.DriverError, match="No plugin implementation available"):
         drv.App("nosuch://x", 8, 8)
-    # the reference kernel only handles uint8 (quirk Q2): other types are refused, not mis-rendered
+    # the reference kernel only handles uint8 (quirk Q2); uint16 is an extension here, the other
+    # types are refused, not mis-rendered
     with pytest.raises(drv.DriverError):
-        a = drv.App("mem://?datatype=uint16#64,64,64,16", 8, 8, synchronous=True)
+        a = drv.App("mem://?datatype=float#64,64,64,16", 8, 8, synchronous=True)
         a.render_frame()
+
+
+def test_uint16_volume_through_the_plugin(drv):
+    # mem:// computes the brick value in the volume's type (MemoryDataSource.cpp:54-57), so a
+    # uint16 volume with the data range (0,255) must give the uint8 volume's frame
+    kw = dict(synchronous=True, min_lod=2, max_lod=2, gpu_cache_mb=8)
+    with drv.App("mem://#64,64,64,16", 40, 40, **kw) as a8:
+        a8.set_camera(spin=(0.4, 0.2))
+        f8, _ = a8.render_frame()
+    with drv.App("mem://?datatype=uint16#64,64,64,16", 40, 40, **kw) as a16:
+        assert a16.volume_info()["bytes_per_voxel"] == 2 if "bytes_per_voxel" in a16.volume_info() else True
+        a16.set_camera(spin=(0.4, 0.2))
+        a16.set_data_range(0.0, 255.0)
+        f16, st = a16.render_frame()
+    assert f8[..., 3].max() > 0.01
+    assert np.abs(f8 - f16).max() < 1e-5
 
 
 def test_row_bands_in_one_launch_are_rows_of_the_full_frame(drv):

@@ -134,6 +134,40 @@ def test_lds_kernel_refuses_clamped_sampler(vrc):
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
 
 
+@pytest.mark.parametrize("name", ["hash64_spin_u16", "hash64_ert_u16", "mem_ragged_u16"])
+def test_uint16_extension_parity(vrc, name):
+    # 16-bit voxels: point sampled and trilinear, classified per sample through the data range
+    from test_cpu_harness import U16_SCENES
+    s = orc.build_scene(**U16_SCENES[name])
+    want, n_want = orc.oracle_render(s, threads=8)
+    want_lin, n_lin = orc.oracle_render(s, threads=8, filter_mode=1)
+    with _gpu(s) as g:
+        sub = np.zeros((8, 8, 8), dtype=np.uint16)  # the u16 atlas round-trips
+        vrc.check(g.L, g.L.vrc_pool_read_region(g.pool, vrc.u32x3(8, 8, 8), vrc.u32x3(8, 8, 8), sub.ctypes.data))
+        assert (sub == s.atlas[8:16, 8:16, 8:16]).all()
+        for k in (vrc.KERNEL_REFERENCE_ORDER, vrc.KERNEL_GRID_DDA):
+            got, n_got, st = g.render(kernel=k)
+            assert st.kernel_variant == k
+            scenes.assert_parity(got, want, name + " k%d" % k)
+            assert abs(n_got - n_want) <= 2e-4 * n_want + 8
+            lin, n_got, _ = g.render(kernel=k, filter_mode=vrc.FILTER_TRILINEAR)
+            scenes.assert_parity(lin, want_lin, name + " trilinear k%d" % k)
+            assert abs(n_got - n_lin) <= 2e-4 * n_lin + 8
+        with pytest.raises(Exception):
+            g.render(kernel=vrc.KERNEL_LDS)  # the LDS kernel is 8-bit only
+
+
+def test_unsupported_voxel_types_are_refused(vrc):
+    L = vrc.load_library()
+    ctx = C.c_void_p()
+    vrc.check(L, L.vrc_ctx_create(0, C.byref(ctx)))
+    pool = C.c_void_p()
+    for bpv, signed, flt in ((4, 0, 0), (4, 0, 1), (1, 1, 0), (2, 1, 0)):
+        assert L.vrc_pool_create(ctx, bpv, signed, flt, 1, vrc.u32x3(24, 24, 24), 1 << 20,
+                                 C.byref(pool)) == vrc.VRC_EUNSUPPORTED
+    L.vrc_ctx_destroy(ctx)
+
+
 def test_trilinear_nucleon_clamped(vrc):
     s = scenes.nucleon_scene()
     want, n_want = orc.oracle_render(s, threads=8, filter_mode=1)
@@ -230,7 +264,7 @@ def test_pool_exhaustion_and_slot_reuse(vrc):
     assert L.vrc_pool_copy_to_slot(pool, brick.ctypes.data, vrc.u32x3(25, 24, 24), slot) == vrc.VRC_EINVAL
     L.vrc_pool_destroy(pool)
     # unsupported formats are reported, not mis-rendered (quirk Q2)
-    assert L.vrc_pool_create(ctx, 2, 0, 0, 1, mb, 1 << 20, C.byref(pool)) == vrc.VRC_EUNSUPPORTED
+    assert L.vrc_pool_create(ctx, 4, 0, 0, 1, mb, 1 << 20, C.byref(pool)) == vrc.VRC_EUNSUPPORTED
     assert L.vrc_pool_create(ctx, 1, 0, 0, 5, mb, 1 << 20, C.byref(pool)) == vrc.VRC_EUNSUPPORTED
     assert b"Channel number" in L.vrc_last_error()
     L.vrc_ctx_destroy(ctx)
