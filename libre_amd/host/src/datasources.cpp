@@ -254,8 +254,30 @@ public:
         _volumeInfo.overlap = Vector3ui( 0u );
         _volumeInfo.rootNode = RootNode( 1, Vector3ui( 1 ) ); /* one brick = whole volume, depth 1 */
         _volumeInfo.maximumBlockSize = _volumeInfo.voxels;
-        if( size_t( _volumeInfo.voxels.product() ) * _volumeInfo.getBytesPerVoxel() > _size )
+        if( size_t( _volumeInfo.voxels[0] ) * _volumeInfo.voxels[1] * _volumeInfo.voxels[2] *
+                _volumeInfo.getBytesPerVoxel() > _size )
             throw std::runtime_error( "raw file smaller than the declared volume" );
+        /* EXTENSION (beyond the reference, whose raw source is the single brick above): a fifth
+         * fragment parameter = block size turns the file into an out-of-core bricked volume with
+         * the LOD tree, overlap and brick geometry of mem:// (DataSourcePlugin.cpp:55-109):
+         * bricks are cut from the mapped file on demand (the page cache does the I/O), clamped at
+         * the volume border; level l samples every 2^(depth-1-l)-th voxel. */
+        _bricked = p.size() >= 5;
+        if( _bricked )
+        {
+            const uint32_t block = toUint( p[4] );
+            if( block == 0 )
+                throw std::runtime_error( "raw://: block size 0" );
+            _volumeInfo.overlap = Vector3ui( 4u );
+            _volumeInfo.maximumBlockSize = Vector3ui( block ) + _volumeInfo.overlap * 2u;
+            _volumeInfo.frameRange = FULL_FRAME_RANGE;
+            /* fillRegularVolumeInfo derives world size and tree from voxels / block */
+            if( !fillRegularVolumeInfo( _volumeInfo ) )
+                throw std::runtime_error( "raw://: cannot build the LOD tree for this block size" );
+#if defined( MADV_RANDOM )
+            (void)::madvise( _mmapPtr, _size, MADV_RANDOM );
+#endif
+        }
     }
     ~RawDataSource()
     {
@@ -265,10 +287,63 @@ public:
     static bool handles( const DataSourcePluginData& d ) { return d.getURI().getScheme() == "raw"; }
     MemoryUnitPtr getData( const LODNode& node ) final
     {
+        if( _bricked )
+            return cutBrick( node );
         /* RawDataSource.cpp:123-129 reports blockSize.product() bytes whatever the voxel type
          * (quirk Q14); here the size includes bytes per voxel */
         const size_t dataSize = size_t( node.getBlockSize().product() ) * _volumeInfo.getBytesPerVoxel();
         return MemoryUnitPtr( new ConstMemoryUnit( static_cast< const uint8_t* >( _mmapPtr ), dataSize ) );
+    }
+
+private:
+    /* brick + overlap of one LOD node, cut out of the mapped volume */
+    MemoryUnitPtr cutBrick( const LODNode& node ) const
+    {
+        const size_t bpv = _volumeInfo.getBytesPerVoxel();
+        const Vector3ui bs = node.getBlockSize() + _volumeInfo.overlap * 2u;
+        std::shared_ptr< AllocMemoryUnit > mem( new AllocMemoryUnit( size_t( bs[0] ) * bs[1] * bs[2] * bpv ) );
+        uint8_t* dst = mem->getData< uint8_t >();
+        const uint8_t* src = static_cast< const uint8_t* >( _mmapPtr );
+        const uint32_t shift = _volumeInfo.rootNode.getDepth() - 1 - node.getRefLevel();
+        const Vector3ui o = node.getVoxelBox().getMin();
+        const int64_t vx = _volumeInfo.voxels[0], vy = _volumeInfo.voxels[1], vz = _volumeInfo.voxels[2];
+        /* source x of every brick column, clamped at the volume border */
+        std::vector< int64_t > sx( bs[0] );
+        for( uint32_t x = 0; x < bs[0]; ++x )
+        {
+            const int64_t g = ( int64_t( o[0] ) + x - _volumeInfo.overlap[0] ) << shift;
+            sx[x] = g < 0 ? 0 : ( g > vx - 1 ? vx - 1 : g );
+        }
+        /* the interior run of a finest-level row is contiguous in the file */
+        uint32_t runBegin = 0, runEnd = 0;
+        if( shift == 0 )
+        {
+            while( runBegin < bs[0] && ( int64_t( o[0] ) + runBegin ) < int64_t( _volumeInfo.overlap[0] ) )
+                ++runBegin;
+            runEnd = runBegin;
+            while( runEnd < bs[0] && sx[runEnd] == sx[runBegin] + int64_t( runEnd - runBegin ) )
+                ++runEnd;
+        }
+        for( uint32_t z = 0; z < bs[2]; ++z )
+        {
+            int64_t gz = ( int64_t( o[2] ) + z - _volumeInfo.overlap[2] ) << shift;
+            gz = gz < 0 ? 0 : ( gz > vz - 1 ? vz - 1 : gz );
+            for( uint32_t y = 0; y < bs[1]; ++y )
+            {
+                int64_t gy = ( int64_t( o[1] ) + y - _volumeInfo.overlap[1] ) << shift;
+                gy = gy < 0 ? 0 : ( gy > vy - 1 ? vy - 1 : gy );
+                const uint8_t* row = src + size_t( ( gz * vy + gy ) * vx ) * bpv;
+                uint8_t* out = dst + ( size_t( z ) * bs[1] + y ) * bs[0] * bpv;
+                for( uint32_t x = 0; x < runBegin; ++x )
+                    std::memcpy( out + x * bpv, row + size_t( sx[x] ) * bpv, bpv );
+                if( runEnd > runBegin )
+                    std::memcpy( out + runBegin * bpv, row + size_t( sx[runBegin] ) * bpv,
+                                 size_t( runEnd - runBegin ) * bpv );
+                for( uint32_t x = runEnd; x < bs[0]; ++x )
+                    std::memcpy( out + x * bpv, row + size_t( sx[x] ) * bpv, bpv );
+            }
+        }
+        return mem;
     }
 
 private:
@@ -286,6 +361,7 @@ private:
     void* _mmapPtr;
     int _fd;
     size_t _size;
+    bool _bricked = false;
 };
 
 namespace

@@ -297,7 +297,10 @@ def build_scene(voxels=(64, 64, 64), block=16, viewport=(64, 64), spr=0, alpha=0
     s.atlas = np.zeros((s.atlas_dim[2], s.atlas_dim[1], s.atlas_dim[0]), dtype=np_dtype)
 
     vol = None
-    if volume == "hash":
+    if isinstance(volume, np.ndarray):  # caller-provided (z, y, x) volume of the scene's dtype
+        vol = volume
+        assert vol.dtype == np_dtype and list(vol.shape) == [voxels[2], voxels[1], voxels[0]]
+    elif volume == "hash":
         vol = hash_volume(*voxels)
         if dtype == "u16":  # spread over 16 bits, keep the low byte busy
             vol = vol.astype(np.uint16) * np.uint16(257) ^ (vol.astype(np.uint16) >> np.uint16(3))

@@ -216,3 +216,44 @@ def test_frames_in_flight_share_one_atlas(drv):
         assert tex["misses"] == 64 and tex["count"] == 64  # one upload per brick in total
         with pytest.raises(drv.DriverError):
             app.select_slot(3)
+
+
+def test_out_of_core_raw_uint16_volume_matches_oracle(drv, tmp_path):
+    # BASELINE C3 in small: raw:// uint16 file, bricked on demand with an LOD tree (extension),
+    # asynchronous upload, then the same frame as the synchronous mode and as the oracle
+    from libre_amd import vrc
+    vol = (orc.hash_volume(64, 64, 64).astype(np.uint16) * np.uint16(200)) + np.uint16(7)
+    path = str(tmp_path / "vol16.raw")
+    vol.tofile(path)
+    uri = "raw://%s#64,64,64,uint16,16" % path
+    kw = dict(min_lod=2, max_lod=2, gpu_cache_mb=8)
+    with drv.App(uri, 48, 40, synchronous=True, **kw) as app:
+        assert app.volume_info()["depth"] == 3
+        app.set_camera(spin=(0.5, 0.35))
+        app.set_colormap(orc.linear_ramp_tf(0.05))
+        app.set_data_range(0.0, 51007.0)
+        app.set_option(vrc.OPT_COUNT_SAMPLES, 1)
+        fb, st = app.render_frame()
+        ids = app.visible_set()
+        s = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(48, 40), spin=(0.5, 0.35), volume=vol,
+                            dtype="u16", ids=ids, data_range=(0.0, 51007.0))
+        want, n_want = orc.oracle_render(s, threads=8)
+        assert want[..., 3].max() > 0.05
+        scenes.assert_parity(fb, want, "raw u16 sync")
+        assert abs(int(app.stats().samples) - n_want) <= 2e-4 * n_want + 8
+        app.set_option(vrc.OPT_FILTER, vrc.FILTER_TRILINEAR)
+        lin, _ = app.render_frame()
+        want_lin, _ = orc.oracle_render(s, threads=8, filter_mode=1)
+        scenes.assert_parity(lin, want_lin, "raw u16 trilinear")
+    with drv.App(uri, 48, 40, synchronous=False, **kw) as app:
+        app.set_camera(spin=(0.5, 0.35))
+        app.set_colormap(orc.linear_ramp_tf(0.05))
+        app.set_data_range(0.0, 51007.0)
+        for _ in range(200):
+            out, st = app.render_frame()
+            app.wait_uploads()
+            if st.n_not_available == 0:
+                break
+        assert st.n_not_available == 0
+        out, _ = app.render_frame()
+        assert (out == fb).all()

@@ -139,3 +139,35 @@ def test_raw_data_source_single_brick(drv):
     assert L.lvh_datasource_brick(b"raw:///nonexistent.raw#4,4,4,uint8", 0, None, 0, C.byref(n)) != 0
     assert L.lvh_datasource_brick(b"nosuch://x", 0, None, 0, C.byref(n)) != 0
     assert b"No plugin implementation available" in L.lvh_last_error()
+
+
+@pytest.mark.parametrize("dtype", ["uint8", "uint16"])
+def test_raw_data_source_bricked_out_of_core(drv, tmp_path, dtype):
+    # EXTENSION (BASELINE C3): a fifth fragment parameter bricks the raw file with the tree and
+    # overlap of mem://; bricks are cut from the mapped file, clamped at the volume border;
+    # coarser levels take every 2^k-th voxel
+    vol = orc.hash_volume(48, 32, 64)  # (z, y, x) = (64, 32, 48), ragged tree
+    if dtype == "uint16":
+        vol = vol.astype(np.uint16) * np.uint16(257)
+    path = str(tmp_path / "vol.raw")
+    vol.tofile(path)
+    uri = "raw://%s#48,32,64,%s,16" % (path, dtype)
+    vi = orc.mem_volume_info(48, 32, 64, 16)
+    for nid in orc.leaf_ids(vi):
+        want = orc.brick_from_volume(vol, vi, orc.lod_node(vi, nid))
+        got = drv.datasource_brick(uri, nid).view(vol.dtype).reshape(want.shape)
+        assert (got == want).all()
+    # one level up: stride 2 in the full-resolution volume
+    depth = vi.depth
+    nid = orc.pack(depth - 2, 0, 0, 0)
+    node = orc.lod_node(vi, nid)
+    ov = 4
+    lo = [int(node.voxelBoxMin[a]) - ov for a in range(3)]
+    hi = [int(node.voxelBoxMax[a]) + ov for a in range(3)]
+    ix = [np.clip(np.arange(lo[a], hi[a]) * 2, 0, vol.shape[2 - a] - 1) for a in range(3)]
+    want = vol[np.ix_(ix[2], ix[1], ix[0])]
+    got = drv.datasource_brick(uri, nid).view(vol.dtype).reshape(want.shape)
+    assert (got == want).all()
+    # the four-parameter form stays the reference's single brick
+    whole = drv.datasource_brick("raw://%s#48,32,64,%s" % (path, dtype), orc.pack(0, 0, 0, 0))
+    assert (whole.view(vol.dtype) == vol.ravel()).all()
