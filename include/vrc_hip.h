@@ -90,6 +90,16 @@ typedef struct
                                    * voxel-space increments | 0 the reference's float world-space
                                    * accumulation (cuda/Renderer.cu:208: pos += step) */
 
+#define VRC_OPT_VARIANT 7         /* which of the reference's two raycasters the frame must match:
+                                   * VRC_VARIANT_CUDARAYCASTER (default) | VRC_VARIANT_GLRAYCASTER */
+
+#define VRC_VARIANT_CUDARAYCASTER 0 /* renderers/cudaRaycaster/cuda/Renderer.cu:95-230 */
+#define VRC_VARIANT_GLRAYCASTER 1   /* renderers/glRaycaster/shaders/fragRaycast.glsl:113-215: pixel centre
+                                     * +0.5, hit test t0 <= t1, first sample of a brick snapped to the
+                                     * global step lattice, clip planes per brick after the snap (the
+                                     * RGBA8 transfer function of GLRaycastRenderer.cpp:188-192 is the
+                                     * caller's: pass the quantised table to vrc_update) */
+
 #define VRC_FILTER_NEAREST 0   /* cuda/TexturePool.cu:167 (cudaFilterModePoint): the reference */
 #define VRC_FILTER_TRILINEAR 1 /* extension: texel centres at i+0.5, float weights, transfer function
                                 * and opacity correction evaluated per sample on the interpolated density */

@@ -123,6 +123,7 @@ struct vrc_ctx
     vrc_frame tileOrderFrame;
     int64_t optTileOrder = 1;
     int64_t optStepping = 1;
+    int64_t optVariant = VRC_VARIANT_CUDARAYCASTER;
 
     unsigned long long* dCounter = nullptr;
     unsigned long long* hCounter = nullptr; /* pinned */
@@ -252,6 +253,11 @@ int vrc_set_option( vrc_ctx* c, int option, int64_t value )
     case VRC_OPT_COUNT_SAMPLES: c->optCount = value ? 1 : 0; return VRC_OK;
     case VRC_OPT_TILE_ORDER: c->optTileOrder = value ? 1 : 0; return VRC_OK;
     case VRC_OPT_STEPPING: c->optStepping = value ? 1 : 0; return VRC_OK;
+    case VRC_OPT_VARIANT:
+        if( value != VRC_VARIANT_CUDARAYCASTER && value != VRC_VARIANT_GLRAYCASTER )
+            return fail( VRC_EINVAL, "vrc_set_option: variant is 0 (cudaRaycaster) or 1 (glRaycaster)" );
+        c->optVariant = value;
+        return VRC_OK;
     default: return fail( VRC_EINVAL, "vrc_set_option: unknown option" );
     }
 }
@@ -268,6 +274,7 @@ int vrc_get_option( vrc_ctx* c, int option, int64_t* value )
     case VRC_OPT_COUNT_SAMPLES: *value = c->optCount; return VRC_OK;
     case VRC_OPT_TILE_ORDER: *value = c->optTileOrder; return VRC_OK;
     case VRC_OPT_STEPPING: *value = c->optStepping; return VRC_OK;
+    case VRC_OPT_VARIANT: *value = c->optVariant; return VRC_OK;
     default: return fail( VRC_EINVAL, "vrc_get_option: unknown option" );
     }
 }
@@ -862,9 +869,13 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         }
         for( int a = 0; a < 3; ++a )
             geom.slots[a] = pool->slots[a];
+        /* the GLSL twin casts through the pixel centre (gl_FragCoord, fragRaycast.glsl:127), the
+         * CUDA kernel through the pixel corner (Renderer.cu:106-112) */
+        const float centre = c->optVariant == VRC_VARIANT_GLRAYCASTER ? 0.5f : 0.0f;
         vrc_fill_frame( f, *view, *render, geom, c->cachedGridFrame, c->planes, c->nPlanes, nNodes,
-                        c->fbW, c->fbH, 0.0f, 0.0f );
+                        c->fbW, c->fbH, centre, centre );
         f.rowMap = c->rowMap.empty() ? nullptr : c->dRowMap;
+        f.variant = c->optVariant == VRC_VARIANT_GLRAYCASTER ? VRC_VARIANT_GL : VRC_VARIANT_CUDA;
     }
 
     /* tile schedule, recomputed only when the frame constants changed */

@@ -35,6 +35,8 @@
 #define VRC_FAST_FP
 #endif
 
+#define VRC_VARIANT_CUDA 0u
+#define VRC_VARIANT_GL 1u
 #define VRC_EARLY_EXIT 0.999f     /* Renderer.cu:34 */
 #define VRC_EPSILON 0.0000000001f /* Renderer.cu:35 */
 
@@ -89,6 +91,9 @@ struct vrc_frame
     /* sort-first row bands: frame row of every row of the pixel buffer (NULL = identity).  The
      * buffer then holds height rows picked from a frame of vpH rows (vrc_set_row_map). */
     const uint32_t* rowMap;
+    /* 0: cudaRaycaster semantics (cuda/Renderer.cu); 1: the GLSL twin's
+     * (glRaycaster/shaders/fragRaycast.glsl), see vrc_brick_segment */
+    uint32_t variant;
 };
 
 /* Atlas memory layout.  The logical atlas is the reference's 3-D array of slots
@@ -254,9 +259,11 @@ VRC_HD vrc_ray vrc_setup_ray( const vrc_frame& f, uint32_t px, uint32_t py )
     const vrc_f3 gmin = { f.aabbMin[0], f.aabbMin[1], f.aabbMin[2] };
     const vrc_f3 gmax = { f.aabbMax[0], f.aabbMax[1], f.aabbMax[2] };
     r.hit = vrc_intersect_box( r.origin, r.invDir, gmin, gmax, &r.tNearGlobal, &r.tFarGlobal );
+    if( f.variant == VRC_VARIANT_GL ) /* fragRaycast.glsl:101: t0 <= t1 */
+        r.hit = r.tNearGlobal <= r.tFarGlobal;
 
-    /* Renderer.cu:132-146 */
-    for( uint32_t i = 0; i < f.nPlanes; ++i )
+    /* Renderer.cu:132-146; the GLSL twin clips per brick instead (fragRaycast.glsl:162-174) */
+    for( uint32_t i = 0; i < ( f.variant == VRC_VARIANT_GL ? 0u : f.nPlanes ); ++i )
     {
         const vrc_f3 n = { f.planes[i][0], f.planes[i][1], f.planes[i][2] };
         float rn = vrc_dot( r.dir, n );
@@ -287,8 +294,8 @@ struct vrc_segment
     float dist;
 };
 
-VRC_HD bool vrc_brick_segment( const vrc_ray& r, const vrc_dev_node& n, float stepSize,
-                               vrc_segment* s, bool* stop )
+VRC_HD bool vrc_brick_segment( const vrc_frame& f, const vrc_ray& r, const vrc_dev_node& n,
+                               float stepSize, vrc_segment* s, bool* stop )
 {
     VRC_STRICT_FP
     const vrc_f3 boxMin = { n.aabbMin[0], n.aabbMin[1], n.aabbMin[2] };
@@ -296,19 +303,53 @@ VRC_HD bool vrc_brick_segment( const vrc_ray& r, const vrc_dev_node& n, float st
                             boxMin.z + n.aabbSize[2] };
     float tNear = 0.0f, tFar = 0.0f;
     *stop = false;
-    if( !vrc_intersect_box( r.origin, r.invDir, boxMin, boxMax, &tNear, &tFar ) )
-        return false;
-    if( tNear > r.tFarGlobal )
+    if( f.variant == VRC_VARIANT_GL )
     {
-        *stop = true;
-        return false;
+        /* fragRaycast.glsl:142-177: hit test t0 <= t1; tnear raised to the near plane only;
+         * first sample snapped to the lattice tnearGlobal + k*stepSize; clip planes move this
+         * brick's interval, after the snap */
+        (void)vrc_intersect_box( r.origin, r.invDir, boxMin, boxMax, &tNear, &tFar );
+        if( !( tNear <= tFar ) )
+            return false;
+        if( tNear < r.tNearPlane )
+            tNear = r.tNearPlane;
+        const float a = tNear - r.tNearGlobal;
+        const float residu = a - stepSize * floorf( a / stepSize );
+        if( residu > 0.0f )
+            tNear += stepSize - residu;
+        if( tNear > tFar )
+            return false;
+        for( uint32_t i = 0; i < f.nPlanes; ++i )
+        {
+            const vrc_f3 pn = { f.planes[i][0], f.planes[i][1], f.planes[i][2] };
+            float rn = vrc_dot( r.dir, pn );
+            if( rn == 0.0f )
+                rn = VRC_EPSILON;
+            const float t = -( vrc_dot( pn, r.origin ) + f.planes[i][3] ) / rn;
+            if( rn > 0.0f )
+                tNear = fmaxf( tNear, t );
+            else
+                tFar = fminf( tFar, t );
+        }
+        if( tNear > tFar )
+            return false;
     }
-    if( tFar < r.tNearGlobal )
-        return false;
-    tNear = fmaxf( fmaxf( r.tNearPlane, tNear ), r.tNearGlobal );
-    tFar = fminf( tFar, r.tFarGlobal );
-    if( tNear > tFar )
-        return false;
+    else
+    {
+        if( !vrc_intersect_box( r.origin, r.invDir, boxMin, boxMax, &tNear, &tFar ) )
+            return false;
+        if( tNear > r.tFarGlobal )
+        {
+            *stop = true;
+            return false;
+        }
+        if( tFar < r.tNearGlobal )
+            return false;
+        tNear = fmaxf( fmaxf( r.tNearPlane, tNear ), r.tNearGlobal );
+        tFar = fminf( tFar, r.tFarGlobal );
+        if( tNear > tFar )
+            return false;
+    }
 
     const vrc_f3 rayStart = { r.origin.x + r.dir.x * tNear, r.origin.y + r.dir.y * tNear,
                               r.origin.z + r.dir.z * tNear };
@@ -857,7 +898,7 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
         const vrc_dev_node n = nodes[i];
         vrc_segment s;
         bool stop;
-        if( !vrc_brick_segment( r, n, f.stepSize, &s, &stop ) )
+        if( !vrc_brick_segment( f, r, n, f.stepSize, &s, &stop ) )
         {
             if( stop )
                 break;
@@ -933,7 +974,7 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
                 const vrc_dev_node n = nodes[node];
                 vrc_segment s;
                 bool stop;
-                if( vrc_brick_segment( r, n, f.stepSize, &s, &stop ) )
+                if( vrc_brick_segment( f, r, n, f.stepSize, &s, &stop ) )
                 {
                     if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T >( f, n, s, atlas, lut,
                                                                                  cls, color, nSamples ) )

@@ -262,7 +262,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                         const vrc_dev_node n = nodes[node];
                         vrc_segment s;
                         bool stop;
-                        if( vrc_brick_segment( r, n, stepSize, &s, &stop ) )
+                        if( vrc_brick_segment( f, r, n, stepSize, &s, &stop ) )
                         {
                             if( s.dist > 0.0f )
                             {

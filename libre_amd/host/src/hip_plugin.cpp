@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -290,8 +291,15 @@ void HipRaycastRenderer::preRender( const RenderInputs& renderInputs, const Cons
     for( size_t i = 0; i < planes.size(); ++i )
         for( int k = 0; k < 4; ++k )
             flat[i * 4 + k] = planes[i][k];
-    throwOnVrcError( vrc_update( _ctx, renderInputs.renderSettings.getColorMap().sampleColors().data(),
-                                 planes.empty() ? nullptr : flat, uint32_t( planes.size() ) ),
+    int64_t variant = VRC_VARIANT_CUDARAYCASTER;
+    (void)vrc_get_option( _ctx, VRC_OPT_VARIANT, &variant );
+    std::vector< float > colors = renderInputs.renderSettings.getColorMap().sampleColors();
+    if( variant == VRC_VARIANT_GLRAYCASTER )
+        /* the GL renderer's transfer function is an RGBA8 texture (GLRaycastRenderer.cpp:188-192) */
+        for( float& c : colors )
+            c = std::floor( std::min( std::max( c, 0.0f ), 1.0f ) * 255.0f + 0.5f ) / 255.0f;
+    throwOnVrcError( vrc_update( _ctx, colors.data(), planes.empty() ? nullptr : flat,
+                                 uint32_t( planes.size() ) ),
                      "vrc_update" );
 
     const VolumeInformation& volInfo = renderInputs.dataSource.getVolumeInfo();

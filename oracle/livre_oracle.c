@@ -764,6 +764,134 @@ static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
     return nSamples;
 }
 
+
+/* one pixel of the GLSL twin, renderers/glRaycaster/shaders/fragRaycast.glsl:113-215, with the
+ * per-brick draws (GLRaycastRenderer.cpp:431-510) folded into one loop over the sorted bricks:
+ * the accumulation image (imageLoad/imageStore, :115, :214) is the running colour; a brick the
+ * ray misses or that lies behind the early-exit threshold is "discard".  nSamplesPerPixel = 1
+ * (jitter rand(0,0)/2 = 0, :121-127).  Differences from Renderer.cu, line by line:
+ *   :127     gl_FragCoord = pixel centre (x+0.5, y+0.5), the CUDA kernel uses (x, y)
+ *   :101     intersectBox returns t0 <= t1 (CUDA: tfar > tnear)
+ *   :149-150 tnear is raised to the near plane only (CUDA also clamps to the global interval)
+ *   :154-157 residu = mod(tnear - tnearGlobal, stepSize); tnear += stepSize - residu if > 0
+ *   :162-174 clip planes move this brick's tnear/tfar, after the snap
+ * The volume fetch is the atlas fetch of the CUDA variant (the GL renderer keeps one GL_NEAREST
+ * texture per brick, TexturePool.cpp:103-104: same voxel up to coordinate rounding); the transfer
+ * function an RGBA8 texture (GLRaycastRenderer.cpp:188-192): the caller passes it quantised. */
+static uint64_t raycast_pixel_gl( const job_t* j, uint32_t x, uint32_t y )
+{
+    const orc_view_data* viewData = j->view;
+    const orc_render_data* renderData = j->render;
+    uint64_t nSamples = 0;
+
+    const size_t pixelPos = (size_t)y * j->width + x;
+    float* px = j->pixelBuffer + pixelPos * 4;
+    float color[4] = { px[0], px[1], px[2], px[3] };
+
+    const f4 pixelEyeSpacePos = eye_space_from_window( (float)x + 0.5f, (float)y + 0.5f,
+                                                       viewData->glViewport, viewData->invProjMatrix );
+    const f4 pixelWorldSpacePos = mat_mul_vec4( viewData->invViewMatrix, pixelEyeSpacePos );
+    const f3 eyePos = { viewData->eyePosition[0], viewData->eyePosition[1],
+                        viewData->eyePosition[2] };
+    const f3 d0 = { pixelWorldSpacePos.x - eyePos.x, pixelWorldSpacePos.y - eyePos.y,
+                    pixelWorldSpacePos.z - eyePos.z };
+    f3 dir = normalize_f3( d0 );
+    if( dir.x == 0.0f ) dir.x = EPSILON;
+    if( dir.y == 0.0f ) dir.y = EPSILON;
+    if( dir.z == 0.0f ) dir.z = EPSILON;
+    const f3 origin = eyePos;
+
+    float tnearGlobal, tfarGlobal;
+    const f3 globalBoxMin = { viewData->aabbMin[0], viewData->aabbMin[1], viewData->aabbMin[2] };
+    const f3 globalBoxMax = { viewData->aabbMax[0], viewData->aabbMax[1], viewData->aabbMax[2] };
+    intersect_box( origin, dir, globalBoxMin, globalBoxMax, &tnearGlobal, &tfarGlobal );
+    if( !( tnearGlobal <= tfarGlobal ) )
+        return 0;
+
+    const f3 e3 = { pixelEyeSpacePos.x, pixelEyeSpacePos.y, pixelEyeSpacePos.z };
+    const f3 nPixelEyeSpacePos = normalize_f3( e3 );
+    const float tNearPlane = -viewData->nearPlane / nPixelEyeSpacePos.z;
+
+    const float r0 = renderData->dataSourceRange[0], r1 = renderData->dataSourceRange[1];
+    const float multiplyer = 1.0f / ( r1 - r0 );
+    const float addedValue = -r0 / ( r1 - r0 );
+    const float alphaCorrection =
+        (float)renderData->maxSamplesPerRay / (float)renderData->samplesPerRay;
+    const float stepSize = 1.0f / (float)renderData->samplesPerRay;
+
+    for( uint32_t i = 0; i < j->nodeCount; ++i )
+    {
+        if( color[3] > EARLY_EXIT ) /* :115-117 */
+            break;
+        const orc_node_data* nodeData = &j->nodes[i];
+        const f3 boxMin = { nodeData->aabbMin[0], nodeData->aabbMin[1], nodeData->aabbMin[2] };
+        const f3 boxSize = { nodeData->aabbSize[0], nodeData->aabbSize[1], nodeData->aabbSize[2] };
+        const f3 boxMax = { boxMin.x + boxSize.x, boxMin.y + boxSize.y, boxMin.z + boxSize.z };
+
+        float tnear = 0.0f, tfar = 0.0f;
+        intersect_box( origin, dir, boxMin, boxMax, &tnear, &tfar );
+        if( !( tnear <= tfar ) )
+            continue;
+        if( tnear < tNearPlane )
+            tnear = tNearPlane;
+        const float a = tnear - tnearGlobal;
+        const float residu = a - stepSize * floorf( a / stepSize ); /* GLSL mod() */
+        if( residu > 0.0f )
+            tnear += stepSize - residu;
+        if( tnear > tfar )
+            continue;
+        for( uint32_t k = 0; k < j->nPlanes; ++k )
+        {
+            const float* cp = j->clipPlanes + 4 * k;
+            const f3 planeNormal = { cp[0], cp[1], cp[2] };
+            float rn = dot3( dir, planeNormal );
+            if( rn == 0.0f )
+                rn = EPSILON;
+            const float t = -( dot3( planeNormal, eyePos ) + cp[3] ) / rn;
+            if( rn > 0.0f )
+                tnear = fmaxf( tnear, t );
+            else
+                tfar = fminf( tfar, t );
+        }
+        if( tnear > tfar )
+            continue;
+
+        const f3 rayStart = { origin.x + dir.x * tnear, origin.y + dir.y * tnear,
+                              origin.z + dir.z * tnear };
+        const f3 rayStop = { origin.x + dir.x * tfar, origin.y + dir.y * tfar,
+                             origin.z + dir.z * tfar };
+        f3 pos = rayStart;
+        const f3 diff = { rayStop.x - rayStart.x, rayStop.y - rayStart.y, rayStop.z - rayStart.z };
+        const f3 ndiff = normalize_f3( diff );
+        const f3 step = { ndiff.x * stepSize, ndiff.y * stepSize, ndiff.z * stepSize };
+        const float dist = sqrtf( dot3( diff, diff ) );
+        const f3 texMin = { nodeData->textureMin[0], nodeData->textureMin[1], nodeData->textureMin[2] };
+        const f3 texSize = { nodeData->textureSize[0], nodeData->textureSize[1], nodeData->textureSize[2] };
+
+        for( float travel = dist; travel > 0.0f;
+             pos.x += step.x, pos.y += step.y, pos.z += step.z, travel -= stepSize )
+        {
+            const f3 texPos = { ( ( pos.x - boxMin.x ) / boxSize.x ) * texSize.x + texMin.x,
+                                ( ( pos.y - boxMin.y ) / boxSize.y ) * texSize.y + texMin.y,
+                                ( ( pos.z - boxMin.z ) / boxSize.z ) * texSize.z + texMin.z };
+            const float density = j->opt.filter
+                                      ? fetch_trilinear( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos )
+                                      : fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
+            float transferFn[4];
+            orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, transferFn );
+            orc_composite( transferFn, color, alphaCorrection );
+            ++nSamples;
+            if( color[3] > EARLY_EXIT )
+                break;
+        }
+    }
+    px[0] = color[0];
+    px[1] = color[1];
+    px[2] = color[2];
+    px[3] = color[3];
+    return nSamples;
+}
+
 typedef struct
 {
     const job_t* job;
@@ -784,7 +912,7 @@ static void* worker_main( void* p )
             break;
         const uint32_t y = (uint32_t)y64;
         for( uint32_t x = 0; x < j->width; ++x )
-            n += raycast_pixel( j, x, y );
+            n += j->opt.variant == 1 ? raycast_pixel_gl( j, x, y ) : raycast_pixel( j, x, y );
     }
     w->samples = n;
     return NULL;
@@ -820,6 +948,7 @@ uint64_t orc_raycast( const uint8_t* atlas, const uint32_t atlasDim[3], float* p
         job.opt.rowEnd = height;
         job.opt.rowStride = 1;
         job.opt.voxelBytes = 1;
+        job.opt.variant = 0;
     }
     if( job.opt.rowStride == 0 ) job.opt.rowStride = 1;
     if( job.opt.rowEnd == 0 || job.opt.rowEnd > height ) job.opt.rowEnd = height;

@@ -92,6 +92,10 @@ typedef struct
     int voxelBytes;  /* 0 or 1 = uint8 atlas (the reference kernel, Renderer.cu:211); 2 = uint16 atlas
                       * (EXTENSION: the reference CUDA kernel fetches unsigned char only; the value
                       * is mapped through RenderData.dataSourceRange as Renderer.cu:162-164 does) */
+    int variant;     /* 0 = cudaRaycaster (cuda/Renderer.cu:95-230); 1 = glRaycaster: the GLSL twin
+                      * (shaders/fragRaycast.glsl:113-215) -- pixel centre at +0.5, hit test
+                      * t0 <= t1, first sample of a brick snapped to the global step lattice, clip
+                      * planes applied per brick after the snap, no clamp to the global interval */
 } orc_options;
 
 /* ---- NodeId: livre/core/data/NodeId.h:38-49, livre/core/types.h:191-195, mathTypes.h:82 */

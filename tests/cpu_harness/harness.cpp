@@ -16,7 +16,7 @@ extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atla
                                const vrc_view_data* view, uint32_t nNodes,
                                const vrc_node_data* nodes, const vrc_render_data* render,
                                int fracBits, int kernel, int pixelOffX, int pixelOffY,
-                               uint64_t* samplesOut, int* gridOkOut, int voxelBytes )
+                               uint64_t* samplesOut, int* gridOkOut, int voxelBytes, int variant )
 {
     if( voxelBytes != 1 && voxelBytes != 2 )
         return 3;
@@ -73,8 +73,10 @@ extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atla
             pl[i][k] = planes[i * 4 + k];
     vrc_frame f;
     std::memset( &f, 0, sizeof( f ) );
-    vrc_fill_frame( f, *view, *render, geom, t.g, pl, nPlanes, nNodes, W, H, (float)pixelOffX,
-                    (float)pixelOffY );
+    const float centre = variant == 1 ? 0.5f : 0.0f; /* glRaycaster: gl_FragCoord */
+    vrc_fill_frame( f, *view, *render, geom, t.g, pl, nPlanes, nNodes, W, H, (float)pixelOffX + centre,
+                    (float)pixelOffY + centre );
+    f.variant = variant == 1 ? VRC_VARIANT_GL : VRC_VARIANT_CUDA;
 
     /* kernel: 1 reference order, 2 grid DDA, 3/4 the same with fixed-point stepping (u8 only),
      * 5/6 the same with the trilinear filter, 7/8 point sampling with per-sample

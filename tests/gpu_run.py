@@ -36,13 +36,14 @@ class GpuScene:
                     slots=list(sl), free=fs.value)
 
     def render(self, kernel=vrc.KERNEL_AUTO, frac_bits=8, count=True, passes=None, stepping=1,
-               filter_mode=0):
+               filter_mode=0, variant=0):
         L, s = self.L, self.s
         vrc.check(L, L.vrc_set_option(self.ctx, vrc.OPT_KERNEL, kernel))
         vrc.check(L, L.vrc_set_option(self.ctx, vrc.OPT_TF_FRAC_BITS, frac_bits))
         vrc.check(L, L.vrc_set_option(self.ctx, vrc.OPT_COUNT_SAMPLES, 1 if count else 0))
         vrc.check(L, L.vrc_set_option(self.ctx, vrc.OPT_STEPPING, stepping))
         vrc.check(L, L.vrc_set_option(self.ctx, vrc.OPT_FILTER, filter_mode))
+        vrc.check(L, L.vrc_set_option(self.ctx, vrc.OPT_VARIANT, variant))
         planes = s.planes
         vrc.check(L, L.vrc_update(self.ctx, s.tf.ctypes.data,
                                   planes.ctypes.data if len(planes) else None, len(planes)))

@@ -53,7 +53,7 @@ class LODNode(C.Structure):
 class Options(C.Structure):
     _fields_ = [("tfFracBits", C.c_int), ("filter", C.c_int), ("nThreads", C.c_int),
                 ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32), ("rowStride", C.c_uint32),
-                ("voxelBytes", C.c_int)]
+                ("voxelBytes", C.c_int), ("variant", C.c_int)]
 
 
 def build_oracle():
@@ -371,12 +371,12 @@ def build_scene(voxels=(64, 64, 64), block=16, viewport=(64, 64), spr=0, alpha=0
     return s
 
 
-def oracle_render(s, frac_bits=8, threads=8, rows=None, fb=None, filter_mode=0):
+def oracle_render(s, frac_bits=8, threads=8, rows=None, fb=None, filter_mode=0, variant=0):
     """Run the oracle integrator on a scene. Returns (rgba[H,W,4], samples)."""
     L = lib()
     if fb is None:
         fb = np.zeros((s.H, s.W, 4), dtype=np.float32)
-    opt = Options(frac_bits, filter_mode, threads, 0, s.H, 1, s.atlas.dtype.itemsize)
+    opt = Options(frac_bits, filter_mode, threads, 0, s.H, 1, s.atlas.dtype.itemsize, variant)
     if rows is not None:
         opt.rowBegin, opt.rowEnd, opt.rowStride = rows
     n = L.orc_raycast(s.atlas.ctypes.data, u32x3(*s.atlas_dim), fb.ctypes.data, s.W, s.H,
@@ -386,7 +386,7 @@ def oracle_render(s, frac_bits=8, threads=8, rows=None, fb=None, filter_mode=0):
     return fb, int(n)
 
 
-def harness_render(s, kernel=2, frac_bits=8, fb=None, sanitize=False, pixel_off=(0, 0)):
+def harness_render(s, kernel=2, frac_bits=8, fb=None, sanitize=False, pixel_off=(0, 0), variant=0):
     """Run the host build of the HIP kernel's per-ray code (vrc_core.h)."""
     H = harness(sanitize)
     if fb is None:
@@ -398,7 +398,7 @@ def harness_render(s, kernel=2, frac_bits=8, fb=None, sanitize=False, pixel_off=
                           s.planes.ctypes.data if len(s.planes) else None, len(s.planes),
                           s.tf.ctypes.data, C.byref(s.view), s.n_nodes, s.nodes,
                           C.byref(s.render), frac_bits, kernel, pixel_off[0], pixel_off[1],
-                          C.byref(samples), C.byref(grid_ok), s.atlas.dtype.itemsize)
+                          C.byref(samples), C.byref(grid_ok), s.atlas.dtype.itemsize, variant)
     if rc != 0:
         raise RuntimeError("harness_render failed: %d" % rc)
     return fb, int(samples.value), bool(grid_ok.value)

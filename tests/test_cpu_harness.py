@@ -252,3 +252,22 @@ def test_per_sample_classification_equals_the_classified_table():
     per_sample, n_p, _ = orc.harness_render(s, kernel=8)
     assert n_t == n_p
     assert np.abs(table - per_sample).max() < 1e-5
+
+
+@pytest.mark.parametrize("name", sorted(scenes.SCENES))
+def test_glraycaster_variant_matches_its_oracle(name):
+    # the second parity target: the GLSL twin's semantics (fragRaycast.glsl:113-215) --
+    # pixel centres, lattice-snapped first sample, per-brick clip planes
+    s = scenes.get(name)
+    want, n_want = orc.oracle_render(s, threads=4, variant=1)
+    for kernel in (1, 2, 4):
+        got, n_got, _ = orc.harness_render(s, kernel=kernel, variant=1)
+        scenes.assert_parity(got, want, "%s gl k%d" % (name, kernel))
+        assert abs(n_got - n_want) <= 3e-4 * n_want + 8
+
+
+def test_the_two_reference_variants_differ():
+    s = scenes.get("hash64_spin")
+    cuda, _ = orc.oracle_render(s, threads=4)
+    gl, _ = orc.oracle_render(s, threads=4, variant=1)
+    assert np.abs(cuda - gl).max() > 10 * scenes.MAX_ABS

@@ -257,3 +257,21 @@ def test_out_of_core_raw_uint16_volume_matches_oracle(drv, tmp_path):
         assert st.n_not_available == 0
         out, _ = app.render_frame()
         assert (out == fb).all()
+
+
+def test_glraycaster_variant_through_the_plugin(drv):
+    # VRC_OPT_VARIANT on the renderer plugin: GLSL-twin semantics + RGBA8 transfer function
+    from libre_amd import vrc
+    with drv.App("hash://#64,64,64,16", 48, 48, synchronous=True, min_lod=2, max_lod=2,
+                 gpu_cache_mb=8) as app:
+        app.set_camera(spin=(0.5, 0.35))
+        tf = orc.linear_ramp_tf(0.3)
+        app.set_colormap(tf)
+        app.set_option(vrc.OPT_VARIANT, vrc.VARIANT_GLRAYCASTER)
+        fb, _ = app.render_frame()
+        ids = app.visible_set()
+        s = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(48, 48), spin=(0.5, 0.35), alpha=0.3,
+                            volume="hash", ids=ids)
+        s.tf = (np.floor(np.clip(s.tf, 0, 1) * 255.0 + 0.5) / 255.0).astype(np.float32)
+        want, _ = orc.oracle_render(s, threads=8, variant=1)
+        scenes.assert_parity(fb, want, "gl variant via plugin")

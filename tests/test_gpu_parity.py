@@ -168,6 +168,21 @@ def test_unsupported_voxel_types_are_refused(vrc):
     L.vrc_ctx_destroy(ctx)
 
 
+@pytest.mark.parametrize("name", sorted(scenes.SCENES))
+def test_glraycaster_variant_parity(vrc, name):
+    # VRC_OPT_VARIANT = glRaycaster: the GLSL twin's frame (second parity target)
+    s = scenes.get(name)
+    want, n_want = orc.oracle_render(s, threads=8, variant=1)
+    with _gpu(s) as g:
+        for k in (vrc.KERNEL_REFERENCE_ORDER, vrc.KERNEL_GRID_DDA, vrc.KERNEL_LDS):
+            got, n_got, st = g.render(kernel=k, variant=vrc.VARIANT_GLRAYCASTER)
+            assert st.kernel_variant == k
+            scenes.assert_parity(got, want, name + " gl k%d" % k)
+            assert abs(n_got - n_want) <= 3e-4 * n_want + 8
+        back, _, _ = g.render()  # and back to the CUDA variant
+        scenes.assert_parity(back, orc.oracle_render(s, threads=8)[0], name + " cuda after gl")
+
+
 def test_trilinear_nucleon_clamped(vrc):
     s = scenes.nucleon_scene()
     want, n_want = orc.oracle_render(s, threads=8, filter_mode=1)
