@@ -53,8 +53,16 @@ struct vrc_pool
     size_t slotBytes = 0, atlasBytes = 0;
     void* dAtlas = nullptr;
 
-    std::mutex mutex; /* free list + staging ring index + upload event */
-    std::vector< std::array< float, 3 > > freeList;
+    std::mutex mutex; /* free list + staging ring index + upload event + render fences */
+    /* slot position + "was in use before" flag: a released slot may still be read by a march
+     * that is in flight; the upload that reuses it waits for the render fences first */
+    std::vector< std::array< float, 4 > > freeList;
+    struct RenderFence
+    {
+        const vrc_ctx* ctx;
+        hipEvent_t event;
+    };
+    std::vector< RenderFence > renderFences; /* last march of every context that used this pool */
 
     hipStream_t uploadStream = nullptr;
     hipEvent_t lastUpload = nullptr;
@@ -358,7 +366,7 @@ int vrc_pool_create( vrc_ctx* c, size_t bytesPerVoxel, int isSigned, int isFloat
             for( int k = (int)p->slots[2] - 1; k >= 0; --k )
                 p->freeList.push_back( { (float)i / (float)p->slots[0],
                                          (float)j / (float)p->slots[1],
-                                         (float)k / (float)p->slots[2] } );
+                                         (float)k / (float)p->slots[2], 0.0f } );
 
     e = hipMalloc( &p->dAtlas, p->atlasBytes );
     if( e == hipSuccess ) e = hipMemset( p->dAtlas, 0, p->atlasBytes );
@@ -395,12 +403,15 @@ void vrc_pool_destroy( vrc_pool* p )
         if( p->staging[s].done ) (void)hipEventDestroy( p->staging[s].done );
     }
     if( p->lastUpload ) (void)hipEventDestroy( p->lastUpload );
+    for( auto& f : p->renderFences )
+        (void)hipEventDestroy( f.event );
     if( p->uploadStream ) (void)hipStreamDestroy( p->uploadStream );
     if( p->dAtlas ) (void)hipFree( p->dAtlas );
     delete p;
 }
 
-static int pool_take_slot( vrc_pool* p, float slot[3] )
+/* fences: the render events a reused slot's upload has to wait for (empty for a fresh slot) */
+static int pool_take_slot( vrc_pool* p, float slot[3], std::vector< hipEvent_t >& fences )
 {
     std::lock_guard< std::mutex > lock( p->mutex );
     if( p->freeList.empty() )
@@ -413,6 +424,9 @@ static int pool_take_slot( vrc_pool* p, float slot[3] )
     slot[0] = s[0];
     slot[1] = s[1];
     slot[2] = s[2];
+    if( s[3] != 0.0f )
+        for( const auto& f : p->renderFences )
+            fences.push_back( f.event );
     return VRC_OK;
 }
 
@@ -442,7 +456,8 @@ static int pool_upload( vrc_pool* p, const void* src, bool srcIsDevice, const ui
         return rc;
     VRC_HIP_CHECK( hipSetDevice( p->device ) );
     float slot[3];
-    rc = pool_take_slot( p, slot );
+    std::vector< hipEvent_t > fences;
+    rc = pool_take_slot( p, slot, fences );
     if( rc != VRC_OK )
         return rc;
     uint32_t o[3];
@@ -460,6 +475,11 @@ static int pool_upload( vrc_pool* p, const void* src, bool srcIsDevice, const ui
         std::lock_guard< std::mutex > slock( st.mutex );
         if( st.used )
             e = hipEventSynchronize( st.done ); /* staging buffers free again */
+        /* a slot that was released may still be read by a march in flight (the texture cache
+         * drops an object as soon as the host is done with it): order the overwrite after the
+         * last march of every context that rendered from this pool */
+        for( size_t i = 0; i < fences.size() && e == hipSuccess; ++i )
+            e = hipStreamWaitEvent( p->uploadStream, fences[i], 0 );
         const void* devSrc = src;
         if( e == hipSuccess && !srcIsDevice )
         {
@@ -529,7 +549,7 @@ int vrc_pool_release_slot( vrc_pool* p, const float slot[3] )
     if( slot[0] < 0.f || slot[1] < 0.f || slot[2] < 0.f )
         return fail( VRC_EINVAL, "vrc_pool_release_slot: invalid slot" );
     std::lock_guard< std::mutex > lock( p->mutex );
-    p->freeList.push_back( { slot[0], slot[1], slot[2] } );
+    p->freeList.push_back( { slot[0], slot[1], slot[2], 1.0f } );
     return VRC_OK;
 }
 
@@ -943,6 +963,20 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     VRC_HIP_CHECK( hipEventRecord( evp.first, c->stream ) );
     VRC_HIP_CHECK( useLds ? vrc_launch_raycast_lds( a, c->stream ) : vrc_launch_raycast( a, c->stream ) );
     VRC_HIP_CHECK( hipEventRecord( evp.second, c->stream ) );
+    {
+        /* render fence of this context on the pool (see pool_upload) */
+        std::lock_guard< std::mutex > lock( pool->mutex );
+        hipEvent_t fence = nullptr;
+        for( const auto& f : pool->renderFences )
+            if( f.ctx == c )
+                fence = f.event;
+        if( !fence )
+        {
+            VRC_HIP_CHECK( hipEventCreateWithFlags( &fence, hipEventDisableTiming ) );
+            pool->renderFences.push_back( { c, fence } );
+        }
+        VRC_HIP_CHECK( hipEventRecord( fence, c->stream ) );
+    }
     if( c->optCount )
         VRC_HIP_CHECK( hipMemcpyAsync( c->hCounter, c->dCounter, sizeof( unsigned long long ),
                                        hipMemcpyDeviceToHost, c->stream ) );
