@@ -592,6 +592,10 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
         {
 #if defined( VRC_ABLATE_NO_FETCH ) /* timing experiment only */
             e[k] = lut[64u + ( idx[k] >> 31 )];
+#elif defined( VRC_ABLATE_HALF_FETCH ) /* timing experiment only: every other gather dropped */
+            e[k] = lut[(uint32_t)atlas[idx[k & ~1]] + ( idx[k] >> 31 )];
+#elif defined( VRC_ABLATE_QUARTER_FETCH ) /* timing experiment only */
+            e[k] = lut[(uint32_t)atlas[idx[k & ~3]] + ( idx[k] >> 31 )];
 #else
             e[k] = lut[(uint32_t)atlas[idx[k]]];
 #endif
