@@ -37,16 +37,27 @@ class TileGather:
         self.equal = len(set(self.counts)) == 1
         self.recv = None
         self.frame = None
+        # regular interleave (band b = rows [b*h, (b+1)*h) on rank b % world, all bands h rows):
+        # the frame is a permutation of the receive buffer, assembled by ONE strided copy
+        heights = {h for b in layout for _, h in b}
+        self.regular = (self.equal and len(heights) == 1 and all(
+            bands == [((k * self.world + r) * h, h) for k in range(len(bands))]
+            for r, bands in enumerate(layout) for h in heights))
         if rank == dst:
-            self.recv = [torch.empty((c, width, 4), dtype=torch.float32, device=device)
-                         for c in self.counts]
+            if self.equal:
+                self.recv_all = torch.empty((self.world, self.counts[0], width, 4), dtype=torch.float32,
+                                            device=device)
+                self.recv = [self.recv_all[r] for r in range(self.world)]
+            else:
+                self.recv = [torch.empty((c, width, 4), dtype=torch.float32, device=device)
+                             for c in self.counts]
             self.frame = torch.zeros((sum(self.counts), width, 4), dtype=torch.float32, device=device)
 
     def gather(self, local):
         """local: this rank's bands stacked, (rows, W, 4) float32.  Collective."""
         if self.world == 1:
             if self.rank == self.dst:
-                self.recv[0] = local
+                self.recv[0] = local  # no copy: the local frame is the frame
             return
         if self.equal:
             # equal tiles: one RCCL gather; each peer uses its own point-to-point xGMI link
@@ -62,6 +73,12 @@ class TileGather:
     def assemble(self):
         """Display rank only: place the received bands at their rows (the frame assembly)."""
         assert self.rank == self.dst
+        if self.regular and self.world > 1:
+            h = self.layout[0][0][1]
+            bpr = len(self.layout[0])
+            src = self.recv_all.view(self.world, bpr, h, self.width, 4).permute(1, 0, 2, 3, 4)
+            self.frame.view(bpr, self.world, h, self.width, 4).copy_(src)
+            return self.frame
         for r, bands in enumerate(self.layout):
             off = 0
             for (y0, h) in bands:

@@ -78,3 +78,19 @@ def test_band_layout_properties():
     assert all(len(b) == 4 and sum(h for _, h in b) == 128 for b in lay)
     # interleaving: every rank has a band in each quarter of the image
     assert [y0 // 256 for (y0, _) in lay[3]] == [0, 1, 2, 3]
+
+
+def test_assembly_of_regular_and_ragged_layouts_without_a_process_group():
+    # the display rank's placement of received bands: one strided copy for the regular
+    # interleave, band by band otherwise; both must put every frame row where it belongs
+    import torch
+    from libre_amd import sortfirst
+    for height, world, bpr in ((64, 4, 4), (1024, 8, 4), (50, 3, 4), (37, 2, 3)):
+        layout = sortfirst.band_layout(height, world, bpr)
+        tg = sortfirst.TileGather(layout, 8, 0, "cpu")
+        assert tg.regular == (height % (world * bpr) == 0)
+        for r, bands in enumerate(layout):
+            rows = torch.cat([torch.arange(y0, y0 + h) for (y0, h) in bands]).float()
+            tg.recv[r].copy_(rows[:, None, None].expand(-1, 8, 4))
+        frame = tg.assemble()
+        assert torch.equal(frame[:, 0, 0], torch.arange(height).float())
