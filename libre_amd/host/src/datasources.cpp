@@ -13,6 +13,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <vector>
 #include <sstream>
 
 #include "livre_hip/data.h"
@@ -304,9 +307,21 @@ private:
         std::shared_ptr< AllocMemoryUnit > mem( new AllocMemoryUnit( size_t( bs[0] ) * bs[1] * bs[2] * bpv ) );
         uint8_t* dst = mem->getData< uint8_t >();
         const uint8_t* src = static_cast< const uint8_t* >( _mmapPtr );
-        const uint32_t shift = _volumeInfo.rootNode.getDepth() - 1 - node.getRefLevel();
+        uint32_t shift = _volumeInfo.rootNode.getDepth() - 1 - node.getRefLevel();
         const Vector3ui o = node.getVoxelBox().getMin();
-        const int64_t vx = _volumeInfo.voxels[0], vy = _volumeInfo.voxels[1], vz = _volumeInfo.voxels[2];
+        int64_t vx = _volumeInfo.voxels[0], vy = _volumeInfo.voxels[1], vz = _volumeInfo.voxels[2];
+        /* coarse levels come from the in-memory pyramid (every 2^k-th voxel of the file, built
+         * level by level on first use: strided reads of the mapped file cost ~12 ms per coarse
+         * brick, a cut from the decimated copy as little as a finest-level one) */
+        if( shift > 0 )
+        {
+            const PyramidLevel& lvl = pyramidLevel( shift );
+            src = lvl.data.get();
+            vx = lvl.dim[0];
+            vy = lvl.dim[1];
+            vz = lvl.dim[2];
+            shift = 0;
+        }
         /* source x of every brick column, clamped at the volume border */
         std::vector< int64_t > sx( bs[0] );
         for( uint32_t x = 0; x < bs[0]; ++x )
@@ -358,10 +373,48 @@ private:
         else if( t == "float" ) _volumeInfo.dataType = DT_FLOAT;
         else throw std::runtime_error( "Not supported data format" );
     }
+    /* level k of the pyramid: voxel (x,y,z) = file voxel (x<<k, y<<k, z<<k) */
+    struct PyramidLevel
+    {
+        std::unique_ptr< uint8_t[] > data;
+        int64_t dim[3] = { 0, 0, 0 };
+    };
+    const PyramidLevel& pyramidLevel( uint32_t k ) const
+    {
+        std::lock_guard< std::mutex > lock( _pyramidMutex );
+        if( _pyramid.size() <= k )
+            _pyramid.resize( k + 1 );
+        for( uint32_t l = 1; l <= k; ++l )
+        {
+            if( _pyramid[l].data )
+                continue;
+            const size_t bpv = _volumeInfo.getBytesPerVoxel();
+            const uint8_t* prev = l == 1 ? static_cast< const uint8_t* >( _mmapPtr ) : _pyramid[l - 1].data.get();
+            int64_t pd[3];
+            for( int a = 0; a < 3; ++a )
+                pd[a] = l == 1 ? int64_t( _volumeInfo.voxels[a] ) : _pyramid[l - 1].dim[a];
+            PyramidLevel& lv = _pyramid[l];
+            for( int a = 0; a < 3; ++a )
+                lv.dim[a] = ( pd[a] + 1 ) / 2; /* voxels 0, 2, 4, ... of the level below */
+            lv.data.reset( new uint8_t[size_t( lv.dim[0] ) * lv.dim[1] * lv.dim[2] * bpv] );
+            for( int64_t z = 0; z < lv.dim[2]; ++z )
+                for( int64_t y = 0; y < lv.dim[1]; ++y )
+                {
+                    const uint8_t* row = prev + size_t( ( ( 2 * z ) * pd[1] + 2 * y ) * pd[0] ) * bpv;
+                    uint8_t* out = lv.data.get() + size_t( ( z * lv.dim[1] + y ) * lv.dim[0] ) * bpv;
+                    for( int64_t x = 0; x < lv.dim[0]; ++x )
+                        std::memcpy( out + x * bpv, row + size_t( 2 * x ) * bpv, bpv );
+                }
+        }
+        return _pyramid[k];
+    }
+
     void* _mmapPtr;
     int _fd;
     size_t _size;
     bool _bricked = false;
+    mutable std::mutex _pyramidMutex;
+    mutable std::vector< PyramidLevel > _pyramid;
 };
 
 namespace

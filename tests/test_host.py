@@ -157,17 +157,30 @@ def test_raw_data_source_bricked_out_of_core(drv, tmp_path, dtype):
         want = orc.brick_from_volume(vol, vi, orc.lod_node(vi, nid))
         got = drv.datasource_brick(uri, nid).view(vol.dtype).reshape(want.shape)
         assert (got == want).all()
-    # one level up: stride 2 in the full-resolution volume
+    # one level up: every second voxel of the full-resolution volume (served from the pyramid)
     depth = vi.depth
     nid = orc.pack(depth - 2, 0, 0, 0)
     node = orc.lod_node(vi, nid)
     ov = 4
     lo = [int(node.voxelBoxMin[a]) - ov for a in range(3)]
     hi = [int(node.voxelBoxMax[a]) + ov for a in range(3)]
-    ix = [np.clip(np.arange(lo[a], hi[a]) * 2, 0, vol.shape[2 - a] - 1) for a in range(3)]
+    # border replication happens in the level's own (decimated) voxel grid
+    ix = [np.clip(np.arange(lo[a], hi[a]), 0, (vol.shape[2 - a] + 1) // 2 - 1) * 2 for a in range(3)]
     want = vol[np.ix_(ix[2], ix[1], ix[0])]
     got = drv.datasource_brick(uri, nid).view(vol.dtype).reshape(want.shape)
     assert (got == want).all()
+    # two levels up (level 0 here is the root): built from the level above it
+    if depth >= 3:
+        nid = orc.pack(depth - 3, 0, 0, 0)
+        node = orc.lod_node(vi, nid)
+        lo = [int(node.voxelBoxMin[a]) - ov for a in range(3)]
+        hi = [int(node.voxelBoxMax[a]) + ov for a in range(3)]
+        d1 = [(vol.shape[2 - a] + 1) // 2 for a in range(3)]
+        d2 = [(d1[a] + 1) // 2 for a in range(3)]
+        ix = [np.clip(np.arange(lo[a], hi[a]), 0, d2[a] - 1) * 4 for a in range(3)]
+        want = vol[np.ix_(ix[2], ix[1], ix[0])]
+        got = drv.datasource_brick(uri, nid).view(vol.dtype).reshape(want.shape)
+        assert (got == want).all()
     # the four-parameter form stays the reference's single brick
     whole = drv.datasource_brick("raw://%s#48,32,64,%s" % (path, dtype), orc.pack(0, 0, 0, 0))
     assert (whole.view(vol.dtype) == vol.ravel()).all()
