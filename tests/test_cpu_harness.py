@@ -151,8 +151,16 @@ def test_sanitized_build_runs_clean():
         s = scenes.get("hash_clip")
         a, n, _ = orc.harness_render(s, kernel=2, sanitize=True)
         b, m, _ = orc.harness_render(s, kernel=1, sanitize=True)
+        for k in (4, 6, 8):  # fixed-point stepping, trilinear, per-sample classification
+            orc.harness_render(s, kernel=k, sanitize=True)
+        orc.harness_render(s, kernel=2, sanitize=True, variant=1)  # glRaycaster rules
         s = scenes.nucleon_scene(viewport=(24, 24))
-        orc.harness_render(s, kernel=2, sanitize=True)
+        for k in (2, 5, 6):  # clamped sampler, point and trilinear
+            orc.harness_render(s, kernel=k, sanitize=True)
+        s16 = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(24, 24), volume="hash",
+                              spin=(0.5, 0.35), dtype="u16")
+        for k in (5, 6, 7, 8):  # 16-bit voxels
+            orc.harness_render(s16, kernel=k, sanitize=True)
         print("OK", n, m)
     """ % os.path.dirname(os.path.abspath(__file__)))
     asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
