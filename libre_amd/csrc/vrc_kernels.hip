@@ -351,6 +351,20 @@ __global__ __launch_bounds__( VRC_WG, VRC_MIN_WAVES ) void vrc_k_raycast(
         lut[lane + i * VRC_WG] = lutGlobal[lane + i * VRC_WG];
     if( lane < VRC_TFP_ENTRIES - 256u )
         lut[256u + lane] = lutGlobal[256u + lane];
+#if defined( VRC_ADDR_TABLES )
+    if( FIXED )
+    {
+        const uint32_t cyy = f.sbx * VRC_MB_VOXELS - 64u, czz = f.sbx * f.sby * VRC_MB_VOXELS - 512u;
+#pragma unroll
+        for( uint32_t i = 0; i < 256u / VRC_WG; ++i )
+        {
+            const uint32_t u = lane + i * VRC_WG, q = u >> VRC_MB_SHIFT;
+            vrc_addr_tab[u] = u + 504u * q;
+            vrc_addr_tab[256u + u] = 8u * u + cyy * q;
+            vrc_addr_tab[512u + u] = 64u * u + czz * q;
+        }
+    }
+#endif
     __syncthreads();
 
     /* Workgroup -> tile.  Ray lengths vary by more than 2x over the image and whole tiles miss
