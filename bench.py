@@ -316,7 +316,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "u8 voxels, f32 compositing",
+            "dtype": "u8",
             "data": "synthetic (mem:// rule of datasources/memory/MemoryDataSource.cpp:54-57)",
             "config": {"workload": "C2: %s uint8, %dx%d viewport, leaves only (%d bricks of %d^3), "
                                    "%d samples/ray, linear-ramp TF alpha=%.3g, default camera"
@@ -331,7 +331,7 @@ def main():
                        "with_readback_to_pinned_host": readback},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "vrc_k_raycast<true,false,false,true>",
+                         "kernel": "vrc_k_raycast<true,false,false,true,0,unsigned char>",
                          "kernel_ms_per_frame": kernel_ms_per_frame,
                          "algorithmic_bytes_per_launch": per_rank_alg,
                          "algorithmic_bytes_per_frame_all_ranks": alg_bytes,
