@@ -585,7 +585,7 @@ VRC_HD void vrc_composite( vrc_f4& c, const vrc_f4& e, bool frozen = false )
 #define VRC_GROUP 8
 #endif
 
-template < bool CLAMP, bool COUNT, bool FIXED, typename ATLAS_T >
+template < bool CLAMP, bool COUNT, bool FIXED, typename ATLAS_T, int GROUP = VRC_GROUP >
 VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_segment s,
                                const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
                                vrc_f4& color, uint32_t& nSamples )
@@ -601,23 +601,23 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
     if( FIXED )
         fp = vrc_fixpos_init( sm, pos, s.step );
 
-    /* all VRC_GROUP samples of a group are reached by the reference loop if more than
-     * VRC_GROUP steps remain (the sequentially rounded travel differs from the exact one by
+    /* all GROUP samples of a group are reached by the reference loop if more than
+     * GROUP steps remain (the sequentially rounded travel differs from the exact one by
      * far less than one step) */
-    const float guard = stepSize * (float)( VRC_GROUP + 1 );
+    const float guard = stepSize * (float)( GROUP + 1 );
     while( travel > guard )
     {
-        uint32_t idx[VRC_GROUP];
+        uint32_t idx[GROUP];
         if( FIXED )
-            vrc_group_indices_fixed< VRC_GROUP >( sm, fp, idx );
+            vrc_group_indices_fixed< GROUP >( sm, fp, idx );
         else
-            vrc_group_indices< CLAMP, VRC_GROUP >( sm, pos, s.step, idx );
+            vrc_group_indices< CLAMP, GROUP >( sm, pos, s.step, idx );
 #pragma unroll
-        for( int k = 0; k < VRC_GROUP; ++k )
+        for( int k = 0; k < GROUP; ++k )
             travel -= stepSize; /* same sequential subtraction as the reference */
-        vrc_f4 e[VRC_GROUP];
+        vrc_f4 e[GROUP];
 #pragma unroll
-        for( int k = 0; k < VRC_GROUP; ++k )
+        for( int k = 0; k < GROUP; ++k )
         {
 #if defined( VRC_ABLATE_NO_FETCH ) /* timing experiment only */
             e[k] = lut[64u + ( idx[k] >> 31 )];
@@ -631,18 +631,18 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
         }
         const vrc_f4 saved = color;
 #pragma unroll
-        for( int k = 0; k < VRC_GROUP; ++k )
+        for( int k = 0; k < GROUP; ++k )
             vrc_composite( color, e[k] );
         if( COUNT )
-            nSamples += VRC_GROUP;
+            nSamples += GROUP;
         if( color.w > VRC_EARLY_EXIT )
         {
             /* crossed inside this group: replay it with the reference's per-sample exit */
             color = saved;
             if( COUNT )
-                nSamples -= VRC_GROUP;
+                nSamples -= GROUP;
 #pragma unroll
-            for( int k = 0; k < VRC_GROUP; ++k )
+            for( int k = 0; k < GROUP; ++k )
             {
                 vrc_composite( color, e[k], done );
                 if( COUNT )
@@ -656,13 +656,13 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
     /* tail: general form */
     while( travel > 0.0f && !done )
     {
-        uint32_t idx[VRC_GROUP], d[VRC_GROUP], cnt = 0;
+        uint32_t idx[GROUP], d[GROUP], cnt = 0;
         if( FIXED )
-            vrc_group_indices_fixed< VRC_GROUP >( sm, fp, idx );
+            vrc_group_indices_fixed< GROUP >( sm, fp, idx );
         else
-            vrc_group_indices< CLAMP, VRC_GROUP >( sm, pos, s.step, idx );
+            vrc_group_indices< CLAMP, GROUP >( sm, pos, s.step, idx );
 #pragma unroll
-        for( int k = 0; k < VRC_GROUP; ++k )
+        for( int k = 0; k < GROUP; ++k )
         {
             const bool v = travel > 0.0f;
             cnt += v ? 1u : 0u;
@@ -670,14 +670,14 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
             travel -= stepSize;
         }
 #pragma unroll
-        for( int k = 0; k < VRC_GROUP; ++k )
+        for( int k = 0; k < GROUP; ++k )
             d[k] = (uint32_t)atlas[idx[k]];
-        vrc_f4 e[VRC_GROUP];
+        vrc_f4 e[GROUP];
 #pragma unroll
-        for( int k = 0; k < VRC_GROUP; ++k )
+        for( int k = 0; k < GROUP; ++k )
             e[k] = lut[(uint32_t)k < cnt ? d[k] : 256u];
 #pragma unroll
-        for( int k = 0; k < VRC_GROUP; ++k )
+        for( int k = 0; k < GROUP; ++k )
         {
             const bool active = ( (uint32_t)k < cnt ) && !done;
             vrc_composite( color, e[k], done );
@@ -901,7 +901,7 @@ VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n,
 #define VRC_MODE_TRILINEAR 1
 #define VRC_MODE_POINT 2
 
-template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T >
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP >
 VRC_HD bool vrc_march_brick( const vrc_frame& f, const vrc_dev_node& n, const vrc_segment& s,
                              const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
                              const vrc_classifier& cls, vrc_f4& color, uint32_t& nSamples )
@@ -909,10 +909,10 @@ VRC_HD bool vrc_march_brick( const vrc_frame& f, const vrc_dev_node& n, const vr
     if( MODE != VRC_MODE_TABLE )
         return vrc_march_segment_linear< CLAMP, COUNT, MODE == VRC_MODE_TRILINEAR, ATLAS_T >(
             f, n, s, atlas, lut, cls, color, nSamples );
-    return vrc_march_segment< CLAMP, COUNT, FIXED, ATLAS_T >( f, n, s, atlas, lut, color, nSamples );
+    return vrc_march_segment< CLAMP, COUNT, FIXED, ATLAS_T, GROUP >( f, n, s, atlas, lut, color, nSamples );
 }
 
-template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T >
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP >
 VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
                                        const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
                                        const vrc_classifier& cls,
@@ -937,7 +937,7 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
                 break;
             continue;
         }
-        if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T >( f, n, s, atlas, lut, cls, color,
+        if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP >( f, n, s, atlas, lut, cls, color,
                                                                      nSamples ) )
             break;
     }
@@ -950,7 +950,7 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
  * For a regular single-LOD grid the along-ray order equals the reference's host order for
  * every pair of bricks that share a ray ("brick order").
  * ---------------------------------------------------------------------------------------- */
-template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T >
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP >
 VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
                                 const int32_t* __restrict__ gridTable,
                                 const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
@@ -1009,7 +1009,7 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
                 bool stop;
                 if( vrc_brick_segment( f, r, n, f.stepSize, &s, &stop ) )
                 {
-                    if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T >( f, n, s, atlas, lut,
+                    if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP >( f, n, s, atlas, lut,
                                                                                  cls, color, nSamples ) )
                         break;
                 }

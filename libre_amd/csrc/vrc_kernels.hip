@@ -334,8 +334,12 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t*
 #ifndef VRC_MIN_WAVES
 #define VRC_MIN_WAVES 4
 #endif
-template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T >
-__global__ __launch_bounds__( VRC_WG, VRC_MIN_WAVES ) void vrc_k_raycast(
+/* GROUP: samples a lane keeps in flight.  8 is fastest when the launch fills the machine several
+ * times over (4 waves per SIMD); 16 (2 waves per SIMD) halves the dependent round trips of a ray
+ * and wins when a launch is no more than about one wave per SIMD slot and the longest ray's
+ * latency sets the time -- the per-rank share of a sort-first frame from 4 ranks up. */
+template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP >
+__global__ __launch_bounds__( VRC_WG, GROUP > 8 ? 2 : VRC_MIN_WAVES ) void vrc_k_raycast(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ gridTable, const ATLAS_T* __restrict__ atlas,
     const vrc_f4* __restrict__ lutGlobal, const vrc_classifier cls,
@@ -390,10 +394,10 @@ __global__ __launch_bounds__( VRC_WG, VRC_MIN_WAVES ) void vrc_k_raycast(
     if( px < f.width && py < f.height )
     {
         if( DDA )
-            vrc_pixel_grid_dda< CLAMP, COUNT, FIXED, MODE, ATLAS_T >(
+            vrc_pixel_grid_dda< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP >(
                 f, nodes, gridTable, atlas, lut, cls, pixelBuffer, px, py, nSamples );
         else
-            vrc_pixel_reference_order< CLAMP, COUNT, FIXED, MODE, ATLAS_T >(
+            vrc_pixel_reference_order< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP >(
                 f, nodes, atlas, lut, cls, pixelBuffer, px, py, nSamples );
     }
     if( COUNT )
@@ -408,7 +412,7 @@ __global__ __launch_bounds__( VRC_WG, VRC_MIN_WAVES ) void vrc_k_raycast(
     }
 }
 
-template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T >
+template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP >
 static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream )
 {
     const uint32_t tilesX = ( a.frame.width + VRC_TILE_W - 1 ) / VRC_TILE_W;
@@ -416,7 +420,7 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
     const uint32_t nTiles = tilesX * tilesY;
     if( nTiles == 0 )
         return hipSuccess;
-    hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, MODE, ATLAS_T > ), dim3( nTiles ),
+    hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP > ), dim3( nTiles ),
                         dim3( VRC_WG ), 0, stream, a.frame, a.nodes, a.gridTable,
                         (const ATLAS_T*)a.atlas, a.lut, a.classifier, a.pixelBuffer,
                         a.sampleCounter, a.tileOrder, tilesX, nTiles );
@@ -454,6 +458,11 @@ hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
     /* the clamped sampler (overlap 0) always uses the float position chain */
     const bool fixed = a.fixedStepping && !a.clamp;
     const int key = ( fixed ? 8 : 0 ) | ( a.gridDda ? 4 : 0 ) | ( a.clamp ? 2 : 0 ) | ( count ? 1 : 0 );
+    /* launches of at most ~1.5 waves per SIMD slot (256 CUs x 4 SIMDs x 4 waves) are latency-bound:
+     * measured 0.153 -> 0.130 ms for an eighth of the C2 frame, 0.538 -> 0.562 ms for the whole */
+    const uint32_t nTilesLaunch = ( ( a.frame.width + VRC_TILE_W - 1 ) / VRC_TILE_W ) *
+                                  ( ( a.frame.height + VRC_TILE_H - 1 ) / VRC_TILE_H );
+    const bool smallLaunch = nTilesLaunch <= 6144u;
     switch( key )
     {
     case 0: return launch_variant< false, false, false, false, VRC_MODE_TABLE, uint8_t >( a, stream );
@@ -466,7 +475,13 @@ hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
     case 7: return launch_variant< true, true, true, false, VRC_MODE_TABLE, uint8_t >( a, stream );
     case 8: return launch_variant< false, false, false, true, VRC_MODE_TABLE, uint8_t >( a, stream );
     case 9: return launch_variant< false, false, true, true, VRC_MODE_TABLE, uint8_t >( a, stream );
-    case 12: return launch_variant< true, false, false, true, VRC_MODE_TABLE, uint8_t >( a, stream );
-    default: return launch_variant< true, false, true, true, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 12:
+        if( smallLaunch )
+            return launch_variant< true, false, false, true, VRC_MODE_TABLE, uint8_t, 16 >( a, stream );
+        return launch_variant< true, false, false, true, VRC_MODE_TABLE, uint8_t >( a, stream );
+    default:
+        if( smallLaunch )
+            return launch_variant< true, false, true, true, VRC_MODE_TABLE, uint8_t, 16 >( a, stream );
+        return launch_variant< true, false, true, true, VRC_MODE_TABLE, uint8_t >( a, stream );
     }
 }

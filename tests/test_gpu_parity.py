@@ -192,6 +192,19 @@ def test_trilinear_nucleon_clamped(vrc):
     assert n_got == n_want
 
 
+def test_large_launch_uses_groups_of_eight_and_matches_small_launch_rules(vrc):
+    # launches above ~6144 tiles march in groups of 8 samples, smaller ones in groups of 16
+    # (vrc_launch_raycast); both must reproduce the oracle, sample for sample
+    s = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(1024, 512), volume="hash", spin=(0.5, 0.35),
+                        alpha=0.3)
+    want, n_want = orc.oracle_render(s, threads=16)
+    with _gpu(s) as g:
+        got, n_got, st = g.render()
+        assert st.kernel_variant == vrc.KERNEL_GRID_DDA
+    scenes.assert_parity(got, want, "8192-tile launch")
+    assert abs(n_got - n_want) <= 2e-4 * n_want + 8
+
+
 def test_c1_config_parity(vrc):
     # mem://#128,128,128,32, 512^2 viewport, 512 samples/ray, 64 leaf bricks
     s = orc.build_scene(voxels=(128, 128, 128), block=32, viewport=(512, 512))
