@@ -98,6 +98,14 @@ int lvh_selftest_camera( float out_matrices[4][16] );
 int lvh_datasource_brick( const char* volume_uri, uint64_t node_id, uint8_t* out, size_t capacity,
                           size_t* n );
 
+/* data-source metadata without a renderer (no GPU): VolumeInformation and one LODNode.
+ * data_type is the DataType enum of livre/core/data/VolumeInformation.h (DT_UINT8 = 1 ...). */
+int lvh_datasource_info( const char* volume_uri, uint32_t voxels[3], uint32_t max_block[3],
+                         uint32_t overlap[3], float world_size[3], uint32_t* depth,
+                         uint32_t root_blocks[3], uint32_t* data_type, uint32_t* comp_count );
+int lvh_datasource_node( const char* volume_uri, uint64_t node_id, int* valid, uint32_t block_size[3],
+                         uint32_t voxel_box[6], float world_box[6] );
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,7 +30,7 @@ EXPORTS = [
     "lvh_app_get_stats", "lvh_app_wait_uploads", "lvh_app_synchronize", "lvh_app_volume_info",
     "lvh_app_visible_set", "lvh_app_view_matrices", "lvh_app_cache_stats", "lvh_select_visibles",
     "lvh_selftest_cache", "lvh_selftest_plugin_factory", "lvh_selftest_camera",
-    "lvh_datasource_brick",
+    "lvh_datasource_brick", "lvh_datasource_info", "lvh_datasource_node",
 ]
 
 _lib = None
@@ -73,6 +73,9 @@ def load_library():
                                       C.c_size_t, C.POINTER(C.c_size_t)]
     L.lvh_selftest_camera.argtypes = [(C.c_float * 16) * 4]
     L.lvh_datasource_brick.argtypes = [C.c_char_p, C.c_uint64, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    u3, f3 = C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+    L.lvh_datasource_info.argtypes = [C.c_char_p, u3, u3, u3, f3, u3, u3, u3, u3]
+    L.lvh_datasource_node.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_int), u3, u3, f3]
     _lib = L
     return L
 
@@ -208,6 +211,23 @@ def select_visibles(volume_uri, mv, proj, window_height, sse, min_lod, max_lod):
     check(L, L.lvh_select_visibles(volume_uri.encode(), m, p, window_height, sse, min_lod, max_lod,
                                    ids, n.value, C.byref(n)))
     return list(ids)[:n.value]
+
+
+def datasource_info(volume_uri):
+    L = load_library()
+    v, mb, ov, rb = (C.c_uint32 * 3)(), (C.c_uint32 * 3)(), (C.c_uint32 * 3)(), (C.c_uint32 * 3)()
+    ws, depth, dt, cc = (C.c_float * 3)(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    check(L, L.lvh_datasource_info(volume_uri.encode(), v, mb, ov, ws, C.byref(depth), rb, C.byref(dt),
+                                   C.byref(cc)))
+    return dict(voxels=list(v), max_block=list(mb), overlap=list(ov), world_size=list(ws), depth=depth.value,
+                root_blocks=list(rb), data_type=dt.value, comp_count=cc.value)
+
+
+def datasource_node(volume_uri, node_id):
+    L = load_library()
+    valid, bs, vb, wb = C.c_int(), (C.c_uint32 * 3)(), (C.c_uint32 * 6)(), (C.c_float * 6)()
+    check(L, L.lvh_datasource_node(volume_uri.encode(), C.c_uint64(node_id), C.byref(valid), bs, vb, wb))
+    return dict(valid=bool(valid.value), block_size=list(bs), voxel_box=list(vb), world_box=list(wb))
 
 
 def datasource_brick(volume_uri, node_id):

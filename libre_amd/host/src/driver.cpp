@@ -521,4 +521,61 @@ int lvh_datasource_brick( const char* uri, uint64_t nodeId, uint8_t* out, size_t
         return fail( e.what() );
     }
 }
+
+int lvh_datasource_info( const char* uri, uint32_t voxels[3], uint32_t maxBlock[3], uint32_t overlap[3],
+                         float worldSize[3], uint32_t* depth, uint32_t rootBlocks[3], uint32_t* dataType,
+                         uint32_t* compCount )
+{
+    try
+    {
+        DataSource dataSource{ std::string( uri ) };
+        const VolumeInformation& vi = dataSource.getVolumeInfo();
+        for( int a = 0; a < 3; ++a )
+        {
+            if( voxels ) voxels[a] = vi.voxels[a];
+            if( maxBlock ) maxBlock[a] = vi.maximumBlockSize[a];
+            if( overlap ) overlap[a] = vi.overlap[a];
+            if( worldSize ) worldSize[a] = vi.worldSize[a];
+            if( rootBlocks ) rootBlocks[a] = vi.rootNode.getBlockSize()[a];
+        }
+        if( depth ) *depth = vi.rootNode.getDepth();
+        if( dataType ) *dataType = uint32_t( vi.dataType );
+        if( compCount ) *compCount = vi.compCount;
+        return 0;
+    }
+    catch( const std::exception& e )
+    {
+        return fail( e.what() );
+    }
+}
+
+int lvh_datasource_node( const char* uri, uint64_t nodeId, int* valid, uint32_t blockSize[3],
+                         uint32_t voxelBox[6], float worldBox[6] )
+{
+    try
+    {
+        DataSource dataSource{ std::string( uri ) };
+        const LODNode node = dataSource.getNode( NodeId( nodeId ) );
+        if( valid ) *valid = node.isValid() ? 1 : 0;
+        for( int a = 0; a < 3; ++a )
+        {
+            if( blockSize ) blockSize[a] = node.getBlockSize()[a];
+            if( voxelBox )
+            {
+                voxelBox[a] = node.getVoxelBox().getMin()[a];
+                voxelBox[3 + a] = node.getVoxelBox().getMax()[a];
+            }
+            if( worldBox )
+            {
+                worldBox[a] = node.getWorldBox().getMin()[a];
+                worldBox[3 + a] = node.getWorldBox().getMax()[a];
+            }
+        }
+        return 0;
+    }
+    catch( const std::exception& e )
+    {
+        return fail( e.what() );
+    }
+}
 }

@@ -1,0 +1,296 @@
+/*
+ * uvf:// data source: the Livre side of datasources/uvf/UVFDataSource.cpp:62-381 without Tuvok.
+ *
+ * The reference reads UVF files through the Tuvok library (tuvok::UVFDataset, TOCBlock,
+ * ExtendedOctree), which is an un-vendored git subproject: the container format below is
+ * restated from the file the reference's own test ships (tests/uvf/mouse_reduced.uvf) and from
+ * what UVFDataSource.cpp does with Tuvok's answers.  What is pinned: every value the reference
+ * test checks (tests/uvf/uvf.cpp:42-71: tree depth, component count, data type, voxels, overlap,
+ * block sizes, brick byte size); brick payloads were cross-checked by reassembling the volume
+ * (neighbouring bricks agree on their shared overlap voxels).  What is NOT pinned: the brick
+ * world boxes (Tuvok's ComputeMetaData) -- here a brick's box is its voxel range as a fraction of
+ * its level's domain, mapped onto the world size, the convention of DataSourcePlugin.cpp:55-81.
+ *
+ * Container, little endian (the flag is read; big-endian files are refused):
+ *   "UVF-DATA" | u8 bigEndian | u64 version | u64 checksumSemantics | u64 checksumLength |
+ *   checksum bytes | u64 offsetToFirstBlock
+ *   data block header: u64 idLength | id chars | u64 semantics | u64 compression | u64 offsetToNext
+ *   TOC block (semantics 9), ExtendedOctree header, 105 bytes:
+ *     u32 componentType | u64 componentCount | u8 precomputedNormals | 3 x u64 volumeSize |
+ *     3 x f64 aspect | 3 x u64 maxBrickSize | u32 overlap | u32 version | u64 dataSize | u32 ?
+ *   then one 36-byte entry per brick { u64 offset | u64 length | u32 compression (0 none,
+ *   1 zlib) | u64 uncompressedLength | u64 ? }, LOD 0 (full resolution) first, x fastest inside
+ *   a LOD; offsets are relative to the end of the data block header.  LOD l+1 halves LOD l
+ *   rounding up, until the volume is one voxel; a LOD's bricks cover (maxBrickSize - 2 overlap)
+ *   voxels each plus the overlap; voxels outside the volume are 0.
+ */
+#include "livre_hip/data.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+namespace livre
+{
+namespace
+{
+const uint64_t BS_TOC_BLOCK = 9; /* tuvok UVFTables::BS_TOC_BLOCK */
+
+struct Reader
+{
+    const uint8_t* p;
+    size_t size, pos;
+    template < typename T > T get()
+    {
+        if( pos + sizeof( T ) > size )
+            throw std::runtime_error( "UVF data format initialization failed" );
+        T v;
+        std::memcpy( &v, p + pos, sizeof( T ) );
+        pos += sizeof( T );
+        return v;
+    }
+    void skip( size_t n )
+    {
+        if( pos + n > size )
+            throw std::runtime_error( "UVF data format initialization failed" );
+        pos += n;
+    }
+};
+
+struct TocEntry
+{
+    uint64_t offset, length, uncompressed;
+    uint32_t compression;
+};
+}
+
+class UVFDataSource : public DataSourcePlugin
+{
+public:
+    explicit UVFDataSource( const DataSourcePluginData& initData ) : _map( nullptr ), _fd( -1 ), _size( 0 ), _offset( 0 )
+    {
+        const std::string& path = initData.getURI().getPath();
+        _fd = ::open( path.c_str(), O_RDONLY );
+        struct stat sb;
+        if( _fd == -1 || ::fstat( _fd, &sb ) == -1 )
+            throw std::runtime_error( "UVF data format initialization failed" );
+        _size = size_t( sb.st_size );
+        _map = ::mmap( nullptr, _size, PROT_READ, MAP_PRIVATE, _fd, 0 );
+        if( _map == MAP_FAILED )
+        {
+            _map = nullptr;
+            ::close( _fd );
+            throw std::runtime_error( "UVF data format initialization failed" );
+        }
+        try
+        {
+            parse();
+        }
+        catch( ... )
+        {
+            ::munmap( _map, _size );
+            ::close( _fd );
+            throw;
+        }
+    }
+    ~UVFDataSource()
+    {
+        if( _map ) ::munmap( _map, _size );
+        if( _fd != -1 ) ::close( _fd );
+    }
+    static bool handles( const DataSourcePluginData& d ) { return d.getURI().getScheme() == "uvf"; }
+    bool nodeLookupIsCheap() const final { return true; }
+
+    /* UVFDataSource.cpp:304-355 */
+    LODNode internalNodeToLODNode( const NodeId& internalNode ) const final
+    {
+        const uint32_t lod = treeLevelToTuvokLevel( internalNode.getLevel() );
+        if( lod >= _lodSize.size() )
+            return LODNode();
+        const Vector3ui layout = brickLayout( lod );
+        const Vector3ui pos = internalNode.getPosition();
+        if( pos[0] >= layout[0] || pos[1] >= layout[1] || pos[2] >= layout[2] )
+            return LODNode(); /* "UVF format is not a perfect octree but ... a subset" */
+        const Vector3ui inner = _volumeInfo.maximumBlockSize - _volumeInfo.overlap * 2u;
+        Vector3ui blockSize;
+        Vector3f boxMin, boxMax;
+        for( int a = 0; a < 3; ++a )
+        {
+            const uint32_t begin = pos[a] * inner[a];
+            blockSize[a] = std::min( inner[a], _lodSize[lod][a] - begin );
+            /* the level's domain covers the world size of the volume, whatever the rounding */
+            const float w = _volumeInfo.worldSize[a];
+            boxMin[a] = float( begin ) / float( _lodSize[lod][a] ) * w - w * 0.5f;
+            boxMax[a] = float( begin + blockSize[a] ) / float( _lodSize[lod][a] ) * w - w * 0.5f;
+        }
+        return LODNode( internalNode, blockSize, Boxf( boxMin, boxMax ) );
+    }
+
+    /* UVFDataSource.cpp:204-301 */
+    MemoryUnitPtr getData( const LODNode& node ) final
+    {
+        const uint32_t lod = treeLevelToTuvokLevel( node.getRefLevel() );
+        const Vector3ui layout = brickLayout( lod );
+        const Vector3ui pos = node.getAbsolutePosition();
+        const size_t index = _lodFirstEntry[lod] + pos[0] + size_t( pos[1] ) * layout[0] +
+                             size_t( pos[2] ) * layout[0] * layout[1];
+        if( index >= _toc.size() )
+            throw std::runtime_error( "UVF: brick index outside the table of contents" );
+        const TocEntry& e = _toc[index];
+        const Vector3ui dims = node.getBlockSize() + _volumeInfo.overlap * 2u;
+        const size_t bytes = size_t( dims[0] ) * dims[1] * dims[2] * _volumeInfo.compCount *
+                             _volumeInfo.getBytesPerVoxel();
+        if( _offset + e.offset + e.length > _size )
+            throw std::runtime_error( "UVF: brick outside the file" );
+        const uint8_t* src = static_cast< const uint8_t* >( _map ) + _offset + e.offset;
+        if( e.compression == 0 ) /* CT_NONE: the mapped file is the brick */
+            return MemoryUnitPtr( new ConstMemoryUnit( src, size_t( e.length ) ) );
+        if( e.compression != 1 ) /* CT_ZLIB is the only codec the reference decodes (:274-287) */
+            throw std::runtime_error( "UVF: unsupported brick compression" );
+        std::shared_ptr< AllocMemoryUnit > mem( new AllocMemoryUnit( bytes ) );
+        uLongf outLen = uLongf( bytes );
+        if( ::uncompress( mem->getData< Bytef >(), &outLen, src, uLong( e.length ) ) != Z_OK || outLen != bytes )
+            throw std::runtime_error( "UVF: brick does not inflate to its size" );
+        return mem;
+    }
+
+private:
+    uint32_t treeLevelToTuvokLevel( uint32_t treeLevel ) const
+    {
+        return _volumeInfo.rootNode.getDepth() - treeLevel - 1;
+    }
+    Vector3ui brickLayout( uint32_t lod ) const
+    {
+        const Vector3ui inner = _volumeInfo.maximumBlockSize - _volumeInfo.overlap * 2u;
+        return Vector3ui( ( _lodSize[lod][0] + inner[0] - 1 ) / inner[0],
+                          ( _lodSize[lod][1] + inner[1] - 1 ) / inner[1],
+                          ( _lodSize[lod][2] + inner[2] - 1 ) / inner[2] );
+    }
+
+    void parse()
+    {
+        Reader r{ static_cast< const uint8_t* >( _map ), _size, 0 };
+        if( _size < 8 || std::memcmp( r.p, "UVF-DATA", 8 ) != 0 )
+            throw std::runtime_error( "UVF data format initialization failed" );
+        r.pos = 8;
+        _volumeInfo.bigEndian = r.get< uint8_t >() != 0;
+        if( _volumeInfo.bigEndian )
+            throw std::runtime_error( "UVF data format initialization failed" );
+        r.get< uint64_t >(); /* version */
+        r.get< uint64_t >(); /* checksum semantics */
+        const uint64_t checksumLength = r.get< uint64_t >();
+        r.skip( size_t( checksumLength ) );
+        r.get< uint64_t >(); /* offset to the first data block */
+
+        /* walk the chain of data blocks to the table of contents (UVFDataSource.cpp:152-165) */
+        for( ;; )
+        {
+            const size_t blockStart = r.pos;
+            const uint64_t idLength = r.get< uint64_t >();
+            r.skip( size_t( idLength ) );
+            const uint64_t semantics = r.get< uint64_t >();
+            r.get< uint64_t >(); /* block compression scheme */
+            const uint64_t next = r.get< uint64_t >();
+            if( semantics == BS_TOC_BLOCK )
+                break;
+            if( next == 0 )
+                throw std::runtime_error( "UVF TOC block not found in data set" );
+            r.pos = blockStart + size_t( next );
+        }
+        _offset = r.pos; /* brick offsets count from here (:167-190) */
+
+        const uint32_t componentType = r.get< uint32_t >();
+        _volumeInfo.compCount = uint32_t( r.get< uint64_t >() );
+        r.get< uint8_t >(); /* precomputed normals */
+        uint64_t domain[3], maxBrick[3];
+        for( int a = 0; a < 3; ++a ) domain[a] = r.get< uint64_t >();
+        for( int a = 0; a < 3; ++a ) r.get< double >(); /* aspect: isotropic scale is assumed */
+        for( int a = 0; a < 3; ++a ) maxBrick[a] = r.get< uint64_t >();
+        const uint32_t overlap = r.get< uint32_t >();
+        r.get< uint32_t >(); /* octree version */
+        r.get< uint64_t >(); /* payload size */
+        r.get< uint32_t >();
+
+        /* tuvok ExtendedOctree::COMPONENT_TYPE */
+        switch( componentType )
+        {
+        case 0: _volumeInfo.dataType = DT_UINT8; break;
+        case 1: _volumeInfo.dataType = DT_UINT16; break;
+        case 2: _volumeInfo.dataType = DT_UINT32; break;
+        case 4: _volumeInfo.dataType = DT_INT8; break;
+        case 5: _volumeInfo.dataType = DT_INT16; break;
+        case 6: _volumeInfo.dataType = DT_INT32; break;
+        case 8: _volumeInfo.dataType = DT_FLOAT; break;
+        default: throw std::runtime_error( "Livre doesn't suppport double data type." ); /* :101 */
+        }
+        for( int a = 0; a < 3; ++a )
+            if( domain[a] == 0 || maxBrick[a] <= 2u * overlap || domain[a] > 0xFFFFFFFFull )
+                throw std::runtime_error( "UVF data format initialization failed" );
+        _volumeInfo.voxels = Vector3ui( uint32_t( domain[0] ), uint32_t( domain[1] ), uint32_t( domain[2] ) );
+        _volumeInfo.maximumBlockSize = Vector3ui( uint32_t( maxBrick[0] ), uint32_t( maxBrick[1] ), uint32_t( maxBrick[2] ) );
+        _volumeInfo.overlap = Vector3ui( overlap );
+        const float maxDomain = float( _volumeInfo.voxels.find_max() );
+        _volumeInfo.worldSpacePerVoxel = 1.0f / maxDomain;
+        _volumeInfo.worldSize = Vector3f( float( domain[0] ), float( domain[1] ), float( domain[2] ) ) / maxDomain;
+        _volumeInfo.frameRange = Vector2ui( 0u, 1u );
+
+        /* LOD pyramid: halve, rounding up, down to one voxel */
+        Vector3ui s = _volumeInfo.voxels;
+        for( ;; )
+        {
+            _lodSize.push_back( s );
+            if( s[0] == 1 && s[1] == 1 && s[2] == 1 )
+                break;
+            s = Vector3ui( ( s[0] + 1 ) / 2, ( s[1] + 1 ) / 2, ( s[2] + 1 ) / 2 );
+        }
+        size_t nBricks = 0;
+        for( uint32_t l = 0; l < _lodSize.size(); ++l )
+        {
+            _lodFirstEntry.push_back( nBricks );
+            const Vector3ui layout = brickLayout( l );
+            nBricks += size_t( layout[0] ) * layout[1] * layout[2];
+        }
+        _toc.resize( nBricks );
+        for( TocEntry& e : _toc )
+        {
+            e.offset = r.get< uint64_t >();
+            e.length = r.get< uint64_t >();
+            e.compression = r.get< uint32_t >();
+            e.uncompressed = r.get< uint64_t >();
+            r.get< uint64_t >();
+        }
+
+        /* UVFDataSource.cpp:77-92: the tree is as deep as the LODs whose brick layout is still
+         * more than one brick in every direction, plus the one above */
+        uint32_t depth = 0;
+        Vector3ui layout;
+        do
+        {
+            ++depth;
+            if( depth >= _lodSize.size() )
+                break;
+            layout = brickLayout( depth );
+        } while( layout[0] > 1 && layout[1] > 1 && layout[2] > 1 );
+        _volumeInfo.rootNode = RootNode( depth, brickLayout( depth - 1 ) );
+    }
+
+    void* _map;
+    int _fd;
+    size_t _size;
+    size_t _offset;
+    std::vector< Vector3ui > _lodSize;
+    std::vector< size_t > _lodFirstEntry;
+    std::vector< TocEntry > _toc;
+};
+
+namespace
+{
+PluginRegisterer< UVFDataSource, const DataSourcePluginData& > uvfRegisterer;
+}
+}

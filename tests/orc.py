@@ -409,3 +409,83 @@ def compare(a, b):
     d = np.abs(a.astype(np.float64) - b.astype(np.float64))
     over = (d.max(axis=-1) > 2e-3).mean()
     return float(d.max()), float(d.mean()), float(over)
+
+
+def scene_from_datasource(drv, uri, ids, viewport, spin=(0.0, 0.0), alpha=0.05, eye=(0.0, 0.0, 1.5),
+                          spr=0, data_range=(0.0, 255.0)):
+    """Oracle scene for an irregular tree (uvf://): brick geometry and payloads come from the
+    host library's data source (libre_amd.driver.datasource_*), everything downstream -- atlas
+    emulation, texture coordinates, view data, brick order, the integrator -- is the oracle's."""
+    L = lib()
+    info = drv.datasource_info(uri)
+    assert info["data_type"] == 1  # uint8
+    s = Scene()
+    vi = VolumeInfo()
+    for a in range(3):
+        vi.voxels[a] = info["voxels"][a]
+        vi.maximumBlockSize[a] = info["max_block"][a]
+        vi.overlap[a] = info["overlap"][a]
+        vi.worldSize[a] = info["world_size"][a]
+    vi.depth = info["depth"]
+    s.vi = vi
+    n = len(ids)
+    mb = info["max_block"]
+    ov = info["overlap"]
+    slot_dim = [(m + 7) // 8 * 8 for m in mb]
+    s.slot_dim = slot_dim
+    slot_bytes = slot_dim[0] * slot_dim[1] * slot_dim[2]
+    slots = u32x3()
+    blocks = n
+    while True:
+        L.orc_pool_slots(u32x3(*slot_dim), slot_bytes, blocks * slot_bytes, u32x3(4096, 4096, 4096), slots)
+        if slots[0] * slots[1] * slots[2] >= n:
+            break
+        blocks += 1
+    s.slots = [slots[a] for a in range(3)]
+    s.atlas_dim = [s.slots[a] * slot_dim[a] for a in range(3)]
+    s.atlas = np.zeros((s.atlas_dim[2], s.atlas_dim[1], s.atlas_dim[0]), dtype=np.uint8)
+    s.W, s.H = viewport
+    s.mv = default_mv(spin, eye)
+    s.proj = default_proj()
+    s.view = ViewData()
+    L.orc_make_view_data(s.mv, s.proj, (C.c_uint32 * 4)(0, 0, s.W, s.H), C.byref(vi), C.byref(s.view))
+    mv = np.array(list(s.mv), dtype=np.float32).reshape(4, 4).T  # column-major -> rows
+    recs = []
+    for k, nid in enumerate(ids):
+        node = drv.datasource_node(uri, nid)
+        assert node["valid"]
+        bs = node["block_size"]
+        full = [bs[a] + 2 * ov[a] for a in range(3)]
+        brick = drv.datasource_brick(uri, nid).reshape(full[2], full[1], full[0])
+        slot = f32x3()
+        L.orc_pool_kth_slot(slots, k, slot)
+        origin = u32x3()
+        L.orc_pool_slot_voxel_origin(slots, u32x3(*slot_dim), slot, origin)
+        o = [origin[a] for a in range(3)]
+        # brick + border replication into the slot padding (what the upload does)
+        pad = [(0, slot_dim[2 - a] - full[2 - a]) for a in range(3)]
+        s.atlas[o[2]:o[2] + slot_dim[2], o[1]:o[1] + slot_dim[1], o[0]:o[0] + slot_dim[0]] = \
+            np.pad(brick, pad, mode="edge")
+        wb = node["world_box"]
+        centre = np.array([(wb[a] + wb[3 + a]) * 0.5 for a in range(3)] + [1.0], dtype=np.float32)
+        dist = float(np.linalg.norm((mv @ centre)[:3]))
+        recs.append((dist, k, nid, o, bs, wb))
+    recs.sort(key=lambda r: r[0])  # CudaRaycastRenderer.cpp:160-163
+    s.nodes = (NodeData * n)()
+    for i, (_, k, nid, o, bs, wb) in enumerate(recs):
+        nd = s.nodes[i]
+        for a in range(3):
+            nd.textureMin[a] = np.float32(o[a] + ov[a]) / np.float32(s.atlas_dim[a])
+            nd.textureSize[a] = np.float32(bs[a]) / np.float32(s.atlas_dim[a])
+            nd.aabbMin[a] = wb[a]
+            nd.aabbSize[a] = np.float32(wb[3 + a]) - np.float32(wb[a])
+    s.n_nodes = n
+    s.ids = [r[2] for r in recs]
+    max_level = max(unpack(nid)[0] for nid in ids)
+    if spr == 0:  # CudaRaycastRenderer.cpp:113-129
+        max_dim = float(max(info["voxels"]))
+        spr = int(max(max_dim / float(1 << (info["depth"] - max_level - 1)), 512.0))
+    s.render = RenderData(spr, 1, 32, 0, (C.c_float * 2)(*data_range))
+    s.tf = linear_ramp_tf(alpha)
+    s.planes = np.zeros((0, 4), dtype=np.float32)
+    return s

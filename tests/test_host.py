@@ -184,3 +184,84 @@ def test_raw_data_source_bricked_out_of_core(drv, tmp_path, dtype):
     # the four-parameter form stays the reference's single brick
     whole = drv.datasource_brick("raw://%s#48,32,64,%s" % (path, dtype), orc.pack(0, 0, 0, 0))
     assert (whole.view(vol.dtype) == vol.ravel()).all()
+
+
+def _uvf_python_decoder(path):
+    """Independent reader of the fixture (numpy + zlib): LOD sizes, brick layouts, bricks."""
+    import struct
+    import zlib
+    d = open(path, "rb").read()
+    assert d[:8] == b"UVF-DATA" and d[8] == 0
+    o = 9 + 24
+    o += struct.unpack_from("<Q", d, 25)[0] + 8
+    n, = struct.unpack_from("<Q", d, o)
+    o += 8 + n
+    sem, _, _ = struct.unpack_from("<QQQ", d, o)
+    assert sem == 9
+    o += 24
+    base = o
+    vox = struct.unpack_from("<QQQ", d, base + 13)
+    brick = struct.unpack_from("<QQQ", d, base + 61)
+    ov, = struct.unpack_from("<I", d, base + 85)
+    inner = [brick[a] - 2 * ov for a in range(3)]
+    sizes = [list(vox)]
+    while sizes[-1] != [1, 1, 1]:
+        sizes.append([(s + 1) // 2 for s in sizes[-1]])
+    layouts = [[-(-s[a] // inner[a]) for a in range(3)] for s in sizes]
+    toc, first, k = [], [], 0
+    for lay in layouts:
+        first.append(k)
+        k += lay[0] * lay[1] * lay[2]
+    for i in range(k):
+        toc.append(struct.unpack_from("<QQIQQ", d, base + 105 + 36 * i))
+
+    def get(lod, x, y, z):
+        lay, s = layouts[lod], sizes[lod]
+        off, ln, comp, usz, _ = toc[first[lod] + x + y * lay[0] + z * lay[0] * lay[1]]
+        raw = d[base + off:base + off + ln]
+        data = zlib.decompress(raw) if comp == 1 else raw
+        shape = [min(inner[a], s[a] - inner[a] * p) + 2 * ov for a, p in ((2, z), (1, y), (0, x))]
+        return np.frombuffer(data, dtype=np.uint8).reshape(shape)
+    return dict(voxels=list(vox), brick=list(brick), overlap=ov, sizes=sizes, layouts=layouts, get=get)
+
+
+def test_uvf_data_source_reference_known_answers(drv):
+    # tests/uvf/uvf.cpp:42-71 (the reference test, which needs Tuvok there): depth 2, one uint8
+    # component, 75x75x138 voxels, overlap 2, first child a valid node of 28^3 voxels whose
+    # padded size is the maximum block size, and a brick of exactly that many bytes
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mouse_reduced.uvf")
+    uri = "uvf://" + path
+    info = drv.datasource_info(uri)
+    assert info["depth"] == 2 and info["comp_count"] == 1 and info["data_type"] == 1  # DT_UINT8
+    assert info["voxels"] == [75, 75, 138] and info["overlap"] == [2, 2, 2]
+    assert info["root_blocks"] == [2, 2, 3]  # Tuvok's brick layout of LOD 1
+    first_child = orc.pack(1, 0, 0, 0)  # NodeId(0, (0,0,0)).getChildren().front()
+    node = drv.datasource_node(uri, first_child)
+    assert node["valid"]
+    assert [node["voxel_box"][3 + a] - node["voxel_box"][a] for a in range(3)] == [28, 28, 28]
+    assert [b + 4 for b in node["block_size"]] == info["max_block"] == [32, 32, 32]
+    brick = drv.datasource_brick(uri, first_child)
+    assert brick.size == 32 * 32 * 32
+    # "UVF format is not a perfect octree": positions outside the brick layout are invalid nodes
+    assert not drv.datasource_node(uri, orc.pack(1, 3, 0, 0))["valid"]
+    assert drv.datasource_node(uri, orc.pack(1, 2, 2, 4))["valid"]
+
+
+def test_uvf_bricks_match_an_independent_decoder(drv):
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mouse_reduced.uvf")
+    uri = "uvf://" + path
+    py = _uvf_python_decoder(path)
+    assert py["layouts"][0] == [3, 3, 5] and py["layouts"][1] == [2, 2, 3]
+    for level, lod in ((1, 0), (0, 1)):  # tree level -> Tuvok LOD (depth 2)
+        lay = py["layouts"][lod]
+        for z in range(lay[2]):
+            for y in range(lay[1]):
+                for x in range(lay[0]):
+                    want = py["get"](lod, x, y, z)
+                    got = drv.datasource_brick(uri, orc.pack(level, x, y, z))
+                    assert got.size == want.size and (got.reshape(want.shape) == want).all()
+    # neighbouring bricks agree on their shared overlap voxels: the payload layout is understood
+    a, b = py["get"](0, 0, 0, 0), py["get"](0, 1, 0, 0)
+    assert (a[:, :, 28:32] == b[:, :, 0:4]).all()
