@@ -148,6 +148,17 @@ int vrc_pool_synchronize( vrc_pool* pool );
 int vrc_pool_read_region( vrc_pool* pool, const uint32_t origin[3], const uint32_t size[3],
                           void* host_out );
 
+/* Histogram of a resident brick as a side kernel (the reference bins the CPU copy,
+ * livre/lib/cache/HistogramObject.cpp:36-119): voxels [origin, origin+size) of the slot in
+ * slot-local coordinates (origin = overlap, size = the node's voxel box: the interior, :94-97);
+ * integral voxels are binned over the type's range, bin = v / (range / bin_count) (:104-110);
+ * every voxel adds scale_factor (8^(depth-1-level), :158-162).  bin_count must divide the range
+ * (256 for uint8, 1024 for uint16 in the reference, :167-176).  Synchronous; host_bins receives
+ * bin_count values. */
+int vrc_pool_histogram( vrc_pool* pool, const float slot[3], const uint32_t origin[3],
+                        const uint32_t size[3], uint32_t bin_count, uint64_t scale_factor,
+                        uint64_t* host_bins );
+
 /* ---- renderer ----------------------------------------------------------------------------- */
 /* cuda::Renderer::update (cuda/Renderer.cu:245-250): 256 RGBA float texels as
  * lexis ColorMap::sampleColors<float>(256,0,256,0) yields them (cuda/ColorMap.cu:56-65), and

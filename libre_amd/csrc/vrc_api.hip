@@ -616,6 +616,49 @@ int vrc_pool_read_region( vrc_pool* p, const uint32_t origin[3], const uint32_t 
     return VRC_OK;
 }
 
+int vrc_pool_histogram( vrc_pool* p, const float slot[3], const uint32_t origin[3],
+                        const uint32_t size[3], uint32_t binCount, uint64_t scaleFactor,
+                        uint64_t* hostBins )
+{
+    if( !p || !slot || !origin || !size || !hostBins )
+        return fail( VRC_EINVAL, "vrc_pool_histogram: NULL argument" );
+    if( slot[0] < 0.f || slot[1] < 0.f || slot[2] < 0.f )
+        return fail( VRC_EINVAL, "vrc_pool_histogram: invalid slot" );
+    const uint32_t typeRange = p->elemBytes == 1 ? 256u : 65536u;
+    if( binCount == 0 || binCount > 4096 || typeRange % binCount != 0 )
+        return fail( VRC_EINVAL, "vrc_pool_histogram: bin count must divide the voxel type's range (max 4096)" );
+    for( int a = 0; a < 3; ++a )
+        if( (uint64_t)origin[a] + size[a] > p->slotDim[a] )
+            return fail( VRC_EINVAL, "vrc_pool_histogram: region outside the slot" );
+    VRC_HIP_CHECK( hipSetDevice( p->device ) );
+    uint32_t o[3];
+    pool_slot_voxel( p, slot, o );
+    vrc_layout lay;
+    for( int a = 0; a < 3; ++a )
+    {
+        lay.slots[a] = p->slots[a];
+        lay.slotDim[a] = p->slotDim[a];
+    }
+    const uint32_t base = vrc_slot_base( lay, o[0] / p->slotDim[0], o[1] / p->slotDim[1], o[2] / p->slotDim[2] );
+    unsigned long long* dBins = nullptr;
+    VRC_HIP_CHECK( hipMalloc( &dBins, binCount * sizeof( unsigned long long ) ) );
+    /* on the upload stream: ordered after the brick's own upload */
+    hipError_t e = hipMemsetAsync( dBins, 0, binCount * sizeof( unsigned long long ), p->uploadStream );
+    if( e == hipSuccess )
+        e = vrc_launch_brick_histogram( (const uint8_t*)p->dAtlas + (size_t)base * p->elemBytes, p->elemBytes,
+                                        p->slotDim[0] / VRC_MB, p->slotDim[1] / VRC_MB, origin, size,
+                                        binCount, (unsigned long long)scaleFactor, dBins, p->uploadStream );
+    if( e == hipSuccess )
+        e = hipMemcpyAsync( hostBins, dBins, binCount * sizeof( unsigned long long ), hipMemcpyDeviceToHost,
+                            p->uploadStream );
+    if( e == hipSuccess )
+        e = hipStreamSynchronize( p->uploadStream );
+    (void)hipFree( dBins );
+    if( e != hipSuccess )
+        return fail( VRC_EHIP, std::string( "vrc_pool_histogram: " ) + hipGetErrorString( e ) );
+    return VRC_OK;
+}
+
 /* ---------------------------------------------------------------------------------------- */
 int vrc_update( vrc_ctx* c, const float tf[256 * 4], const float* planes, uint32_t nPlanes )
 {

@@ -31,6 +31,13 @@ hipError_t vrc_launch_read_region( const void* atlas, void* dstRowMajor, uint32_
                                    const uint32_t origin[3], const uint32_t size[3],
                                    const vrc_layout& lay, hipStream_t stream );
 
+/* histogram of the voxels [origin, origin+size) of one slot (slot-local coordinates): bins[v /
+ * (typeRange / binCount)] += scale per voxel; bins is device memory, zeroed by the caller */
+hipError_t vrc_launch_brick_histogram( const void* slot, uint32_t elemBytes, uint32_t sbx, uint32_t sby,
+                                       const uint32_t origin[3], const uint32_t size[3],
+                                       uint32_t binCount, unsigned long long scale,
+                                       unsigned long long* bins, hipStream_t stream );
+
 struct vrc_raycast_args
 {
     vrc_frame frame;

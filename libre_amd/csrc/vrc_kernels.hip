@@ -18,6 +18,8 @@
  */
 #include "vrc_internal.h"
 
+#include <algorithm>
+
 /* pixel tile of one wave: VRC_TILE_W x VRC_TILE_H = 64 (vrc_internal.h) */
 #define VRC_WG 64u
 
@@ -133,6 +135,59 @@ __global__ void vrc_k_read_region( const T* __restrict__ atlas, T* __restrict__ 
         const uint32_t z = (uint32_t)( i / ( (size_t)sx * sy ) );
         dst[i] = atlas[vrc_atlas_index( lay, ox + x, oy + y, oz + z )];
     }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * brick histogram, a side kernel on a resident brick (livre/lib/cache/HistogramObject.cpp:36-119
+ * computes it on the CPU from the data cache): interior voxels only (the overlap is skipped,
+ * :94-97), integral types are binned over the type's range (:48-52, :104-110), every voxel
+ * counts scaleFactor times (:111).  One LDS histogram per workgroup, then 64-bit global adds.
+ * ---------------------------------------------------------------------------------------- */
+template < typename T >
+__global__ __launch_bounds__( 256 ) void vrc_k_brick_histogram(
+    const T* __restrict__ slot, uint32_t sbx, uint32_t sby, uint32_t ox, uint32_t oy, uint32_t oz,
+    uint32_t nx, uint32_t ny, uint32_t nz, uint32_t binCount, uint32_t perBin,
+    unsigned long long scale, unsigned long long* __restrict__ bins )
+{
+    __shared__ uint32_t h[4096];
+    for( uint32_t i = threadIdx.x; i < binCount; i += blockDim.x )
+        h[i] = 0;
+    __syncthreads();
+    const size_t total = (size_t)nx * ny * nz;
+    for( size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x )
+    {
+        const uint32_t x = (uint32_t)( i % nx ), y = (uint32_t)( ( i / nx ) % ny ),
+                       z = (uint32_t)( i / ( (size_t)nx * ny ) );
+        const uint32_t v = (uint32_t)slot[vrc_slot_local_index( ox + x, oy + y, oz + z, sbx, sby )];
+        atomicAdd( &h[v / perBin], 1u );
+    }
+    __syncthreads();
+    for( uint32_t i = threadIdx.x; i < binCount; i += blockDim.x )
+        if( h[i] )
+            atomicAdd( &bins[i], (unsigned long long)h[i] * scale );
+}
+
+hipError_t vrc_launch_brick_histogram( const void* slot, uint32_t elemBytes, uint32_t sbx, uint32_t sby,
+                                       const uint32_t origin[3], const uint32_t size[3],
+                                       uint32_t binCount, unsigned long long scale,
+                                       unsigned long long* bins, hipStream_t stream )
+{
+    const size_t total = (size_t)size[0] * size[1] * size[2];
+    if( total == 0 || binCount == 0 || binCount > 4096 )
+        return hipErrorInvalidValue;
+    const uint32_t blocks = (uint32_t)std::min< size_t >( ( total + 255 ) / 256, 1024 );
+    if( elemBytes == 1 && 256u % binCount == 0 )
+        hipLaunchKernelGGL( vrc_k_brick_histogram< uint8_t >, dim3( blocks ), dim3( 256 ), 0, stream,
+                            (const uint8_t*)slot, sbx, sby, origin[0], origin[1], origin[2], size[0],
+                            size[1], size[2], binCount, 256u / binCount, scale, bins );
+    else if( elemBytes == 2 && 65536u % binCount == 0 )
+        hipLaunchKernelGGL( vrc_k_brick_histogram< uint16_t >, dim3( blocks ), dim3( 256 ), 0, stream,
+                            (const uint16_t*)slot, sbx, sby, origin[0], origin[1], origin[2], size[0],
+                            size[1], size[2], binCount, 65536u / binCount, scale, bins );
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 
 static uint32_t grid_for( size_t total, uint32_t block )

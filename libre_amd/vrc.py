@@ -54,6 +54,7 @@ EXPORTS = [
     "vrc_ctx_create", "vrc_ctx_destroy", "vrc_ctx_set_stream", "vrc_set_option", "vrc_get_option",
     "vrc_pool_create", "vrc_pool_destroy", "vrc_pool_copy_to_slot", "vrc_pool_copy_to_slot_device",
     "vrc_pool_release_slot", "vrc_pool_info", "vrc_pool_synchronize", "vrc_pool_read_region",
+    "vrc_pool_histogram",
     "vrc_update", "vrc_pre_render", "vrc_set_row_map", "vrc_set_framebuffer", "vrc_get_framebuffer", "vrc_render",
     "vrc_post_render", "vrc_synchronize", "vrc_get_stats", "vrc_last_error", "vrc_abi_version",
 ]
@@ -92,6 +93,7 @@ def load_library(path=None):
                                 C.POINTER(C.c_uint32)]
     L.vrc_pool_synchronize.argtypes = [vp]
     L.vrc_pool_read_region.argtypes = [vp, u32x3, u32x3, vp]
+    L.vrc_pool_histogram.argtypes = [vp, f32x3, u32x3, u32x3, C.c_uint32, C.c_uint64, vp]
     L.vrc_update.argtypes = [vp, vp, vp, C.c_uint32]
     L.vrc_pre_render.argtypes = [vp, C.POINTER(ViewData)]
     L.vrc_set_row_map.argtypes = [vp, vp, C.c_uint32]

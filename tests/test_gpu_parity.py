@@ -183,6 +183,47 @@ def test_glraycaster_variant_parity(vrc, name):
         scenes.assert_parity(back, orc.oracle_render(s, threads=8)[0], name + " cuda after gl")
 
 
+def test_brick_histogram_side_kernel(vrc):
+    # tests/lib/cache.cpp:103-120 (known answer): mem://#1024,1024,512,32, first child of the
+    # root: every interior voxel is 17, 32^3 voxels x scale 8^3 = 2^24 in bin 17, nothing else
+    L = vrc.load_library()
+    vi = orc.mem_volume_info(1024, 1024, 512, 32)
+    nid = orc.pack(1, 0, 0, 0)
+    assert vi.depth == 5
+    brick = np.full((40, 40, 40), orc.lib().orc_mem_brick_value_u8(nid), dtype=np.uint8)
+    assert brick[0, 0, 0] == 17
+    ctx, pool = C.c_void_p(), C.c_void_p()
+    vrc.check(L, L.vrc_ctx_create(0, C.byref(ctx)))
+    vrc.check(L, L.vrc_pool_create(ctx, 1, 0, 0, 1, vrc.u32x3(40, 40, 40), 4 * 40 ** 3, C.byref(pool)))
+    slot = vrc.f32x3()
+    vrc.check(L, L.vrc_pool_copy_to_slot(pool, brick.ctypes.data, vrc.u32x3(40, 40, 40), slot))
+    bins = np.zeros(256, dtype=np.uint64)
+    vrc.check(L, L.vrc_pool_histogram(pool, slot, vrc.u32x3(4, 4, 4), vrc.u32x3(32, 32, 32), 256, 8 ** 3,
+                                      bins.ctypes.data))
+    assert int(bins.argmax()) == 17 and int(bins[17]) == 1 << 24 and int(bins.sum()) == 1 << 24
+    # a noise brick against numpy, interior only, and the reference's 1024 bins for uint16
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, size=(40, 40, 40), dtype=np.uint8)
+    vrc.check(L, L.vrc_pool_copy_to_slot(pool, noise.ctypes.data, vrc.u32x3(40, 40, 40), slot))
+    vrc.check(L, L.vrc_pool_histogram(pool, slot, vrc.u32x3(4, 4, 4), vrc.u32x3(32, 32, 32), 256, 1,
+                                      bins.ctypes.data))
+    assert (bins == np.bincount(noise[4:36, 4:36, 4:36].ravel(), minlength=256)).all()
+    assert L.vrc_pool_histogram(pool, slot, vrc.u32x3(4, 4, 4), vrc.u32x3(40, 40, 40), 256, 1,
+                                bins.ctypes.data) == vrc.VRC_EINVAL  # region leaves the slot
+    L.vrc_pool_destroy(pool)
+    pool16 = C.c_void_p()
+    vrc.check(L, L.vrc_pool_create(ctx, 2, 0, 0, 1, vrc.u32x3(24, 24, 24), 4 * 2 * 24 ** 3, C.byref(pool16)))
+    n16 = rng.integers(0, 65536, size=(24, 24, 24), dtype=np.uint16)
+    vrc.check(L, L.vrc_pool_copy_to_slot(pool16, n16.ctypes.data, vrc.u32x3(24, 24, 24), slot))
+    bins16 = np.zeros(1024, dtype=np.uint64)
+    vrc.check(L, L.vrc_pool_histogram(pool16, slot, vrc.u32x3(4, 4, 4), vrc.u32x3(16, 16, 16), 1024, 8,
+                                      bins16.ctypes.data))
+    want = np.bincount((n16[4:20, 4:20, 4:20].ravel() // 64).astype(np.int64), minlength=1024) * 8
+    assert (bins16 == want.astype(np.uint64)).all()
+    L.vrc_pool_destroy(pool16)
+    L.vrc_ctx_destroy(ctx)
+
+
 def test_trilinear_nucleon_clamped(vrc):
     s = scenes.nucleon_scene()
     want, n_want = orc.oracle_render(s, threads=8, filter_mode=1)
