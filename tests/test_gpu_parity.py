@@ -248,6 +248,28 @@ def test_large_launch_uses_groups_of_eight_and_matches_small_launch_rules(vrc):
     assert abs(n_got - n_want) <= 2e-4 * n_want + 8
 
 
+def test_c2_full_size_rows_and_properties(vrc):
+    # BASELINE C2 at full size (1024^3 mem://, block 128, 1024^2, 512 bricks): the oracle renders
+    # every 64th row; the GPU frame must match those rows and their sample count, be idempotent,
+    # and be the same frame from the reference-order kernel
+    s = orc.build_scene(voxels=(1024, 1024, 1024), block=128, viewport=(1024, 1024))
+    assert s.n_nodes == 512 and s.render.samplesPerRay == 1024
+    rows = (0, 1024, 64)
+    want, n_want = orc.oracle_render(s, threads=16, rows=rows)
+    with _gpu(s) as g:
+        got, n_got, st = g.render()
+        assert st.kernel_variant == vrc.KERNEL_GRID_DDA and list(st.grid_dims) == [8, 8, 8]
+        again, n_again, _ = g.render()
+        assert (again == got).all() and n_again == n_got
+        ref, n_ref, _ = g.render(kernel=vrc.KERNEL_REFERENCE_ORDER)
+    scenes.assert_parity(got[::64], want[::64], "C2 rows")
+    scenes.assert_parity(ref, got, "C2 reference order vs DDA")
+    assert abs(n_ref - n_got) <= 2e-4 * n_got
+    assert 5.5e8 < n_got < 5.8e8  # SURVEY 8d estimate: ~5.6e8 samples per frame
+    # the oracle's count over 16 of 1024 rows, scaled, agrees with the full-frame counter to 3 %
+    assert abs(n_want * 64 - n_got) <= 0.03 * n_got
+
+
 def test_c1_config_parity(vrc):
     # mem://#128,128,128,32, 512^2 viewport, 512 samples/ray, 64 leaf bricks
     s = orc.build_scene(voxels=(128, 128, 128), block=32, viewport=(512, 512))
