@@ -233,6 +233,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
          * walk (ray/box set-up, ~200 instructions) is shared by the wave, so lanes that
          * finish a brick early wait for company (VRC_LDS_REFILL lanes) or for the others to
          * run dry, as the lanes of the gather kernel wait at the end of a brick's march loop. */
+        bool refill; /* wave-uniform */
         {
             const uint64_t needMask = __builtin_amdgcn_ballot_w64( !done && !hasSeg );
             const uint64_t haveMask = __builtin_amdgcn_ballot_w64( hasSeg );
@@ -241,11 +242,10 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
              * depth for the rest of it and never share a box again) */
             const uint64_t soonMask = __builtin_amdgcn_ballot_w64(
                 hasSeg && !( travel > stepSize * (float)VRC_LDS_G ) );
-            if( needMask != 0ull && haveMask != 0ull &&
-                ( __builtin_popcountll( needMask ) < VRC_LDS_REFILL || soonMask != 0ull ) )
-                goto round;
+            refill = !( needMask != 0ull && haveMask != 0ull &&
+                        ( __builtin_popcountll( needMask ) < VRC_LDS_REFILL || soonMask != 0ull ) );
         }
-        while( __builtin_amdgcn_ballot_w64( !done && !hasSeg ) != 0ull )
+        while( refill && __builtin_amdgcn_ballot_w64( !done && !hasSeg ) != 0ull )
         {
             VRC_LDS_STAT( 4, 1 )
             if( !done && !hasSeg )
@@ -314,7 +314,6 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
             }
         }
 
-    round:
         /* B: the round's LDS box is built around one lane (the tile centre if it has a
          * segment): its brick, and the lanes of that brick that are near it */
         const uint64_t segMask = __builtin_amdgcn_ballot_w64( hasSeg );
