@@ -105,6 +105,7 @@ struct vrc_ctx
     size_t fbOwnPixels = 0;
     vrc_f4* fbExt = nullptr;
     uint32_t fbW = 0, fbH = 0;
+    bool clearPending = false; /* pre_render's clear, folded into the first march or done lazily */
 
     /* node table + brick grid */
     vrc_dev_node* dNodes = nullptr;
@@ -745,8 +746,22 @@ int vrc_pre_render( vrc_ctx* c, const vrc_view_data* view )
         c->fbW = w;
         c->fbH = h;
     }
-    /* PixelBufferObject::mapBuffer clears the mapped buffer (cuda/PixelBufferObject.cu:80) */
-    VRC_HIP_CHECK( hipMemsetAsync( ctx_fb( c ), 0, (size_t)w * h * sizeof( vrc_f4 ), c->stream ) );
+    /* PixelBufferObject::mapBuffer clears the mapped buffer (cuda/PixelBufferObject.cu:80).  The
+     * clear is folded into the first march of the frame (vrc_frame::clearFirst); whoever looks at
+     * the buffer before a march has run gets it done then (resolve_clear). */
+    c->clearPending = true;
+    return VRC_OK;
+}
+
+/* the pixel buffer is about to be read or re-pointed: do the clear pre_render promised */
+static int resolve_clear( vrc_ctx* c )
+{
+    if( c->clearPending && ctx_fb( c ) && c->fbW && c->fbH )
+    {
+        VRC_HIP_CHECK( hipSetDevice( c->device ) );
+        VRC_HIP_CHECK( hipMemsetAsync( ctx_fb( c ), 0, (size_t)c->fbW * c->fbH * sizeof( vrc_f4 ), c->stream ) );
+    }
+    c->clearPending = false;
     return VRC_OK;
 }
 
@@ -758,6 +773,11 @@ int vrc_set_framebuffer( vrc_ctx* c, void* deviceRgba, uint32_t width, uint32_t 
         return fail( VRC_EINVAL, "vrc_set_framebuffer: empty framebuffer" );
     if( deviceRgba && ( (uintptr_t)deviceRgba % 16u ) != 0 )
         return fail( VRC_EINVAL, "vrc_set_framebuffer: pointer must be 16-byte aligned" );
+    {
+        const int rc = resolve_clear( c );
+        if( rc != VRC_OK )
+            return rc;
+    }
     c->fbExt = (vrc_f4*)deviceRgba;
     if( deviceRgba )
     {
@@ -783,6 +803,11 @@ int vrc_get_framebuffer( vrc_ctx* c, void** deviceRgba, uint32_t* width, uint32_
 {
     if( !c )
         return fail( VRC_EINVAL, "vrc_get_framebuffer: ctx is NULL" );
+    {
+        const int rc = resolve_clear( c );
+        if( rc != VRC_OK )
+            return rc;
+    }
     if( deviceRgba ) *deviceRgba = ctx_fb( c );
     if( width ) *width = c->fbW;
     if( height ) *height = c->fbH;
@@ -969,6 +994,10 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         a.tileOrder = c->dTileOrder;
     }
 
+    /* fold the frame's clear into this march (after the tile-schedule cache compared frames) */
+    f.clearFirst = c->clearPending ? 1u : 0u;
+    c->clearPending = false;
+
     a.nodes = c->dNodes;
     a.gridTable = useDda ? c->dGrid : nullptr;
     a.atlas = pool->dAtlas;
@@ -1036,6 +1065,11 @@ int vrc_post_render( vrc_ctx* c, float* hostRgba )
     if( !c )
         return fail( VRC_EINVAL, "vrc_post_render: ctx is NULL" );
     VRC_HIP_CHECK( hipSetDevice( c->device ) );
+    {
+        const int rc = resolve_clear( c ); /* a frame without a march still ends cleared */
+        if( rc != VRC_OK )
+            return rc;
+    }
     if( hostRgba )
     {
         if( !ctx_fb( c ) || c->fbW == 0 )
@@ -1053,6 +1087,11 @@ int vrc_synchronize( vrc_ctx* c )
     if( !c )
         return fail( VRC_EINVAL, "vrc_synchronize: ctx is NULL" );
     VRC_HIP_CHECK( hipSetDevice( c->device ) );
+    {
+        const int rc = resolve_clear( c );
+        if( rc != VRC_OK )
+            return rc;
+    }
     VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
     return VRC_OK;
 }

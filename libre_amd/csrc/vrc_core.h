@@ -94,6 +94,10 @@ struct vrc_frame
     /* 0: cudaRaycaster semantics (cuda/Renderer.cu); 1: the GLSL twin's
      * (glRaycaster/shaders/fragRaycast.glsl), see vrc_brick_segment */
     uint32_t variant;
+    /* 1: first march into a pixel buffer that vrc_pre_render declared cleared but did not touch:
+     * every pixel starts from 0 and is stored, hit or miss (the clear of
+     * cuda/PixelBufferObject.cu:80 folded into the march: one pass over the frame less) */
+    uint32_t clearFirst;
 };
 
 /* Atlas memory layout.  The logical atlas is the reference's 3-D array of slots
@@ -920,10 +924,15 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
                                        uint32_t& nSamples )
 {
     const vrc_ray r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
-    if( !r.hit )
-        return; /* Renderer.cu:129-130, :148-149: pixel left untouched */
     const uint32_t pixelPos = py * f.width + px;
-    vrc_f4 color = pixelBuffer[pixelPos];
+    const vrc_f4 zero = { 0.f, 0.f, 0.f, 0.f };
+    if( !r.hit )
+    {
+        if( f.clearFirst )
+            pixelBuffer[pixelPos] = zero;
+        return; /* Renderer.cu:129-130, :148-149: pixel left untouched (= cleared) */
+    }
+    vrc_f4 color = f.clearFirst ? zero : pixelBuffer[pixelPos];
     if( color.w > VRC_EARLY_EXIT ) /* Renderer.cu:152-155 */
         return;
     for( uint32_t i = 0; i < f.nodeCount; ++i )
@@ -959,10 +968,15 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
                                 uint32_t& nSamples )
 {
     const vrc_ray r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
-    if( !r.hit )
-        return;
     const uint32_t pixelPos = py * f.width + px;
-    vrc_f4 color = pixelBuffer[pixelPos];
+    const vrc_f4 zero = { 0.f, 0.f, 0.f, 0.f };
+    if( !r.hit )
+    {
+        if( f.clearFirst )
+            pixelBuffer[pixelPos] = zero;
+        return;
+    }
+    vrc_f4 color = f.clearFirst ? zero : pixelBuffer[pixelPos];
     if( color.w > VRC_EARLY_EXIT )
         return;
 

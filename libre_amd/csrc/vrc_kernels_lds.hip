@@ -165,13 +165,16 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
         r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
         if( r.hit )
         {
-            color = pixelBuffer[pixelPos];
+            if( !f.clearFirst )
+                color = pixelBuffer[pixelPos];
             if( !( color.w > VRC_EARLY_EXIT ) )
             {
                 store = true;
                 done = false;
             }
         }
+        else if( f.clearFirst )
+            store = true; /* the folded clear: a missed pixel is written as 0 */
     }
 
     int cell[3] = { 0, 0, 0 }, stepDir[3] = { 1, 1, 1 };
