@@ -22,6 +22,11 @@
 
 /* pixel tile of one wave: VRC_TILE_W x VRC_TILE_H = 64 (vrc_internal.h) */
 #define VRC_WG 64u
+/* waves (= tiles) per workgroup: they share the LDS tables, set up once per workgroup */
+#ifndef VRC_WAVES_PER_WG
+#define VRC_WAVES_PER_WG 1u
+#endif
+#define VRC_WG_THREADS ( VRC_WG * VRC_WAVES_PER_WG )
 
 /* classified-sample table (vrc_core.h: vrc_lut_entry): 256 entries per frame instead of a TF
  * fetch + pow per sample */
@@ -394,7 +399,7 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t*
  * and wins when a launch is no more than about one wave per SIMD slot and the longest ray's
  * latency sets the time -- the per-rank share of a sort-first frame from 4 ranks up. */
 template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP >
-__global__ __launch_bounds__( VRC_WG, GROUP > 8 ? 2 : VRC_MIN_WAVES ) void vrc_k_raycast(
+__global__ __launch_bounds__( VRC_WG_THREADS, GROUP > 8 ? 2 : VRC_MIN_WAVES ) void vrc_k_raycast(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ gridTable, const ATLAS_T* __restrict__ atlas,
     const vrc_f4* __restrict__ lutGlobal, const vrc_classifier cls,
@@ -404,27 +409,36 @@ __global__ __launch_bounds__( VRC_WG, GROUP > 8 ? 2 : VRC_MIN_WAVES ) void vrc_k
     /* classified table (257 entries) or, for the per-sample classification modes, the padded
      * transfer function (258) */
     __shared__ vrc_f4 lut[VRC_TFP_ENTRIES];
-    const uint32_t lane = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
 #pragma unroll
-    for( uint32_t i = 0; i < 256u / VRC_WG; ++i )
-        lut[lane + i * VRC_WG] = lutGlobal[lane + i * VRC_WG];
-    if( lane < VRC_TFP_ENTRIES - 256u )
-        lut[256u + lane] = lutGlobal[256u + lane];
+    for( uint32_t i = 0; i < ( 256u + VRC_WG_THREADS - 1u ) / VRC_WG_THREADS; ++i )
+        if( tid + i * VRC_WG_THREADS < 256u )
+            lut[tid + i * VRC_WG_THREADS] = lutGlobal[tid + i * VRC_WG_THREADS];
+    if( tid < VRC_TFP_ENTRIES - 256u )
+        lut[256u + tid] = lutGlobal[256u + tid];
 #if defined( VRC_ADDR_TABLES )
     if( FIXED )
     {
         const uint32_t cyy = f.sbx * VRC_MB_VOXELS - 64u, czz = f.sbx * f.sby * VRC_MB_VOXELS - 512u;
 #pragma unroll
-        for( uint32_t i = 0; i < 256u / VRC_WG; ++i )
+        for( uint32_t i = 0; i < ( 256u + VRC_WG_THREADS - 1u ) / VRC_WG_THREADS; ++i )
         {
-            const uint32_t u = lane + i * VRC_WG, q = u >> VRC_MB_SHIFT;
-            vrc_addr_tab[u] = u + 504u * q;
-            vrc_addr_tab[256u + u] = 8u * u + cyy * q;
-            vrc_addr_tab[512u + u] = 64u * u + czz * q;
+            const uint32_t u = tid + i * VRC_WG_THREADS, q = u >> VRC_MB_SHIFT;
+            if( u < 256u )
+            {
+                vrc_addr_tab[u] = u + 504u * q;
+                vrc_addr_tab[256u + u] = 8u * u + cyy * q;
+                vrc_addr_tab[512u + u] = 64u * u + czz * q;
+            }
         }
     }
 #endif
     __syncthreads();
+    /* from here on the waves of the workgroup are independent */
+    const uint32_t slotIndex = blockIdx.x * VRC_WAVES_PER_WG + ( tid >> 6 );
+    if( slotIndex >= nTiles )
+        return;
 
     /* Workgroup -> tile.  Ray lengths vary by more than 2x over the image and whole tiles miss
      * the volume, so dispatch order matters more than L2 affinity here (every voxel is
@@ -432,7 +446,7 @@ __global__ __launch_bounds__( VRC_WG, GROUP > 8 ? 2 : VRC_MIN_WAVES ) void vrc_k
      * tileOrder lists tiles heaviest-first (vrc_k_tile_order), and because the dispatcher
      * deals workgroups b, b+1, ... round-robin over the 8 XCDs (MI355X_MICROARCH.md,
      * "Workgroup dispatch") every XCD gets the same mix and the long tiles start first. */
-    const uint32_t tile = tileOrder ? tileOrder[blockIdx.x] : blockIdx.x;
+    const uint32_t tile = tileOrder ? tileOrder[slotIndex] : slotIndex;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
 #if defined( VRC_LANES_ROWMAJOR ) || VRC_TILE_W != 8
     const uint32_t lx = lane % VRC_TILE_W, ly = lane / VRC_TILE_W;
@@ -475,8 +489,9 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
     const uint32_t nTiles = tilesX * tilesY;
     if( nTiles == 0 )
         return hipSuccess;
-    hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP > ), dim3( nTiles ),
-                        dim3( VRC_WG ), 0, stream, a.frame, a.nodes, a.gridTable,
+    hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP > ),
+                        dim3( ( nTiles + VRC_WAVES_PER_WG - 1u ) / VRC_WAVES_PER_WG ),
+                        dim3( VRC_WG_THREADS ), 0, stream, a.frame, a.nodes, a.gridTable,
                         (const ATLAS_T*)a.atlas, a.lut, a.classifier, a.pixelBuffer,
                         a.sampleCounter, a.tileOrder, tilesX, nTiles );
     return hipGetLastError();
