@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libLivreHipRaycastPipeline.so")
+# LIVRE_HIP_HOST_LIB: another build of the same library (the sanitizer run of the host tests)
+LIB_PATH = os.environ.get("LIVRE_HIP_HOST_LIB") or os.path.join(_HERE, "lib", "libLivreHipRaycastPipeline.so")
 
 
 class Params(C.Structure):  # lvh_params

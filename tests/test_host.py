@@ -265,3 +265,33 @@ def test_uvf_bricks_match_an_independent_decoder(drv):
     # neighbouring bricks agree on their shared overlap voxels: the payload layout is understood
     a, b = py["get"](0, 0, 0, 0), py["get"](0, 1, 0, 0)
     assert (a[:, :, 28:32] == b[:, :, 0:4]).all()
+
+
+def test_host_library_under_sanitizers(tmp_path):
+    # ASan + UBSan + LeakSanitizer build of the host library, driven natively (a preloaded ASan
+    # runtime inside python does not survive C++ exceptions crossing the library): caches, plugin
+    # factory, camera, every data source including the error paths
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "libre_amd", "host")
+    lib = os.path.join(root, "libre_amd", "lib")
+    srcs = [os.path.join(host, "src", n) for n in ("data.cpp", "datasources.cpp", "uvf_datasource.cpp",
+                                                   "render.cpp", "hip_plugin.cpp", "driver.cpp")]
+    san = ["-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-pthread"]
+    so = str(tmp_path / "libLivreHipRaycastPipeline.so")
+    subprocess.check_call(["g++"] + san + ["-fPIC", "-shared", "-I" + os.path.join(host, "include"),
+                                           "-I" + os.path.join(root, "include"), "-o", so] + srcs +
+                          ["-L" + lib, "-lvrc_hip", "-Wl,-rpath," + lib, "-lz"])
+    exe = str(tmp_path / "selftest")
+    subprocess.check_call(["g++"] + san + ["-I" + os.path.join(root, "include"),
+                                           os.path.join(root, "tests", "host_san", "selftest.cpp"), "-o", exe,
+                                           "-L" + str(tmp_path), "-lLivreHipRaycastPipeline",
+                                           "-Wl,-rpath," + str(tmp_path), "-L" + lib, "-lvrc_hip", "-Wl,-rpath," + lib])
+    out = subprocess.run([exe, os.path.join(root, "tests", "golden")], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    text = out.stdout + out.stderr
+    assert out.returncode == 0 and "DONE" in out.stdout, text
+    assert "ERROR: AddressSanitizer" not in text and "runtime error" not in text and "LeakSanitizer" not in text, text
+    assert "cache 0" in text and "factory 0" in text and "camera 0" in text
+    assert "uvf brick rc=0 n=32768" in text and "uvf bad file rc=1" in text
