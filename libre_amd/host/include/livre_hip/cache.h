@@ -126,41 +126,39 @@ public:
             }
             applyPolicy();
         }
-        ObjectPtr obj;
-        bool constructed = false;
+        /* Entry::obj is written with BOTH the entry's mutex and the map's write lock held, so it
+         * may be read under either: here under the entry's mutex, in get()/the hit path under the
+         * map's read lock, in unloadLocked() under its write lock (ThreadSanitizer-checked:
+         * tests/host_san/cache_stress.cpp). */
+        std::lock_guard< std::mutex > elock( entry->mutex );
+        if( entry->obj ) /* another loader of the same id was first */
+            return entry->obj;
+        ObjectPtr created;
+        try
         {
-            std::lock_guard< std::mutex > elock( entry->mutex );
-            if( !entry->obj )
-            {
-                try
-                {
-                    entry->obj.reset( new CacheObjectT( cacheId, args... ) );
-                    constructed = true;
-                }
-                catch( const CacheLoadException& )
-                {
-                }
-            }
-            obj = entry->obj;
+            created.reset( new CacheObjectT( cacheId, args... ) );
+        }
+        catch( const CacheLoadException& )
+        {
         }
         std::unique_lock< std::shared_timed_mutex > lock( _mutex );
-        if( obj )
+        const auto it = _cacheMap.find( cacheId );
+        if( !created )
         {
-            if( constructed )
-            {
-                _statistics.notifyMiss();
-                _statistics.notifyLoaded( *obj );
-                lruInsert( cacheId );
-                applyPolicy();
-            }
-        }
-        else
-        {
-            const auto it = _cacheMap.find( cacheId );
-            if( it != _cacheMap.end() && !it->second->obj )
+            if( it != _cacheMap.end() && it->second == entry && !entry->obj )
                 _cacheMap.erase( it );
+            return ObjectPtr();
         }
-        return obj;
+        entry->obj = created;
+        if( it == _cacheMap.end() )
+            _cacheMap.emplace( cacheId, entry ); /* the empty entry was unloaded meanwhile */
+        else if( it->second != entry )
+            return it->second->obj ? it->second->obj : created; /* replaced meanwhile: keep theirs */
+        _statistics.notifyMiss();
+        _statistics.notifyLoaded( *created );
+        lruInsert( cacheId );
+        applyPolicy();
+        return created;
     }
 
     /** Cache.ipp:222-240 */

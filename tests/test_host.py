@@ -295,3 +295,22 @@ def test_host_library_under_sanitizers(tmp_path):
     assert "ERROR: AddressSanitizer" not in text and "runtime error" not in text and "LeakSanitizer" not in text, text
     assert "cache 0" in text and "factory 0" in text and "camera 0" in text
     assert "uvf brick rc=0 n=32768" in text and "uvf bad file rc=1" in text
+
+
+def test_cache_under_thread_sanitizer(tmp_path):
+    # the mirrored Cache<T> under concurrent load / get / unload with an LRU budget far below the
+    # working set, built with -fsanitize=thread (found and fixed: Entry::obj was written under
+    # the entry's mutex only while get() read it under the map lock)
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "libre_amd", "host")
+    srcs = [os.path.join(host, "src", n) for n in ("data.cpp", "datasources.cpp", "uvf_datasource.cpp", "render.cpp")]
+    exe = str(tmp_path / "cache_stress")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread",
+                           "-I" + os.path.join(host, "include"), "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "host_san", "cache_stress.cpp")] + srcs + ["-o", exe, "-lz"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    text = out.stdout + out.stderr
+    assert out.returncode == 0 and "DONE" in out.stdout, text
+    assert "ThreadSanitizer" not in text, text
