@@ -73,9 +73,10 @@ public:
 
 private:
     std::string _name;
-    size_t _usedMemBytes;
+    /* written under the cache's write lock, read by monitoring code without it */
+    std::atomic< size_t > _usedMemBytes;
     const size_t _maxMemBytes;
-    size_t _objCount, _cacheHit, _cacheMiss;
+    std::atomic< size_t > _objCount, _cacheHit, _cacheMiss;
 };
 
 /** livre/core/cache/Cache.h:38-101 + Cache.ipp.  LRU by load order; an object is evicted only
