@@ -532,10 +532,13 @@ struct HipRaycastPipeline::Impl
                     std::fprintf( stderr, "[livre_hip] loader: %zu bricks, data source + CPU cache %.1f ms, texture upload %.1f ms\n",
                                   end - begin, tData, tTex );
                 {
+                    /* notify under the mutex: the waiter owns the condition variable on its stack
+                     * and may destroy it as soon as it can re-acquire the mutex and sees 0
+                     * (found by ThreadSanitizer, tests/host_san/pipeline_stress.cpp) */
                     std::lock_guard< std::mutex > lock( doneMutex );
                     --pending;
+                    doneCv.notify_all();
                 }
-                doneCv.notify_all();
             } );
         }
         {

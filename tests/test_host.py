@@ -314,3 +314,28 @@ def test_cache_under_thread_sanitizer(tmp_path):
     text = out.stdout + out.stderr
     assert out.returncode == 0 and "DONE" in out.stdout, text
     assert "ThreadSanitizer" not in text, text
+
+
+def test_pipeline_threads_under_thread_sanitizer(tmp_path):
+    # the "hip" pipeline's loaders, asynchronous upload thread and LRU under -fsanitize=thread, over
+    # a CPU stand-in of the device ABI (tests/host_san/vrc_stub.cpp): synchronous multi-pass and
+    # asynchronous frames with and without cache pressure (found and fixed: a condition variable
+    # on the waiter's stack destroyed while the last loader was still notifying it)
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "libre_amd", "host")
+    srcs = [os.path.join(host, "src", n) for n in ("data.cpp", "datasources.cpp", "uvf_datasource.cpp",
+                                                   "render.cpp", "hip_plugin.cpp", "driver.cpp")]
+    srcs += [os.path.join(root, "tests", "host_san", n) for n in ("pipeline_stress.cpp", "vrc_stub.cpp")]
+    exe = str(tmp_path / "pipeline_stress")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread",
+                           "-I" + os.path.join(host, "include"), "-I" + os.path.join(root, "include")] + srcs +
+                          ["-o", exe, "-lz"])
+    for threads in ("2", "6"):
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, LIVRE_HIP_UPLOAD_THREADS=threads))
+        text = out.stdout + out.stderr
+        assert out.returncode == 0 and "DONE" in out.stdout, text
+        assert "ThreadSanitizer" not in text, text
+        assert "sync 1 cache 2 MB: available 512 not available 0 passes 4" in text
