@@ -224,6 +224,23 @@ def test_brick_histogram_side_kernel(vrc):
     L.vrc_ctx_destroy(ctx)
 
 
+def test_contexts_and_pools_release_their_device_memory(vrc):
+    # the HIP runtime libvrc_hip.so itself is linked against (not torch's bundled copy)
+    hip = C.CDLL("libamdhip64.so")
+    s = scenes.get("hash64_spin")
+    free0 = None
+    for i in range(12):
+        with _gpu(s) as g:
+            g.render()
+            g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
+        free, total = C.c_size_t(), C.c_size_t()
+        assert hip.hipDeviceSynchronize() == 0
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        if i == 1:
+            free0 = free.value  # after the first cycles have warmed the runtime's own pools
+    assert free0 - free.value < 32 << 20, (free0, free.value)
+
+
 def test_trilinear_nucleon_clamped(vrc):
     s = scenes.nucleon_scene()
     want, n_want = orc.oracle_render(s, threads=8, filter_mode=1)
