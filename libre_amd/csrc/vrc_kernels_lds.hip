@@ -29,6 +29,8 @@
  */
 #include "vrc_internal.h"
 
+#include <type_traits>
+
 #define VRC_LDS_PY 32u                           /* row pitch = max x extent of a region */
 #define VRC_LDS_RY 24u                           /* max y extent */
 #define VRC_LDS_PZ ( VRC_LDS_PY * VRC_LDS_RY )   /* slice pitch */
@@ -438,78 +440,93 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
             /* ---- march g steps from LDS ---------------------------------------------------- */
             const uint32_t bias = box.z0 * VRC_LDS_PZ + box.y0 * VRC_LDS_PY + box.x0;
             constexpr int BATCH = LINEAR ? 4 : VRC_LDS_G;
+            /* FASTR: a full round (g = VRC_LDS_G) in which every participating lane has more than
+             * g steps left: no per-step "does this lane take this step" selects */
+            auto marchLds = [&]( auto fastTag ) {
+                constexpr bool FASTR = decltype( fastTag )::value;
 #pragma unroll
-            for( int b0 = 0; b0 < VRC_LDS_G; b0 += BATCH )
-            {
-                if( b0 < g ) /* wave-uniform */
+                for( int b0 = 0; b0 < VRC_LDS_G; b0 += BATCH )
                 {
-                    /* addresses of the batch; a step the lane does not take reads offset 0 */
-                    uint32_t a[BATCH], wfx[BATCH], wfy[BATCH], wfz[BATCH];
-                    bool act[BATCH];
-#pragma unroll
-                    for( int s = 0; s < BATCH; ++s )
+                    if( FASTR || b0 < g ) /* wave-uniform */
                     {
-                        const bool take = part && ( b0 + s < g );
-                        act[s] = take && travel > 0.0f;
-                        const uint32_t av = ( fz >> 24 ) * VRC_LDS_PZ + ( fy >> 24 ) * VRC_LDS_PY +
-                                            ( fx >> 24 ) - bias;
-                        a[s] = act[s] ? av : 0u;
-                        wfx[s] = fx;
-                        wfy[s] = fy;
-                        wfz[s] = fz;
-                        fx += take ? fdx : 0u;
-                        fy += take ? fdy : 0u;
-                        fz += take ? fdz : 0u;
-                        travel -= take ? stepSize : 0.0f;
-                    }
-                    vrc_f4 e[BATCH];
-                    if( LINEAR )
-                    {
-                        float t[BATCH][8];
+                        /* addresses of the batch; a step the lane does not take reads offset 0 */
+                        uint32_t a[BATCH], wfx[BATCH], wfy[BATCH], wfz[BATCH];
+                        bool act[BATCH];
 #pragma unroll
                         for( int s = 0; s < BATCH; ++s )
                         {
-                            const uint8_t* const p = region + a[s];
-                            t[s][0] = (float)p[0];
-                            t[s][1] = (float)p[1];
-                            t[s][2] = (float)p[VRC_LDS_PY];
-                            t[s][3] = (float)p[VRC_LDS_PY + 1u];
-                            t[s][4] = (float)p[VRC_LDS_PZ];
-                            t[s][5] = (float)p[VRC_LDS_PZ + 1u];
-                            t[s][6] = (float)p[VRC_LDS_PZ + VRC_LDS_PY];
-                            t[s][7] = (float)p[VRC_LDS_PZ + VRC_LDS_PY + 1u];
+                            const bool take = FASTR ? true : ( part && ( b0 + s < g ) );
+                            act[s] = FASTR ? true : ( take && travel > 0.0f );
+                            const uint32_t av = ( fz >> 24 ) * VRC_LDS_PZ + ( fy >> 24 ) * VRC_LDS_PY +
+                                                ( fx >> 24 ) - bias;
+                            a[s] = act[s] ? av : 0u;
+                            wfx[s] = fx;
+                            wfy[s] = fy;
+                            wfz[s] = fz;
+                            fx += take ? fdx : 0u;
+                            fy += take ? fdy : 0u;
+                            fz += take ? fdz : 0u;
+                            travel -= take ? stepSize : 0.0f;
+                        }
+                        vrc_f4 e[BATCH];
+                        if( LINEAR )
+                        {
+                            float t[BATCH][8];
+#pragma unroll
+                            for( int s = 0; s < BATCH; ++s )
+                            {
+                                const uint8_t* const p = region + a[s];
+                                t[s][0] = (float)p[0];
+                                t[s][1] = (float)p[1];
+                                t[s][2] = (float)p[VRC_LDS_PY];
+                                t[s][3] = (float)p[VRC_LDS_PY + 1u];
+                                t[s][4] = (float)p[VRC_LDS_PZ];
+                                t[s][5] = (float)p[VRC_LDS_PZ + 1u];
+                                t[s][6] = (float)p[VRC_LDS_PZ + VRC_LDS_PY];
+                                t[s][7] = (float)p[VRC_LDS_PZ + VRC_LDS_PY + 1u];
+                            }
+#pragma unroll
+                            for( int s = 0; s < BATCH; ++s )
+                            {
+                                const float sc = 1.0f / 16777216.0f;
+                                const float wx = (float)( wfx[s] & 0xFFFFFFu ) * sc;
+                                const float wy = (float)( wfy[s] & 0xFFFFFFu ) * sc;
+                                const float wz = (float)( wfz[s] & 0xFFFFFFu ) * sc;
+                                e[s] = vrc_classify( lut, vrc_trilerp( t[s], wx, wy, wz ), cls );
+                            }
+                        }
+                        else
+                        {
+                            uint32_t d[BATCH];
+#pragma unroll
+                            for( int s = 0; s < BATCH; ++s )
+                                d[s] = (uint32_t)region[a[s]];
+#pragma unroll
+                            for( int s = 0; s < BATCH; ++s )
+                                e[s] = lut[act[s] ? d[s] : 256u];
                         }
 #pragma unroll
                         for( int s = 0; s < BATCH; ++s )
                         {
-                            const float sc = 1.0f / 16777216.0f;
-                            const float wx = (float)( wfx[s] & 0xFFFFFFu ) * sc;
-                            const float wy = (float)( wfy[s] & 0xFFFFFFu ) * sc;
-                            const float wz = (float)( wfz[s] & 0xFFFFFFu ) * sc;
-                            e[s] = vrc_classify( lut, vrc_trilerp( t[s], wx, wy, wz ), cls );
+                            const bool on = act[s] && !done;
+                            vrc_composite( color, e[s], !on );
+                            if( COUNT )
+                                nSamples += on ? 1u : 0u;
+                            done = done || ( on && color.w > VRC_EARLY_EXIT );
                         }
-                    }
-                    else
-                    {
-                        uint32_t d[BATCH];
-#pragma unroll
-                        for( int s = 0; s < BATCH; ++s )
-                            d[s] = (uint32_t)region[a[s]];
-#pragma unroll
-                        for( int s = 0; s < BATCH; ++s )
-                            e[s] = lut[act[s] ? d[s] : 256u];
-                    }
-#pragma unroll
-                    for( int s = 0; s < BATCH; ++s )
-                    {
-                        const bool on = act[s] && !done;
-                        vrc_composite( color, e[s], !on );
-                        if( COUNT )
-                            nSamples += on ? 1u : 0u;
-                        done = done || ( on && color.w > VRC_EARLY_EXIT );
                     }
                 }
+            };
+            const bool fastRound =
+                g == VRC_LDS_G &&
+                __builtin_amdgcn_ballot_w64( part && !( travel > stepSize * (float)( VRC_LDS_G + 1 ) ) ) == 0ull;
+            if( fastRound )
+            {
+                if( part ) /* the lanes outside the box keep their state */
+                    marchLds( std::true_type() );
             }
+            else
+                marchLds( std::false_type() );
             /* ---- the other lanes with a segment: same steps by gathers from the atlas ------ */
             const bool strag = hasSeg && !part;
             if( __builtin_amdgcn_ballot_w64( strag ) != 0ull )
