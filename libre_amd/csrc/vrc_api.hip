@@ -38,6 +38,7 @@ int fail( int code, const std::string& msg )
     } while( 0 )
 
 constexpr int kStagingSlots = 8;
+constexpr int kNodeStages = 4;
 } // namespace
 
 struct vrc_pool
@@ -112,8 +113,14 @@ struct vrc_ctx
     size_t dNodesCap = 0;
     int32_t* dGrid = nullptr;
     size_t dGridCap = 0;
-    void* hStage = nullptr; /* pinned staging for nodes + grid */
+    /* pinned staging for nodes + grid: a ring of kNodeStages areas of hStageCap bytes, each with
+     * the event of the copies last issued from it, so a changed node list (a moving camera
+     * re-sorts the bricks) does not have to wait for the frames still in the stream */
+    void* hStage = nullptr;
     size_t hStageCap = 0;
+    hipEvent_t stageEvent[4] = { nullptr, nullptr, nullptr, nullptr };
+    bool stageUsed[4] = { false, false, false, false };
+    uint32_t stageNext = 0;
     std::vector< vrc_node_data > cachedNodes;
     uint64_t cachedPoolUid = 0;
     bool cachedGridOk = false;
@@ -215,6 +222,8 @@ void vrc_ctx_destroy( vrc_ctx* c )
     if( c->dNodes ) (void)hipFree( c->dNodes );
     if( c->dGrid ) (void)hipFree( c->dGrid );
     if( c->hStage ) (void)hipHostFree( c->hStage );
+    for( hipEvent_t e : c->stageEvent )
+        if( e ) (void)hipEventDestroy( e );
     if( c->dTileOrder ) (void)hipFree( c->dTileOrder );
     if( c->dRowMap ) (void)hipFree( c->dRowMap );
     if( c->dCounter ) (void)hipFree( c->dCounter );
@@ -844,9 +853,11 @@ static int ensure_capacity( vrc_ctx* c, size_t nNodes, size_t nGrid )
         if( c->hStage ) VRC_HIP_CHECK( hipHostFree( c->hStage ) );
         c->hStage = nullptr;
         c->hStageCap = 0;
-        const size_t cap = std::max< size_t >( stageBytes, 1 << 20 );
-        VRC_HIP_CHECK( hipHostMalloc( &c->hStage, cap ) );
+        const size_t cap = ( std::max< size_t >( stageBytes, 1 << 18 ) + 255 ) / 256 * 256;
+        VRC_HIP_CHECK( hipHostMalloc( &c->hStage, cap * kNodeStages ) );
         c->hStageCap = cap;
+        for( int i = 0; i < kNodeStages; ++i )
+            c->stageUsed[i] = false;
     }
     return VRC_OK;
 }
@@ -913,8 +924,12 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         const int rc = ensure_capacity( c, t.nodes.size(), t.grid.size() );
         if( rc != VRC_OK )
             return rc;
-        VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) ); /* staging buffer reuse */
-        uint8_t* h = (uint8_t*)c->hStage;
+        const uint32_t stage = c->stageNext++ % kNodeStages;
+        if( c->stageUsed[stage] ) /* the copies issued from this area four node lists ago */
+            VRC_HIP_CHECK( hipEventSynchronize( c->stageEvent[stage] ) );
+        if( !c->stageEvent[stage] )
+            VRC_HIP_CHECK( hipEventCreateWithFlags( &c->stageEvent[stage], hipEventDisableTiming ) );
+        uint8_t* h = (uint8_t*)c->hStage + (size_t)stage * c->hStageCap;
         const size_t nb = t.nodes.size() * sizeof( vrc_dev_node );
         const size_t gb = t.grid.size() * sizeof( int32_t );
         std::memcpy( h, t.nodes.data(), nb );
@@ -925,6 +940,8 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
             VRC_HIP_CHECK(
                 hipMemcpyAsync( c->dGrid, h + nb, gb, hipMemcpyHostToDevice, c->stream ) );
         }
+        VRC_HIP_CHECK( hipEventRecord( c->stageEvent[stage], c->stream ) );
+        c->stageUsed[stage] = true;
         c->cachedNodes.assign( nodes, nodes + nNodes );
         c->cachedPoolUid = pool->uid;
         c->cachedGridOk = t.gridOk;
