@@ -657,16 +657,21 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
         }
     }
 
-    /* tail: general form */
+    /* tail: general form, in smaller groups (fewer slots wasted on steps no lane takes) */
+#if defined( VRC_TAIL_GROUP )
+    constexpr int TAILG = VRC_TAIL_GROUP;
+#else
+    constexpr int TAILG = GROUP / 2; /* measured on C2: 0.500 -> 0.491 ms against tail groups of GROUP */
+#endif
     while( travel > 0.0f && !done )
     {
-        uint32_t idx[GROUP], d[GROUP], cnt = 0;
+        uint32_t idx[TAILG], d[TAILG], cnt = 0;
         if( FIXED )
-            vrc_group_indices_fixed< GROUP >( sm, fp, idx );
+            vrc_group_indices_fixed< TAILG >( sm, fp, idx );
         else
-            vrc_group_indices< CLAMP, GROUP >( sm, pos, s.step, idx );
+            vrc_group_indices< CLAMP, TAILG >( sm, pos, s.step, idx );
 #pragma unroll
-        for( int k = 0; k < GROUP; ++k )
+        for( int k = 0; k < TAILG; ++k )
         {
             const bool v = travel > 0.0f;
             cnt += v ? 1u : 0u;
@@ -674,14 +679,14 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
             travel -= stepSize;
         }
 #pragma unroll
-        for( int k = 0; k < GROUP; ++k )
+        for( int k = 0; k < TAILG; ++k )
             d[k] = (uint32_t)atlas[idx[k]];
-        vrc_f4 e[GROUP];
+        vrc_f4 e[TAILG];
 #pragma unroll
-        for( int k = 0; k < GROUP; ++k )
+        for( int k = 0; k < TAILG; ++k )
             e[k] = lut[(uint32_t)k < cnt ? d[k] : 256u];
 #pragma unroll
-        for( int k = 0; k < GROUP; ++k )
+        for( int k = 0; k < TAILG; ++k )
         {
             const bool active = ( (uint32_t)k < cnt ) && !done;
             vrc_composite( color, e[k], done );
