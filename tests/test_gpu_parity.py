@@ -287,6 +287,26 @@ def test_c2_full_size_rows_and_properties(vrc):
     assert abs(n_want * 64 - n_got) <= 0.03 * n_got
 
 
+def test_c2_full_size_rows_of_the_other_modes(vrc):
+    # BASELINE C2 at full size for the glRaycaster variant, the trilinear filter (LDS kernel) and
+    # the gather form of the trilinear filter: every 128th row against the oracle
+    s = orc.build_scene(voxels=(1024, 1024, 1024), block=128, viewport=(1024, 1024))
+    rows = (0, 1024, 128)
+    want_gl, _ = orc.oracle_render(s, threads=16, rows=rows, variant=1)
+    want_lin, _ = orc.oracle_render(s, threads=16, rows=rows, filter_mode=1)
+    with _gpu(s) as g:
+        gl, _, st = g.render(variant=vrc.VARIANT_GLRAYCASTER)
+        assert st.kernel_variant == vrc.KERNEL_GRID_DDA
+        lin, n_lin, st = g.render(filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_LDS
+        lin_gather, n_gather, st = g.render(kernel=vrc.KERNEL_GRID_DDA, filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_GRID_DDA
+    scenes.assert_parity(gl[::128], want_gl[::128], "C2 rows, glRaycaster variant")
+    scenes.assert_parity(lin[::128], want_lin[::128], "C2 rows, trilinear (LDS kernel)")
+    scenes.assert_parity(lin_gather, lin, "C2 trilinear: gather form vs LDS form")
+    assert abs(n_lin - n_gather) <= 2e-4 * n_lin
+
+
 def test_c1_config_parity(vrc):
     # mem://#128,128,128,32, 512^2 viewport, 512 samples/ray, 64 leaf bricks
     s = orc.build_scene(voxels=(128, 128, 128), block=32, viewport=(512, 512))
