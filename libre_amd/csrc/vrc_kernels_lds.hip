@@ -191,8 +191,15 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                               f.gridMin[2] + f.cellSize[2] * (float)f.gridDim[2] };
         float t0;
         const bool any = vrc_intersect_box( r.origin, r.invDir, gmin, gmax, &t0, &t1 );
-        t0 = fmaxf( fmaxf( t0, r.tNearGlobal ), fmaxf( r.tNearPlane, 0.0f ) );
-        t1 = fminf( t1, r.tFarGlobal );
+        /* the GLSL twin does not clamp a brick's interval to the global box (fragRaycast.glsl:149-150):
+         * bricks of the tree that reach past the volume (ragged trees) are sampled there too */
+        if( f.variant == VRC_VARIANT_GL )
+            t0 = fmaxf( t0, fmaxf( r.tNearPlane, 0.0f ) );
+        else
+        {
+            t0 = fmaxf( fmaxf( t0, r.tNearGlobal ), fmaxf( r.tNearPlane, 0.0f ) );
+            t1 = fminf( t1, r.tFarGlobal );
+        }
         if( !( any && t0 <= t1 ) )
             done = true;
         else

@@ -307,6 +307,29 @@ def test_c2_full_size_rows_of_the_other_modes(vrc):
     assert abs(n_lin - n_gather) <= 2e-4 * n_lin
 
 
+@pytest.mark.parametrize("seed", range(32))
+def test_random_views_all_gpu_kernels_match_the_oracle(vrc, seed):
+    # the fuzz of tests/test_cpu_harness.py on the device: random volumes, cameras (also inside
+    # the volume), clip planes, viewports, step sizes; gather and LDS kernels, both filters,
+    # both reference variants
+    from test_cpu_harness import _fuzz_scene, _fuzz_parity
+    rng = np.random.default_rng(1000 + seed)
+    kw = _fuzz_scene(rng)
+    s = orc.build_scene(**kw)
+    want, n_want = orc.oracle_render(s, threads=8)
+    want_lin, _ = orc.oracle_render(s, threads=8, filter_mode=1)
+    want_gl, _ = orc.oracle_render(s, threads=8, variant=1)
+    with _gpu(s) as g:
+        for k in (vrc.KERNEL_REFERENCE_ORDER, vrc.KERNEL_GRID_DDA, vrc.KERNEL_LDS):
+            got, n_got, _ = g.render(kernel=k)
+            _fuzz_parity(got, want, "seed %d k%d %r" % (seed, k, kw))
+            assert abs(n_got - n_want) <= 3e-4 * n_want + 16, (seed, k, kw)
+            got, _, _ = g.render(kernel=k, filter_mode=vrc.FILTER_TRILINEAR)
+            _fuzz_parity(got, want_lin, "seed %d k%d trilinear %r" % (seed, k, kw))
+            got, _, _ = g.render(kernel=k, variant=vrc.VARIANT_GLRAYCASTER)
+            _fuzz_parity(got, want_gl, "seed %d k%d glRaycaster %r" % (seed, k, kw))
+
+
 def test_c1_config_parity(vrc):
     # mem://#128,128,128,32, 512^2 viewport, 512 samples/ray, 64 leaf bricks
     s = orc.build_scene(voxels=(128, 128, 128), block=32, viewport=(512, 512))
