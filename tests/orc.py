@@ -250,11 +250,13 @@ def hash_volume(vx, vy, vz, seed=0x5EED):
 
 def brick_from_volume(vol, vi, node):
     """Cut brick + overlap out of a full-resolution volume (z,y,x order), clamping at the
-    volume border (what a bricking data source does)."""
+    volume border (what a bricking data source does).  A node above the finest level takes
+    every 2^k-th voxel (the hash:// source of the host library does the same)."""
     ov = [vi.overlap[a] for a in range(3)]
+    shift = int(vi.depth) - 1 - int(unpack(node.nodeId)[0])
     lo = [int(node.voxelBoxMin[a]) - ov[a] for a in range(3)]
     hi = [int(node.voxelBoxMax[a]) + ov[a] for a in range(3)]
-    ix = [np.clip(np.arange(lo[a], hi[a]), 0, vol.shape[2 - a] - 1) for a in range(3)]
+    ix = [np.clip(np.arange(lo[a], hi[a]) << shift, 0, vol.shape[2 - a] - 1) for a in range(3)]
     return np.ascontiguousarray(vol[np.ix_(ix[2], ix[1], ix[0])])
 
 
