@@ -330,6 +330,35 @@ def test_random_views_all_gpu_kernels_match_the_oracle(vrc, seed):
             _fuzz_parity(got, want_gl, "seed %d k%d glRaycaster %r" % (seed, k, kw))
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_views_uint16_and_multipass(vrc, seed):
+    # the same fuzz for 16-bit volumes (gather kernels, per-sample classification) and for frames
+    # rendered in several passes over random splits of the brick list (accumulating pixel buffer)
+    from test_cpu_harness import _fuzz_scene, _fuzz_parity
+    rng = np.random.default_rng(5000 + seed)
+    kw = _fuzz_scene(rng)
+    kw["volume"] = "hash"
+    kw16 = dict(kw, dtype="u16")
+    s16 = orc.build_scene(**kw16)
+    want16, n16 = orc.oracle_render(s16, threads=8)
+    want16_lin, _ = orc.oracle_render(s16, threads=8, filter_mode=1)
+    with _gpu(s16) as g:
+        for k in (vrc.KERNEL_REFERENCE_ORDER, vrc.KERNEL_GRID_DDA):
+            got, n_got, _ = g.render(kernel=k)
+            _fuzz_parity(got, want16, "seed %d u16 k%d %r" % (seed, k, kw))
+            assert abs(n_got - n16) <= 3e-4 * n16 + 16
+            got, _, _ = g.render(kernel=k, filter_mode=vrc.FILTER_TRILINEAR)
+            _fuzz_parity(got, want16_lin, "seed %d u16 trilinear k%d %r" % (seed, k, kw))
+    s = orc.build_scene(**kw)
+    want, n_want = orc.oracle_render(s, threads=8)
+    cuts = sorted(set(int(c) for c in rng.integers(1, max(2, s.n_nodes), size=3)) | {0, s.n_nodes})
+    passes = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+    with _gpu(s) as g:
+        for k in (vrc.KERNEL_REFERENCE_ORDER, vrc.KERNEL_GRID_DDA, vrc.KERNEL_LDS):
+            got, n_got, _ = g.render(kernel=k, passes=passes)
+            _fuzz_parity(got, want, "seed %d multipass %r k%d %r" % (seed, passes, k, kw))
+
+
 def test_c1_config_parity(vrc):
     # mem://#128,128,128,32, 512^2 viewport, 512 samples/ray, 64 leaf bricks
     s = orc.build_scene(voxels=(128, 128, 128), block=32, viewport=(512, 512))
