@@ -379,3 +379,45 @@ def test_random_lod_cuts_through_the_plugin_match_the_oracle(drv, seed):
             "seed %d %s eye %r spin %r sse %g levels %r: max %.3g mean %.3g over %.4f" % (
                 seed, uri, eye, spin, sse, sorted({i & 0xF for i in ids}), mx, mean, over))
         assert abs(int(app.stats().samples) - n_want) <= 5e-4 * n_want + 16
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_sort_first_layouts_reassemble_the_frame(drv, seed):
+    # every rank of a random sort-first layout renders its bands in one launch; the assembled
+    # frame must be the full frame bit for bit -- point sampled, trilinear (LDS kernel) and with
+    # the glRaycaster rules
+    from libre_amd import sortfirst, vrc
+    rng = np.random.default_rng(9000 + seed)
+    W, H = int(rng.integers(16, 56)), int(rng.integers(24, 72))
+    world = int(rng.choice([2, 3, 4, 8]))
+    bpr = int(rng.choice([1, 2, 4]))
+    spin = (float(rng.uniform(-3.1, 3.1)), float(rng.uniform(-1.2, 1.2)))
+    mode = int(rng.integers(0, 3))  # 0 point, 1 trilinear, 2 glRaycaster
+    kw = dict(synchronous=True, min_lod=2, max_lod=2, gpu_cache_mb=8)
+
+    def setup(app):
+        app.set_camera(spin=spin)
+        app.set_colormap(orc.linear_ramp_tf(0.3))
+        if mode == 1:
+            app.set_option(vrc.OPT_FILTER, vrc.FILTER_TRILINEAR)
+        if mode == 2:
+            app.set_option(vrc.OPT_VARIANT, vrc.VARIANT_GLRAYCASTER)
+
+    with drv.App("hash://#64,64,64,16", W, H, **kw) as full_app:
+        setup(full_app)
+        full, _ = full_app.render_frame()
+    assert full[..., 3].max() > 0.05
+    layout = sortfirst.band_layout(H, world, bpr)
+    out = np.full_like(full, -1.0)
+    with drv.App("hash://#64,64,64,16", W, H, **kw) as app:
+        setup(app)
+        for bands in layout:
+            if not bands:
+                continue
+            app.set_bands(bands)
+            fb, _ = app.render_frame()
+            off = 0
+            for (y0, h) in bands:
+                out[y0:y0 + h] = fb[off:off + h]
+                off += h
+    assert (out == full).all(), (seed, W, H, world, bpr, mode)
