@@ -15,6 +15,7 @@
  *     one global_load_dwordx4 + one ds_write2_b64 per lane and z-slice), and the samples are
  *     taken from LDS with a linear address (z*PZ + y*PY + x, compile-time pitches, so the
  *     eight trilinear taps are immediate offsets of one address);
+ *   - the region comes in two shapes (flat 32x24x11; deeper 32x20x16 for views along y);
  *   - a box that does not fit the LDS region halves the round (8,4,2,1 steps) and then the
  *     lane set (half tile, quarter tile, 2x2 quad, single lane), so any view is handled.
  *
@@ -29,13 +30,22 @@
  */
 #include "vrc_internal.h"
 
+#include <cstdlib>
 #include <type_traits>
 
-#define VRC_LDS_PY 32u                           /* row pitch = max x extent of a region */
-#define VRC_LDS_RY 24u                           /* max y extent */
-#define VRC_LDS_PZ ( VRC_LDS_PY * VRC_LDS_RY )   /* slice pitch */
-#define VRC_LDS_RZ 11u                           /* max z extent */
-#define VRC_LDS_REGION ( VRC_LDS_PZ * VRC_LDS_RZ )
+/* LDS region of one wave: PY = row pitch = max x extent (a multiple of 8), RY / RZ = max y / z
+ * extent, bytes = PY*RY*RZ.  Two shapes, picked per frame from the view direction in volume space
+ * (vrc_launch_raycast_lds): the flat one by default, the deeper one for views within ~20 degrees
+ * of the y axis, the only ones it helps (measured, C2 trilinear, ms per frame flat / deep: along z
+ * 2.46 / 2.71, along y 3.36 / 3.07, along x 3.59 / 3.72, 30/20 degrees off axis 3.59 / 4.17). */
+struct vrc_lds_shape_flat
+{
+    static constexpr uint32_t PY = 32u, RY = 24u, RZ = 11u, PZ = PY * RY, REGION = PZ * RZ;
+};
+struct vrc_lds_shape_deep
+{
+    static constexpr uint32_t PY = 32u, RY = 20u, RZ = 16u, PZ = PY * RY, REGION = PZ * RZ;
+};
 #ifndef VRC_LDS_WAVES
 #define VRC_LDS_WAVES 4u
 #endif
@@ -95,7 +105,7 @@ __device__ __forceinline__ uint32_t wave_reduce( uint32_t v )
 }
 
 /* copy N z-slices of the box: per lane one 16-byte piece (two 8-voxel rows) per slice */
-template < int N >
+template < typename S, int N >
 __device__ __forceinline__ void lds_stage( const uint8_t* __restrict__ slotPtr, uint32_t partial,
                                            uint32_t sliceStride, uint32_t z0, uint32_t dz, bool on,
                                            uint8_t* dst )
@@ -114,8 +124,11 @@ __device__ __forceinline__ void lds_stage( const uint8_t* __restrict__ slotPtr, 
 #pragma unroll
     for( int z = 0; z < N; ++z )
     {
-        *reinterpret_cast< uint2* >( dst + z * VRC_LDS_PZ ) = make_uint2( v[z].x, v[z].y );
-        *reinterpret_cast< uint2* >( dst + z * VRC_LDS_PZ + VRC_LDS_PY ) = make_uint2( v[z].z, v[z].w );
+        if( (uint32_t)z < dz ) /* wave-uniform; never write past the box (the region ends with it) */
+        {
+            *reinterpret_cast< uint2* >( dst + z * S::PZ ) = make_uint2( v[z].x, v[z].y );
+            *reinterpret_cast< uint2* >( dst + z * S::PZ + S::PY ) = make_uint2( v[z].z, v[z].w );
+        }
     }
 }
 
@@ -126,7 +139,7 @@ struct lds_box
 };
 }
 
-template < bool COUNT, bool LINEAR >
+template < bool COUNT, bool LINEAR, typename S >
 __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ gridTable, const uint8_t* __restrict__ atlas,
@@ -135,7 +148,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
     const uint32_t* __restrict__ tileOrder, const uint32_t tilesX, const uint32_t nTiles )
 {
     __shared__ vrc_f4 lut[VRC_TFP_ENTRIES];
-    __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t regions[VRC_LDS_WAVES][VRC_LDS_REGION];
+    __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t regions[VRC_LDS_WAVES][S::REGION];
 
     for( uint32_t i = threadIdx.x; i < VRC_TFP_ENTRIES; i += 64u * VRC_LDS_WAVES )
         lut[i] = lutGlobal[i];
@@ -236,7 +249,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
 
     /* staging role of the lane: 4 row-pairs across (x), 16 down (y) per z-slice */
     const uint32_t sxr = lane & 3u, syp = lane >> 2;
-    const uint32_t ldsLane = syp * 2u * VRC_LDS_PY + sxr * 8u;
+    const uint32_t ldsLane = syp * 2u * S::PY + sxr * 8u;
     const uint32_t sliceStride = f.sbx * f.sby * VRC_MB_VOXELS;
 
     for( ;; )
@@ -365,8 +378,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                 loy = loy < hiy ? loy : hiy;
                 loz = loz < hiz ? loz : hiz;
                 /* x origin is aligned down to 8, y origin to 2 */
-                const bool ownFit = hix - ( lox & ~7u ) < VRC_LDS_PY && hiy - ( loy & ~1u ) < VRC_LDS_RY &&
-                                    hiz - loz < VRC_LDS_RZ;
+                const bool ownFit = hix - ( lox & ~7u ) < S::PY && hiy - ( loy & ~1u ) < S::RY &&
+                                    hiz - loz < S::RZ;
                 const bool leadFit = ( __builtin_amdgcn_ballot_w64( ownFit ) >> lead ) & 1ull;
                 if( leadFit || g == 1 )
                 {
@@ -392,7 +405,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                 box.dy = mxy - box.y0 + 1u;
                 box.dz = mxz - box.z0 + 1u;
                 VRC_LDS_STAT( 3, 1 )
-                if( ( box.dx <= VRC_LDS_PY && box.dy <= VRC_LDS_RY && box.dz <= VRC_LDS_RZ ) || windowed )
+                if( ( box.dx <= S::PY && box.dy <= S::RY && box.dz <= S::RZ ) || windowed )
                     break;
                 /* The lanes of the brick are too far apart (rays that entered it through
                  * different faces are at different depths): keep the lanes whose footprint
@@ -405,14 +418,14 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                 const uint32_t llz = (uint32_t)__builtin_amdgcn_readlane( (int)loz, lead );
                 const uint32_t lhz = (uint32_t)__builtin_amdgcn_readlane( (int)hiz, lead );
                 const uint32_t ex_ = lhx - llx + 1u, ey_ = lhy - lly + 1u, ez_ = lhz - llz + 1u;
-                const uint32_t sx = ex_ < VRC_LDS_PY - 7u ? ( VRC_LDS_PY - 7u - ex_ ) / 2u : 0u;
-                const uint32_t sy = ey_ < VRC_LDS_RY - 1u ? ( VRC_LDS_RY - 1u - ey_ ) / 2u : 0u;
-                const uint32_t sz = ez_ < VRC_LDS_RZ ? ( VRC_LDS_RZ - ez_ ) / 2u : 0u;
+                const uint32_t sx = ex_ < S::PY - 7u ? ( S::PY - 7u - ex_ ) / 2u : 0u;
+                const uint32_t sy = ey_ < S::RY - 1u ? ( S::RY - 1u - ey_ ) / 2u : 0u;
+                const uint32_t sz = ez_ < S::RZ ? ( S::RZ - ez_ ) / 2u : 0u;
                 const uint32_t wx0 = ( llx - ( llx < sx ? llx : sx ) ) & ~7u;
                 const uint32_t wy0 = ( lly - ( lly < sy ? lly : sy ) ) & ~1u;
                 const uint32_t wz0 = llz - ( llz < sz ? llz : sz );
-                part = part && lox >= wx0 && hix < wx0 + VRC_LDS_PY && loy >= wy0 &&
-                       hiy < wy0 + VRC_LDS_RY && loz >= wz0 && hiz < wz0 + VRC_LDS_RZ;
+                part = part && lox >= wx0 && hix < wx0 + S::PY && loy >= wy0 &&
+                       hiy < wy0 + S::RY && loz >= wz0 && hiz < wz0 + S::RZ;
                 windowed = true;
             }
 
@@ -436,16 +449,23 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                 /* every slice load of the round is issued before the first LDS write; slices
                  * past the box repeat its last slice (branch-free, same cache lines) */
                 if( box.dz <= 8u )
-                    lds_stage< 8 >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst );
+                    lds_stage< S, 8 >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst );
+                else if( box.dz <= 11u )
+                    lds_stage< S, 11 >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst );
                 else
-                    lds_stage< (int)VRC_LDS_RZ >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst );
+                {
+                    /* deep boxes (S::RZ > 11) in two halves: at most 11 loads in flight */
+                    const uint32_t h = ( box.dz + 1u ) / 2u;
+                    lds_stage< S, 11 >( slotPtr, partial, sliceStride, box.z0, h, on, dst );
+                    lds_stage< S, 11 >( slotPtr, partial, sliceStride, box.z0 + h, box.dz - h, on, dst + h * S::PZ );
+                }
             }
             /* a wave's LDS accesses complete in issue order, so its own region needs no
              * s_barrier; the compiler must still not move the reads above the copies */
             __builtin_amdgcn_wave_barrier();
 
             /* ---- march g steps from LDS ---------------------------------------------------- */
-            const uint32_t bias = box.z0 * VRC_LDS_PZ + box.y0 * VRC_LDS_PY + box.x0;
+            const uint32_t bias = box.z0 * S::PZ + box.y0 * S::PY + box.x0;
             constexpr int BATCH = LINEAR ? 4 : VRC_LDS_G;
             /* FASTR: a full round (g = VRC_LDS_G) in which every participating lane has more than
              * g steps left: no per-step "does this lane take this step" selects */
@@ -464,7 +484,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                         {
                             const bool take = FASTR ? true : ( part && ( b0 + s < g ) );
                             act[s] = FASTR ? true : ( take && travel > 0.0f );
-                            const uint32_t av = ( fz >> 24 ) * VRC_LDS_PZ + ( fy >> 24 ) * VRC_LDS_PY +
+                            const uint32_t av = ( fz >> 24 ) * S::PZ + ( fy >> 24 ) * S::PY +
                                                 ( fx >> 24 ) - bias;
                             a[s] = act[s] ? av : 0u;
                             wfx[s] = fx;
@@ -485,12 +505,12 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                                 const uint8_t* const p = region + a[s];
                                 t[s][0] = (float)p[0];
                                 t[s][1] = (float)p[1];
-                                t[s][2] = (float)p[VRC_LDS_PY];
-                                t[s][3] = (float)p[VRC_LDS_PY + 1u];
-                                t[s][4] = (float)p[VRC_LDS_PZ];
-                                t[s][5] = (float)p[VRC_LDS_PZ + 1u];
-                                t[s][6] = (float)p[VRC_LDS_PZ + VRC_LDS_PY];
-                                t[s][7] = (float)p[VRC_LDS_PZ + VRC_LDS_PY + 1u];
+                                t[s][2] = (float)p[S::PY];
+                                t[s][3] = (float)p[S::PY + 1u];
+                                t[s][4] = (float)p[S::PZ];
+                                t[s][5] = (float)p[S::PZ + 1u];
+                                t[s][6] = (float)p[S::PZ + S::PY];
+                                t[s][7] = (float)p[S::PZ + S::PY + 1u];
                             }
 #pragma unroll
                             for( int s = 0; s < BATCH; ++s )
@@ -656,18 +676,29 @@ hipError_t vrc_launch_raycast_lds( const vrc_raycast_args& a, hipStream_t stream
         return hipSuccess;
     const dim3 grid( ( nTiles + VRC_LDS_WAVES - 1u ) / VRC_LDS_WAVES ), block( 64u * VRC_LDS_WAVES );
     const bool count = a.sampleCounter != nullptr;
-#define VRC_LDS_LAUNCH( COUNT, LINEAR )                                                         \
-    hipLaunchKernelGGL( ( vrc_k_raycast_lds< COUNT, LINEAR > ), grid, block, 0, stream, a.frame, \
-                        a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut, a.classifier,      \
+    /* region shape from the view direction in volume space (the ray through the frame centre) */
+    const vrc_ray centre = vrc_setup_ray( a.frame, a.frame.width / 2u, (uint32_t)( a.frame.vpH * 0.5f ) );
+    bool flat = fabsf( centre.dir.y ) <= 0.94f;
+    if( const char* force = getenv( "VRC_LDS_SHAPE" ) ) /* A/B measurements only (tools/dev_bench.py) */
+        flat = force[0] == 'f';
+#define VRC_LDS_LAUNCH( COUNT, LINEAR, SHAPE )                                                        \
+    hipLaunchKernelGGL( ( vrc_k_raycast_lds< COUNT, LINEAR, SHAPE > ), grid, block, 0, stream, a.frame, \
+                        a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut, a.classifier,            \
                         a.pixelBuffer, a.sampleCounter, a.tileOrder, tilesX, nTiles )
+#define VRC_LDS_LAUNCH_SHAPE( COUNT, LINEAR )                         \
+    {                                                                 \
+        if( flat ) VRC_LDS_LAUNCH( COUNT, LINEAR, vrc_lds_shape_flat ); \
+        else VRC_LDS_LAUNCH( COUNT, LINEAR, vrc_lds_shape_deep );       \
+    }
     if( a.linear )
     {
-        if( count ) VRC_LDS_LAUNCH( true, true ); else VRC_LDS_LAUNCH( false, true );
+        if( count ) VRC_LDS_LAUNCH_SHAPE( true, true ) else VRC_LDS_LAUNCH_SHAPE( false, true )
     }
     else
     {
-        if( count ) VRC_LDS_LAUNCH( true, false ); else VRC_LDS_LAUNCH( false, false );
+        if( count ) VRC_LDS_LAUNCH_SHAPE( true, false ) else VRC_LDS_LAUNCH_SHAPE( false, false )
     }
+#undef VRC_LDS_LAUNCH_SHAPE
 #undef VRC_LDS_LAUNCH
     return hipGetLastError();
 }

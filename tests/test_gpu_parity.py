@@ -125,6 +125,30 @@ def test_lds_staged_kernel_parity(vrc, name):
         assert (auto == lin).all()
 
 
+@pytest.mark.parametrize("spin", [(0.0, 0.0), (1.5708, 0.0), (1.40, 0.12), (-1.5, 0.3), (0.0, 1.5708),
+                                  (0.3, 1.45), (0.7854, 0.7854)])
+def test_lds_region_shapes_by_view_axis(vrc, spin):
+    # the LDS kernel picks its region shape (32x24x11 / 32x20x16) from the view direction: views
+    # along each volume axis and near the switch-over, against the gather kernel (same sample
+    # sequence, so same sample count and frame) and the oracle; boxes deeper than 11 slices take
+    # the two-halves staging path of the deep shape
+    s = orc.build_scene(voxels=(96, 80, 112), block=16, viewport=(160, 128), volume="hash", spin=spin)
+    want, n_want = orc.oracle_render(s, threads=8)
+    want_lin, n_want_lin = orc.oracle_render(s, threads=8, filter_mode=1)
+    with _gpu(s) as g:
+        got, n_got, _ = g.render(kernel=vrc.KERNEL_LDS)
+        dda, n_dda, _ = g.render(kernel=vrc.KERNEL_GRID_DDA)
+        assert n_got == n_dda
+        assert np.abs(got - dda).max() <= 1e-6
+        scenes.assert_parity(got, want, "lds nearest spin %s" % (spin,))
+        lin, n_lin, _ = g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
+        gat, n_gat, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, filter_mode=vrc.FILTER_TRILINEAR)
+        assert n_lin == n_gat
+        assert np.abs(lin - gat).max() <= 1e-5  # same taps, fma contraction may differ
+        scenes.assert_parity(lin, want_lin, "lds trilinear spin %s" % (spin,))
+        assert abs(n_lin - n_want_lin) <= 2e-4 * n_want_lin + 8
+
+
 def test_lds_kernel_refuses_clamped_sampler(vrc):
     s = scenes.nucleon_scene()
     with _gpu(s) as g:
