@@ -109,6 +109,7 @@ typedef struct
 #define VRC_KERNEL_GRID_DDA 2        /* 3-D DDA over the brick grid; needs a grid-aligned node set */
 #define VRC_KERNEL_LDS 3             /* grid DDA + voxels staged through LDS per wave and round (needs
                                       * overlap >= 1); what AUTO picks for the trilinear filter */
+#define VRC_KERNEL_RAY_LOD 4         /* reported by vrc_get_stats when vrc_set_ray_lod is on; not selectable */
 
 /* ---- context ---------------------------------------------------------------------------- */
 /* cuda::Renderer::Renderer() (cuda/Renderer.cu:234-238); device is explicit (fixes Q11) */
@@ -118,6 +119,17 @@ void vrc_ctx_destroy( vrc_ctx* ctx );
 int vrc_ctx_set_stream( vrc_ctx* ctx, void* hip_stream );
 int vrc_set_option( vrc_ctx* ctx, int option, int64_t value );
 int vrc_get_option( vrc_ctx* ctx, int option, int64_t* value );
+/* EXTENSION (BASELINE C5): per-ray adaptive LOD.  The reference selects the LOD per brick on the host
+ * (livre/core/render/SelectVisibles.cpp:52-68: a brick is fine enough when
+ * worldSpacePerVoxel / worldSpacePerPixel * near / (near + distance) <= screenSpaceError at the
+ * point of its box nearest to the near plane).  With this on, the node list of vrc_render is a
+ * hierarchy of resident bricks (a cut of the octree plus any of its ancestors; boxes of different
+ * levels nest, boxes of one level do not overlap, all aligned to the smallest box) and every ray
+ * applies that criterion at each brick-sized cell it enters: it samples the coarsest level that is
+ * fine enough there (else the next coarser one present, else the next finer), with step and
+ * opacity exponent scaled by 2^level.  world_space_per_pixel = (frustum.top - frustum.bottom) /
+ * window height, as in SelectVisibles.cpp:57.  cudaRaycaster variant only. */
+int vrc_set_ray_lod( vrc_ctx* ctx, int enable, float screen_space_error, float world_space_per_pixel );
 
 /* ---- texture pool (brick atlas) ----------------------------------------------------------- */
 /* cuda::TexturePool::TexturePool (cuda/TexturePool.cu:101-173).  max_block is the slot size

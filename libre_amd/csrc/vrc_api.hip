@@ -100,6 +100,7 @@ struct vrc_ctx
     uint64_t lutTfVersion = 0;
     vrc_lut_params lutParams = { 0, 0, 0, 0 };
     bool lutLinear = false;
+    uint32_t lutLevels = 1;
 
     /* pixel buffer (cuda::PixelBufferObject) */
     vrc_f4* fbOwn = nullptr;
@@ -124,6 +125,10 @@ struct vrc_ctx
     std::vector< vrc_node_data > cachedNodes;
     uint64_t cachedPoolUid = 0;
     bool cachedGridOk = false;
+    bool cachedRayLod = false; /* tables are per-level (vrc_build_lod_tables) */
+    bool cachedLodOk = false;
+    uint32_t cachedLodLevels = 0;
+    double cachedFinestVoxel = 0.0;
     bool cachedClamp = false;
     vrc_frame cachedGridFrame; /* only grid* fields are meaningful */
 
@@ -140,6 +145,8 @@ struct vrc_ctx
     int64_t optTileOrder = 1;
     int64_t optStepping = 1;
     int64_t optVariant = VRC_VARIANT_CUDARAYCASTER;
+    bool rayLod = false; /* vrc_set_ray_lod */
+    float rayLodSse = 1.0f, rayLodWorldPerPixel = 0.0f;
 
     unsigned long long* dCounter = nullptr;
     unsigned long long* hCounter = nullptr; /* pinned */
@@ -178,7 +185,7 @@ int vrc_ctx_create( int device, vrc_ctx** out )
     std::memset( c->planes, 0, sizeof( c->planes ) );
     hipError_t e = hipStreamCreateWithFlags( &c->ownStream, hipStreamNonBlocking );
     if( e == hipSuccess ) e = hipMalloc( &c->dTf, 256 * 4 * sizeof( float ) );
-    if( e == hipSuccess ) e = hipMalloc( &c->dLut, VRC_TFP_ENTRIES * sizeof( vrc_f4 ) );
+    if( e == hipSuccess ) e = hipMalloc( &c->dLut, ( VRC_MAX_LOD_LEVELS * VRC_LUT_ENTRIES + 1u ) * sizeof( vrc_f4 ) );
     if( e == hipSuccess ) e = hipHostMalloc( &c->hTf, 256 * 4 * sizeof( float ) );
     if( e == hipSuccess ) e = hipMalloc( &c->dCounter, sizeof( unsigned long long ) );
     if( e == hipSuccess ) e = hipHostMalloc( &c->hCounter, sizeof( unsigned long long ) );
@@ -295,6 +302,22 @@ int vrc_get_option( vrc_ctx* c, int option, int64_t* value )
     case VRC_OPT_VARIANT: *value = c->optVariant; return VRC_OK;
     default: return fail( VRC_EINVAL, "vrc_get_option: unknown option" );
     }
+}
+
+/* per-ray adaptive LOD (extension): see include/vrc_hip.h */
+int vrc_set_ray_lod( vrc_ctx* c, int enable, float screenSpaceError, float worldSpacePerPixel )
+{
+    if( !c )
+        return fail( VRC_EINVAL, "vrc_set_ray_lod: ctx is NULL" );
+    if( enable && ( !( screenSpaceError > 0.0f ) || !( worldSpacePerPixel > 0.0f ) ) )
+        return fail( VRC_EINVAL, "vrc_set_ray_lod: screen-space error and world space per pixel must be > 0" );
+    c->rayLod = enable != 0;
+    if( enable )
+    {
+        c->rayLodSse = screenSpaceError;
+        c->rayLodWorldPerPixel = worldSpacePerPixel;
+    }
+    return VRC_OK;
 }
 
 /* ---------------------------------------------------------------------------------------- */
@@ -894,12 +917,22 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     /* samples classified one by one (padded transfer function in the table buffer) whenever the
      * 257-entry classified table cannot be used: continuous or 16-bit densities */
     const bool classify = linear || pool->elemBytes != 1;
+    /* per-ray LOD: one classified table per level, opacity exponent doubled per level (a level-j
+     * brick is sampled with step * 2^j); always all levels, so the table does not depend on the list */
+    const uint32_t lutLevels = ( c->rayLod && !classify ) ? (uint32_t)VRC_MAX_LOD_LEVELS : 1u;
     if( !c->lutValid || c->lutTfVersion != c->tfVersion || c->lutLinear != classify ||
-        std::memcmp( &lp, &c->lutParams, sizeof( lp ) ) != 0 )
+        c->lutLevels != lutLevels || std::memcmp( &lp, &c->lutParams, sizeof( lp ) ) != 0 )
     {
-        VRC_HIP_CHECK( vrc_launch_build_lut( c->dTf, c->dLut, lp, classify, c->stream ) );
+        for( uint32_t j = 0; j < lutLevels; ++j )
+        {
+            vrc_lut_params lj = lp;
+            lj.alphaCorrection = lp.alphaCorrection * (float)( 1u << j );
+            VRC_HIP_CHECK( vrc_launch_build_lut( c->dTf, c->dLut + j * VRC_LUT_ENTRIES, lj, classify,
+                                                 c->stream ) );
+        }
         c->lutParams = lp;
         c->lutLinear = classify;
+        c->lutLevels = lutLevels;
         c->lutTfVersion = c->tfVersion;
         c->lutValid = true;
     }
@@ -907,6 +940,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     /* node table + grid, re-derived and re-uploaded only when the node list changed
      * (the reference re-uploads synchronously every pass, Renderer.cu:259-267) */
     const bool sameNodes = c->cachedPoolUid == pool->uid && c->cachedNodes.size() == nNodes &&
+                           c->cachedRayLod == c->rayLod &&
                            std::memcmp( c->cachedNodes.data(), nodes,
                                         nNodes * sizeof( vrc_node_data ) ) == 0;
     if( !sameNodes )
@@ -921,6 +955,8 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         for( int a = 0; a < 3; ++a )
             geom.slots[a] = pool->slots[a];
         vrc_build_tables( geom, nodes, nNodes, t );
+        if( c->rayLod )
+            vrc_build_lod_tables( geom, nodes, nNodes, t );
         const int rc = ensure_capacity( c, t.nodes.size(), t.grid.size() );
         if( rc != VRC_OK )
             return rc;
@@ -944,11 +980,24 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         c->stageUsed[stage] = true;
         c->cachedNodes.assign( nodes, nodes + nNodes );
         c->cachedPoolUid = pool->uid;
-        c->cachedGridOk = t.gridOk;
+        c->cachedGridOk = t.gridOk && !c->rayLod; /* the grid buffer holds the per-level tables */
+        c->cachedRayLod = c->rayLod;
+        c->cachedLodOk = t.lodOk;
+        c->cachedLodLevels = t.lodLevels;
+        c->cachedFinestVoxel = t.finestVoxelWorld;
         c->cachedClamp = t.clamp;
         c->cachedGridFrame = t.g;
     }
 
+    if( c->rayLod )
+    {
+        if( !c->cachedLodOk )
+            return fail( VRC_EINVAL, "vrc_render: per-ray LOD needs a hierarchy of cell-aligned bricks (levels may nest, bricks of one level may not overlap)" );
+        if( c->optVariant != VRC_VARIANT_CUDARAYCASTER )
+            return fail( VRC_EINVAL, "vrc_render: per-ray LOD is defined for the cudaRaycaster variant only" );
+        if( c->optKernel != VRC_KERNEL_AUTO )
+            return fail( VRC_EINVAL, "vrc_render: per-ray LOD has its own kernel; leave VRC_OPT_KERNEL at AUTO" );
+    }
     bool useDda = c->cachedGridOk;
     if( c->optKernel == VRC_KERNEL_REFERENCE_ORDER )
         useDda = false;
@@ -959,8 +1008,8 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     const bool ldsEligible = c->cachedGridOk && !c->cachedClamp && pool->elemBytes == 1;
     if( c->optKernel == VRC_KERNEL_LDS && !ldsEligible )
         return fail( VRC_EINVAL, "vrc_render: the LDS kernel needs a grid-aligned node set of 8-bit bricks with overlap >= 1" );
-    const bool useLds = c->optKernel == VRC_KERNEL_LDS ||
-                        ( c->optKernel == VRC_KERNEL_AUTO && linear && ldsEligible );
+    const bool useLds = !c->rayLod && ( c->optKernel == VRC_KERNEL_LDS ||
+                                        ( c->optKernel == VRC_KERNEL_AUTO && linear && ldsEligible ) );
 
     vrc_raycast_args a;
     std::memset( &a, 0, sizeof( a ) );
@@ -981,6 +1030,12 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
                         c->fbW, c->fbH, centre, centre );
         f.rowMap = c->rowMap.empty() ? nullptr : c->dRowMap;
         f.variant = c->optVariant == VRC_VARIANT_GLRAYCASTER ? VRC_VARIANT_GL : VRC_VARIANT_CUDA;
+        if( c->rayLod )
+        {
+            f.lodLevels = c->cachedLodLevels;
+            f.lodBase = (float)( c->cachedFinestVoxel /
+                                 ( (double)c->rayLodSse * (double)c->rayLodWorldPerPixel ) );
+        }
     }
 
     /* tile schedule, recomputed only when the frame constants changed */
@@ -1016,7 +1071,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     c->clearPending = false;
 
     a.nodes = c->dNodes;
-    a.gridTable = useDda ? c->dGrid : nullptr;
+    a.gridTable = ( useDda || c->rayLod ) ? c->dGrid : nullptr;
     a.atlas = pool->dAtlas;
     a.lut = c->dLut;
     a.pixelBuffer = ctx_fb( c );
@@ -1050,7 +1105,9 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     }
     const auto& evp = c->evPairs[c->evUsed++];
     VRC_HIP_CHECK( hipEventRecord( evp.first, c->stream ) );
-    VRC_HIP_CHECK( useLds ? vrc_launch_raycast_lds( a, c->stream ) : vrc_launch_raycast( a, c->stream ) );
+    VRC_HIP_CHECK( c->rayLod ? vrc_launch_raycast_raylod( a, c->stream )
+                   : useLds  ? vrc_launch_raycast_lds( a, c->stream )
+                             : vrc_launch_raycast( a, c->stream ) );
     VRC_HIP_CHECK( hipEventRecord( evp.second, c->stream ) );
     {
         /* render fence of this context on the pool (see pool_upload) */
@@ -1071,9 +1128,11 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
                                        hipMemcpyDeviceToHost, c->stream ) );
     c->timed = true;
     c->stats.kernel_variant =
-        useLds ? VRC_KERNEL_LDS : ( useDda ? VRC_KERNEL_GRID_DDA : VRC_KERNEL_REFERENCE_ORDER );
+        c->rayLod ? VRC_KERNEL_RAY_LOD
+        : useLds  ? VRC_KERNEL_LDS
+                  : ( useDda ? VRC_KERNEL_GRID_DDA : VRC_KERNEL_REFERENCE_ORDER );
     for( int i = 0; i < 3; ++i )
-        c->stats.grid_dims[i] = useDda ? (uint32_t)f.gridDim[i] : 0u;
+        c->stats.grid_dims[i] = ( useDda || c->rayLod ) ? (uint32_t)f.gridDim[i] : 0u;
     return VRC_OK;
 }
 

@@ -62,7 +62,8 @@ struct vrc_dev_node
     float voxPerWorld[3]; /* texSize*atlasDim/aabbSize: atlas voxels per world unit */
     float localOrigin[3]; /* atlas-voxel coordinate of aabbMin, relative to the slot origin */
     uint32_t slotBase;    /* element offset of the brick's slot in the atlas buffer */
-    uint32_t pad[3];
+    uint32_t level;       /* per-ray LOD: 0 = the finest voxel size in the node list, +1 per doubling */
+    uint32_t pad[2];
 };
 
 /* Frame constants, derived on the host exactly as Renderer.cu:159-170 does per thread. */
@@ -98,6 +99,10 @@ struct vrc_frame
      * every pixel starts from 0 and is stored, hit or miss (the clear of
      * cuda/PixelBufferObject.cu:80 folded into the march: one pass over the frame less) */
     uint32_t clearFirst;
+    /* per-ray LOD (vrc_pixel_ray_lod): number of levels in the node list and
+     * finestVoxelWorldSize / (screenSpaceError * worldSpacePerPixel) */
+    uint32_t lodLevels;
+    float lodBase;
 };
 
 /* Atlas memory layout.  The logical atlas is the reference's 3-D array of slots
@@ -592,9 +597,10 @@ VRC_HD void vrc_composite( vrc_f4& c, const vrc_f4& e, bool frozen = false )
 template < bool CLAMP, bool COUNT, bool FIXED, typename ATLAS_T, int GROUP = VRC_GROUP >
 VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_segment s,
                                const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
-                               vrc_f4& color, uint32_t& nSamples )
+                               vrc_f4& color, uint32_t& nSamples, float levelStep = 0.0f )
 {
-    const float stepSize = f.stepSize;
+    /* levelStep: step of a coarser brick under per-ray LOD (vrc_pixel_ray_lod); 0 = the frame's */
+    const float stepSize = levelStep > 0.0f ? levelStep : f.stepSize;
     const vrc_sampler sm = vrc_make_sampler( n, f );
     float travel = s.dist;
     vrc_f3 pos = s.pos;
@@ -828,9 +834,9 @@ template < bool CLAMP, bool COUNT, bool TRILINEAR, typename ATLAS_T >
 VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n, vrc_segment s,
                                       const ATLAS_T* __restrict__ atlas, const vrc_f4* tfp,
                                       const vrc_classifier& cls, vrc_f4& color,
-                                      uint32_t& nSamples )
+                                      uint32_t& nSamples, float levelStep = 0.0f )
 {
-    const float stepSize = f.stepSize;
+    const float stepSize = levelStep > 0.0f ? levelStep : f.stepSize;
     const vrc_sampler sm = vrc_make_sampler( n, f );
     float travel = s.dist;
     vrc_f3 pos = s.pos;
@@ -913,12 +919,14 @@ VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n,
 template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP >
 VRC_HD bool vrc_march_brick( const vrc_frame& f, const vrc_dev_node& n, const vrc_segment& s,
                              const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
-                             const vrc_classifier& cls, vrc_f4& color, uint32_t& nSamples )
+                             const vrc_classifier& cls, vrc_f4& color, uint32_t& nSamples,
+                             float levelStep = 0.0f )
 {
     if( MODE != VRC_MODE_TABLE )
         return vrc_march_segment_linear< CLAMP, COUNT, MODE == VRC_MODE_TRILINEAR, ATLAS_T >(
-            f, n, s, atlas, lut, cls, color, nSamples );
-    return vrc_march_segment< CLAMP, COUNT, FIXED, ATLAS_T, GROUP >( f, n, s, atlas, lut, color, nSamples );
+            f, n, s, atlas, lut, cls, color, nSamples, levelStep );
+    return vrc_march_segment< CLAMP, COUNT, FIXED, ATLAS_T, GROUP >( f, n, s, atlas, lut, color, nSamples,
+                                                                   levelStep );
 }
 
 template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP >
@@ -1064,6 +1072,182 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
                 tMax[2] += tDelta[2];
                 if( cell[2] < 0 || cell[2] >= f.gridDim[2] ) break;
             }
+        }
+    }
+    pixelBuffer[pixelPos] = color;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * EXTENSION: per-ray adaptive LOD (BASELINE C5; VRC_OPT_RAY_LOD).  The reference selects the LOD
+ * per brick on the host: a brick is fine enough when its voxels, seen from the point of its box
+ * nearest to the near plane, are at most screenSpaceError pixels wide
+ * (livre/core/render/SelectVisibles.cpp:52-68: pixelPerVoxel * near / (near + distance) <= sse).
+ * Here the same criterion is evaluated along the ray.  The node list is a hierarchy (a cut of the
+ * octree plus ancestors, all resident, boxes may nest); with voxel size vw0 * 2^j at level j and
+ * eye-space depth / near = t / tNearPlane along a ray, level j is fine enough from
+ *     T_j = tNearPlane * lodBase * 2^j,   lodBase = vw0 / (screenSpaceError * worldSpacePerPixel).
+ * The ray walks the cells of the finest brick size (the DDA of vrc_pixel_grid_dda); entering a
+ * cell at parameter te it wants level k = #{ j >= 1 : T_j <= te } and takes the brick covering
+ * the cell at the first level present in the order k, k+1, ..., K-1, k-1, ..., 0.  Consecutive
+ * cells with the same brick form one run; a run is marched like a reference brick segment
+ * (Renderer.cu:195-223: sampling restarts at the run's entry point) with step stepSize * 2^j and
+ * opacity exponent alphaCorrection * 2^j (classified table of level j: lut + j * 257; classifier
+ * exponent scaled for the per-sample modes), so a level-j brick costs 2^-j of the samples and
+ * the opacity of a homogeneous stretch does not depend on the level it is sampled at.
+ * gridTable holds one cell -> node table per level, level-major.  CUDA variant only.
+ * ---------------------------------------------------------------------------------------- */
+#define VRC_MAX_LOD_LEVELS 8
+#define VRC_LUT_ENTRIES 257u
+
+VRC_HD vrc_segment vrc_run_segment( const vrc_ray& r, float tA, float tB, float stepSize )
+{
+    VRC_STRICT_FP
+    /* the tail of vrc_brick_segment (Renderer.cu:195-201) for an explicit interval */
+    const vrc_f3 rayStart = { r.origin.x + r.dir.x * tA, r.origin.y + r.dir.y * tA,
+                              r.origin.z + r.dir.z * tA };
+    const vrc_f3 rayStop = { r.origin.x + r.dir.x * tB, r.origin.y + r.dir.y * tB,
+                             r.origin.z + r.dir.z * tB };
+    const vrc_f3 diff = { rayStop.x - rayStart.x, rayStop.y - rayStart.y, rayStop.z - rayStart.z };
+    const float d2 = vrc_dot( diff, diff );
+    vrc_segment s;
+    s.pos = rayStart;
+    if( d2 > 0.0f )
+    {
+        const float invLen = 1.0f / sqrtf( d2 );
+        s.step.x = diff.x * invLen * stepSize;
+        s.step.y = diff.y * invLen * stepSize;
+        s.step.z = diff.z * invLen * stepSize;
+        s.dist = sqrtf( d2 );
+    }
+    else
+    {
+        s.step.x = s.step.y = s.step.z = 0.0f;
+        s.dist = 0.0f;
+    }
+    return s;
+}
+
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP >
+VRC_HD void vrc_pixel_ray_lod( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
+                               const int32_t* __restrict__ gridTable,
+                               const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
+                               const vrc_classifier& cls,
+                               vrc_f4* __restrict__ pixelBuffer, uint32_t px, uint32_t py,
+                               uint32_t& nSamples )
+{
+    const vrc_ray r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
+    const uint32_t pixelPos = py * f.width + px;
+    const vrc_f4 zero = { 0.f, 0.f, 0.f, 0.f };
+    if( !r.hit )
+    {
+        if( f.clearFirst )
+            pixelBuffer[pixelPos] = zero;
+        return;
+    }
+    vrc_f4 color = f.clearFirst ? zero : pixelBuffer[pixelPos];
+    if( color.w > VRC_EARLY_EXIT )
+        return;
+
+    const vrc_f3 gmin = { f.gridMin[0], f.gridMin[1], f.gridMin[2] };
+    const vrc_f3 gmax = { f.gridMin[0] + f.cellSize[0] * (float)f.gridDim[0],
+                          f.gridMin[1] + f.cellSize[1] * (float)f.gridDim[1],
+                          f.gridMin[2] + f.cellSize[2] * (float)f.gridDim[2] };
+    float t0, t1;
+    const bool any = vrc_intersect_box( r.origin, r.invDir, gmin, gmax, &t0, &t1 );
+    t0 = fmaxf( fmaxf( t0, r.tNearGlobal ), fmaxf( r.tNearPlane, 0.0f ) );
+    t1 = fminf( t1, r.tFarGlobal );
+    if( any && t0 <= t1 )
+    {
+        const int K = (int)f.lodLevels;
+        const int cells = f.gridDim[0] * f.gridDim[1] * f.gridDim[2];
+        float tBase;
+        {
+            VRC_STRICT_FP
+            tBase = r.tNearPlane * f.lodBase;
+        }
+        const float o[3] = { r.origin.x, r.origin.y, r.origin.z };
+        const float d[3] = { r.dir.x, r.dir.y, r.dir.z };
+        const float id[3] = { r.invDir.x, r.invDir.y, r.invDir.z };
+        int cell[3], stepDir[3];
+        float tMax[3], tDelta[3];
+#pragma unroll
+        for( int a = 0; a < 3; ++a )
+        {
+            const float p = o[a] + d[a] * t0;
+            int c = (int)floorf( ( p - f.gridMin[a] ) * f.invCellSize[a] );
+            c = c < 0 ? 0 : ( c > f.gridDim[a] - 1 ? f.gridDim[a] - 1 : c );
+            cell[a] = c;
+            const bool pos = d[a] > 0.0f;
+            stepDir[a] = pos ? 1 : -1;
+            const float boundary = f.gridMin[a] + f.cellSize[a] * (float)( pos ? c + 1 : c );
+            tMax[a] = ( boundary - o[a] ) * id[a];
+            tDelta[a] = f.cellSize[a] * fabsf( id[a] );
+        }
+        int32_t runNode = -1;
+        float runStart = t0, te = t0;
+        bool done = false;
+        const int maxSteps = f.gridDim[0] + f.gridDim[1] + f.gridDim[2] + 3;
+        for( int it = 0; it <= maxSteps && !done; ++it )
+        {
+            /* the brick for this cell (-1 past the end of the walk: flushes the last run) */
+            int32_t node = -1;
+            if( it < maxSteps && te <= t1 && cell[0] >= 0 && cell[0] < f.gridDim[0] && cell[1] >= 0 &&
+                cell[1] < f.gridDim[1] && cell[2] >= 0 && cell[2] < f.gridDim[2] )
+            {
+                int k = 0;
+                float T = tBase;
+                for( int j = 1; j < K; ++j )
+                {
+                    T = T + T; /* T_j, exact */
+                    k += T <= te ? 1 : 0;
+                }
+                const int c = ( cell[2] * f.gridDim[1] + cell[1] ) * f.gridDim[0] + cell[0];
+                for( int j = k; j < K && node < 0; ++j )
+                    node = gridTable[j * cells + c];
+                for( int j = k - 1; j >= 0 && node < 0; --j )
+                    node = gridTable[j * cells + c];
+            }
+            else
+                done = true;
+            if( node != runNode || done )
+            {
+                if( runNode >= 0 )
+                {
+                    const float tB = fminf( te, t1 );
+                    const vrc_dev_node n = nodes[runNode];
+                    const float scale = (float)( 1u << n.level );
+                    const float levelStep = f.stepSize * scale;
+                    const vrc_segment s = vrc_run_segment( r, runStart, tB, levelStep );
+                    vrc_classifier lc = cls;
+                    lc.alphaCorrection = cls.alphaCorrection * scale;
+                    const vrc_f4* ll = MODE == VRC_MODE_TABLE ? lut + n.level * VRC_LUT_ENTRIES : lut;
+                    if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP >(
+                            f, n, s, atlas, ll, lc, color, nSamples, levelStep ) )
+                        break;
+                }
+                runNode = node;
+                runStart = te;
+            }
+            if( done )
+                break;
+            /* advance to the next cell along the ray */
+            const float tNext = fminf( fminf( tMax[0], tMax[1] ), tMax[2] );
+            if( tMax[0] <= tMax[1] && tMax[0] <= tMax[2] )
+            {
+                cell[0] += stepDir[0];
+                tMax[0] += tDelta[0];
+            }
+            else if( tMax[1] <= tMax[2] )
+            {
+                cell[1] += stepDir[1];
+                tMax[1] += tDelta[1];
+            }
+            else
+            {
+                cell[2] += stepDir[2];
+                tMax[2] += tDelta[2];
+            }
+            te = tNext;
         }
     }
     pixelBuffer[pixelPos] = color;

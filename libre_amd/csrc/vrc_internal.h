@@ -68,4 +68,10 @@ hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream );
 /* LDS-staged form (vrc_kernels_lds.hip): needs gridTable, !clamp, 8x8 tiles */
 hipError_t vrc_launch_raycast_lds( const vrc_raycast_args& a, hipStream_t stream );
 
+
+/* per-ray adaptive LOD form (vrc_kernels_raylod.hip): gridTable = frame.lodLevels cell -> node
+ * tables, lut = VRC_MAX_LOD_LEVELS classified tables of VRC_LUT_ENTRIES (u8 point sampling) or the
+ * padded transfer function */
+hipError_t vrc_launch_raycast_raylod( const vrc_raycast_args& a, hipStream_t stream );
+
 #endif

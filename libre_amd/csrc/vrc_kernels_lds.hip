@@ -140,7 +140,8 @@ struct lds_box
 }
 
 template < bool COUNT, bool LINEAR, typename S >
-__global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
+/* the deep region leaves LDS for three workgroups per CU (3 waves per SIMD), the flat one for four */
+__global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) void vrc_k_raycast_lds(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ gridTable, const uint8_t* __restrict__ atlas,
     const vrc_f4* __restrict__ lutGlobal, const vrc_classifier cls,

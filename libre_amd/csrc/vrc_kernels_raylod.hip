@@ -1,0 +1,127 @@
+/*
+ * vrc_kernels_raylod.hip -- per-ray adaptive LOD form of the raycast (EXTENSION, BASELINE C5;
+ * VRC_OPT_RAY_LOD).  The reference picks the LOD per brick on the host
+ * (livre/core/render/SelectVisibles.cpp:52-68); here the node list is a hierarchy of resident
+ * bricks and every ray applies the same screen-space-error criterion at the cells it crosses
+ * (vrc_pixel_ray_lod in vrc_core.h has the definition).
+ *
+ * Same decomposition as vrc_k_raycast: one wave64 = one 8x8 pixel tile (Morton lanes), tiles
+ * heaviest-first.  What differs:
+ *   - the classified table exists once per level (opacity exponent alphaCorrection * 2^level),
+ *     K * 257 entries in dynamic LDS, filled by the workgroup; four waves share one copy;
+ *   - lanes of a wave may be in bricks of different levels and so step at different rates; the
+ *     march itself is vrc_march_brick with the level's step and table.
+ */
+#include "vrc_internal.h"
+
+#define VRC_RL_WAVES 4u
+#define VRC_RL_THREADS ( 64u * VRC_RL_WAVES )
+
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T >
+__global__ __launch_bounds__( VRC_RL_THREADS, 2 ) void vrc_k_raycast_raylod(
+    const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
+    const int32_t* __restrict__ levelTables, const ATLAS_T* __restrict__ atlas,
+    const vrc_f4* __restrict__ lutGlobal, const uint32_t lutEntries, const vrc_classifier cls,
+    vrc_f4* __restrict__ pixelBuffer, unsigned long long* __restrict__ sampleCounter,
+    const uint32_t* __restrict__ tileOrder, const uint32_t tilesX, const uint32_t nTiles )
+{
+    /* MODE_TABLE: lodLevels classified tables of 257 entries; else the padded transfer function */
+    extern __shared__ vrc_f4 lutLevels[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    for( uint32_t i = tid; i < lutEntries; i += VRC_RL_THREADS )
+        lutLevels[i] = lutGlobal[i];
+#if defined( VRC_ADDR_TABLES )
+    if( FIXED )
+    {
+        const uint32_t cyy = f.sbx * VRC_MB_VOXELS - 64u, czz = f.sbx * f.sby * VRC_MB_VOXELS - 512u;
+        const uint32_t u = tid, q = u >> VRC_MB_SHIFT;
+        if( u < 256u )
+        {
+            vrc_addr_tab[u] = u + 504u * q;
+            vrc_addr_tab[256u + u] = 8u * u + cyy * q;
+            vrc_addr_tab[512u + u] = 64u * u + czz * q;
+        }
+    }
+#endif
+    __syncthreads();
+    const uint32_t slotIndex = blockIdx.x * VRC_RL_WAVES + ( tid >> 6 );
+    if( slotIndex >= nTiles )
+        return;
+    const uint32_t tile = tileOrder ? tileOrder[slotIndex] : slotIndex;
+    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
+    const uint32_t lx = ( lane & 1u ) | ( ( lane >> 1 ) & 2u ) | ( ( lane >> 2 ) & 4u );
+    const uint32_t ly = ( ( lane >> 1 ) & 1u ) | ( ( lane >> 2 ) & 2u ) | ( ( lane >> 3 ) & 4u );
+    const uint32_t px = tx * 8u + lx;
+    const uint32_t py = ty * 8u + ly;
+
+    uint32_t nSamples = 0;
+    if( px < f.width && py < f.height )
+        vrc_pixel_ray_lod< CLAMP, COUNT, FIXED, MODE, ATLAS_T >( f, nodes, levelTables, atlas, lutLevels,
+                                                                 cls, pixelBuffer, px, py, nSamples );
+    if( COUNT )
+    {
+        unsigned long long s = nSamples;
+#pragma unroll
+        for( int off = 32; off > 0; off >>= 1 )
+            s += __shfl_down( s, off, 64 );
+        if( lane == 0 && s != 0 )
+            atomicAdd( sampleCounter, s );
+    }
+}
+
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T >
+static hipError_t launch_raylod( const vrc_raycast_args& a, hipStream_t stream )
+{
+    const uint32_t tilesX = ( a.frame.width + 7u ) / 8u, tilesY = ( a.frame.height + 7u ) / 8u;
+    const uint32_t nTiles = tilesX * tilesY;
+    if( nTiles == 0 )
+        return hipSuccess;
+    const uint32_t lutEntries =
+        MODE == VRC_MODE_TABLE ? a.frame.lodLevels * VRC_LUT_ENTRIES : VRC_TFP_ENTRIES;
+    hipLaunchKernelGGL( ( vrc_k_raycast_raylod< CLAMP, COUNT, FIXED, MODE, ATLAS_T > ),
+                        dim3( ( nTiles + VRC_RL_WAVES - 1u ) / VRC_RL_WAVES ), dim3( VRC_RL_THREADS ),
+                        lutEntries * sizeof( vrc_f4 ), stream, a.frame, a.nodes, a.gridTable,
+                        (const ATLAS_T*)a.atlas, a.lut, lutEntries, a.classifier, a.pixelBuffer,
+                        a.sampleCounter, a.tileOrder, tilesX, nTiles );
+    return hipGetLastError();
+}
+
+template < int MODE, typename ATLAS_T >
+static hipError_t launch_raylod_classify( const vrc_raycast_args& a, bool count, hipStream_t stream )
+{
+    switch( ( a.clamp ? 2 : 0 ) | ( count ? 1 : 0 ) )
+    {
+    case 0: return launch_raylod< false, false, false, MODE, ATLAS_T >( a, stream );
+    case 1: return launch_raylod< false, true, false, MODE, ATLAS_T >( a, stream );
+    case 2: return launch_raylod< true, false, false, MODE, ATLAS_T >( a, stream );
+    default: return launch_raylod< true, true, false, MODE, ATLAS_T >( a, stream );
+    }
+}
+
+/* a.gridTable: lodLevels cell -> node tables; a.lut: lodLevels classified tables (u8 point
+ * sampling) or the padded transfer function */
+hipError_t vrc_launch_raycast_raylod( const vrc_raycast_args& a, hipStream_t stream )
+{
+    if( a.frame.lodLevels < 1 || a.frame.lodLevels > VRC_MAX_LOD_LEVELS || !a.gridTable ||
+        a.frame.variant != VRC_VARIANT_CUDA )
+        return hipErrorInvalidValue;
+    const bool count = a.sampleCounter != nullptr;
+    if( a.elemBytes == 2 )
+        return a.linear ? launch_raylod_classify< VRC_MODE_TRILINEAR, uint16_t >( a, count, stream )
+                        : launch_raylod_classify< VRC_MODE_POINT, uint16_t >( a, count, stream );
+    if( a.elemBytes != 1 )
+        return hipErrorInvalidValue;
+    if( a.linear )
+        return launch_raylod_classify< VRC_MODE_TRILINEAR, uint8_t >( a, count, stream );
+    const bool fixed = a.fixedStepping && !a.clamp;
+    switch( ( fixed ? 4 : 0 ) | ( a.clamp ? 2 : 0 ) | ( count ? 1 : 0 ) )
+    {
+    case 0: return launch_raylod< false, false, false, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 1: return launch_raylod< false, true, false, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 2: return launch_raylod< true, false, false, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 3: return launch_raylod< true, true, false, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 4: return launch_raylod< false, false, true, VRC_MODE_TABLE, uint8_t >( a, stream );
+    default: return launch_raylod< false, true, true, VRC_MODE_TABLE, uint8_t >( a, stream );
+    }
+}

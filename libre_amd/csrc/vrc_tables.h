@@ -27,6 +27,10 @@ struct vrc_host_tables
     bool gridOk = false;
     bool clamp = false;
     vrc_frame g; /* grid fields only */
+    /* per-ray LOD (vrc_build_lod_tables): one cell -> node table per level in `grid` */
+    bool lodOk = false;
+    uint32_t lodLevels = 0;
+    double finestVoxelWorld = 0.0;
 };
 
 inline bool vrc_near_int( double v, double tol, long* out )
@@ -80,7 +84,8 @@ inline void vrc_build_tables( const vrc_atlas_geom& p, const vrc_node_data* in, 
             lay.slotDim[a] = p.slotDim[a];
         }
         d.slotBase = vrc_slot_base( lay, slotIdx[0], slotIdx[1], slotIdx[2] );
-        d.pad[0] = d.pad[1] = d.pad[2] = 0;
+        d.level = 0;
+        d.pad[0] = d.pad[1] = 0;
     }
 
     /* brick grid: cells of the finest brick size covering the union of the node boxes */
@@ -158,6 +163,100 @@ inline void vrc_build_tables( const vrc_atlas_geom& p, const vrc_node_data* in, 
     t.gridOk = true;
 }
 
+/* Per-ray LOD tables (vrc_pixel_ray_lod): the node list is a hierarchy -- boxes of different
+ * levels may nest, boxes of one level may not overlap.  Level of a node = log2 of its voxel size
+ * over the finest voxel size in the list (robust for the smaller bricks at the border of ragged
+ * trees, whose box size says nothing about their level).  Cells have the size of the smallest
+ * box; t.grid holds lodLevels tables of gridDim cells, level-major.  Overwrites t.grid / t.g;
+ * t.lodOk = false (and t.grid empty) when the list does not fit this form. */
+inline void vrc_build_lod_tables( const vrc_atlas_geom& p, const vrc_node_data* in, uint32_t n,
+                                  vrc_host_tables& t )
+{
+    t.lodOk = false;
+    t.lodLevels = 0;
+    t.grid.clear();
+    if( n == 0 || t.nodes.size() != n )
+        return;
+    std::vector< double > vw( n );
+    double vw0 = 0.0;
+    for( uint32_t i = 0; i < n; ++i )
+    {
+        const double texVox = std::floor( (double)in[i].textureSize[0] * p.atlasDim[0] + 0.5 );
+        if( !( texVox >= 1.0 ) || !( in[i].aabbSize[0] > 0.f ) )
+            return;
+        vw[i] = (double)in[i].aabbSize[0] / texVox;
+        vw0 = i == 0 ? vw[i] : std::min( vw0, vw[i] );
+    }
+    uint32_t levels = 0;
+    for( uint32_t i = 0; i < n; ++i )
+    {
+        long lv;
+        if( !vrc_near_int( std::log2( vw[i] / vw0 ), 0.05, &lv ) || lv < 0 || lv >= VRC_MAX_LOD_LEVELS )
+            return;
+        t.nodes[i].level = (uint32_t)lv;
+        levels = std::max( levels, (uint32_t)lv + 1u );
+    }
+    double cell[3], gmin[3], gmax[3];
+    for( int a = 0; a < 3; ++a )
+    {
+        cell[a] = in[0].aabbSize[a];
+        gmin[a] = in[0].aabbMin[a];
+        gmax[a] = (double)in[0].aabbMin[a] + in[0].aabbSize[a];
+    }
+    for( uint32_t i = 1; i < n; ++i )
+        for( int a = 0; a < 3; ++a )
+        {
+            cell[a] = std::min( cell[a], (double)in[i].aabbSize[a] );
+            gmin[a] = std::min( gmin[a], (double)in[i].aabbMin[a] );
+            gmax[a] = std::max( gmax[a], (double)in[i].aabbMin[a] + in[i].aabbSize[a] );
+        }
+    long dim[3];
+    for( int a = 0; a < 3; ++a )
+        if( !( cell[a] > 0.0 ) ||
+            !vrc_near_int( ( gmax[a] - gmin[a] ) / cell[a], 1e-3, &dim[a] ) || dim[a] < 1 ||
+            dim[a] > 4096 )
+            return;
+    const double cells = (double)dim[0] * dim[1] * dim[2];
+    if( cells * levels > 64.0 * 1024 * 1024 )
+        return;
+    t.grid.assign( (size_t)cells * levels, -1 );
+    for( uint32_t i = 0; i < n; ++i )
+    {
+        long i0[3], cnt[3];
+        for( int a = 0; a < 3; ++a )
+            if( !vrc_near_int( ( (double)in[i].aabbMin[a] - gmin[a] ) / cell[a], 1e-3, &i0[a] ) ||
+                !vrc_near_int( (double)in[i].aabbSize[a] / cell[a], 1e-3, &cnt[a] ) || cnt[a] < 1 ||
+                i0[a] < 0 || i0[a] + cnt[a] > dim[a] )
+            {
+                t.grid.clear();
+                return;
+            }
+        int32_t* table = t.grid.data() + (size_t)t.nodes[i].level * (size_t)cells;
+        for( long z = i0[2]; z < i0[2] + cnt[2]; ++z )
+            for( long y = i0[1]; y < i0[1] + cnt[1]; ++y )
+                for( long x = i0[0]; x < i0[0] + cnt[0]; ++x )
+                {
+                    int32_t& c = table[( (size_t)z * dim[1] + y ) * dim[0] + x];
+                    if( c != -1 ) /* two bricks of one level over the same cell */
+                    {
+                        t.grid.clear();
+                        return;
+                    }
+                    c = (int32_t)i;
+                }
+    }
+    for( int a = 0; a < 3; ++a )
+    {
+        t.g.gridMin[a] = (float)gmin[a];
+        t.g.cellSize[a] = (float)cell[a];
+        t.g.invCellSize[a] = (float)( 1.0 / cell[a] );
+        t.g.gridDim[a] = (int32_t)dim[a];
+    }
+    t.lodLevels = levels;
+    t.finestVoxelWorld = vw0;
+    t.lodOk = true;
+}
+
 /* Frame constants from the reference-shaped PODs (Renderer.cu:159-170 derives the same
  * values per thread).  Grid fields come from vrc_build_tables. */
 inline void vrc_fill_frame( vrc_frame& f, const vrc_view_data& view, const vrc_render_data& render,
@@ -200,6 +299,8 @@ inline void vrc_fill_frame( vrc_frame& f, const vrc_view_data& view, const vrc_r
     f.sbx = geom.slotDim[0] / VRC_MB;
     f.sby = geom.slotDim[1] / VRC_MB;
     f.rowMap = nullptr;
+    f.lodLevels = 0;
+    f.lodBase = 0.f;
 }
 
 #endif

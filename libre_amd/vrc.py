@@ -13,7 +13,7 @@ VRC_OK, VRC_EINVAL, VRC_EHIP, VRC_EFULL, VRC_ENOMEM, VRC_EUNSUPPORTED = range(6)
 OPT_KERNEL, OPT_FILTER, OPT_TF_FRAC_BITS, OPT_COUNT_SAMPLES, OPT_TILE_ORDER, OPT_STEPPING, OPT_VARIANT = range(1, 8)
 VARIANT_CUDARAYCASTER, VARIANT_GLRAYCASTER = 0, 1
 FILTER_NEAREST, FILTER_TRILINEAR = 0, 1
-KERNEL_AUTO, KERNEL_REFERENCE_ORDER, KERNEL_GRID_DDA, KERNEL_LDS = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_REFERENCE_ORDER, KERNEL_GRID_DDA, KERNEL_LDS, KERNEL_RAY_LOD = 0, 1, 2, 3, 4
 
 f32x3 = C.c_float * 3
 u32x3 = C.c_uint32 * 3
@@ -51,7 +51,7 @@ class VrcError(RuntimeError):
 
 #: every symbol include/vrc_hip.h declares; tests check the library exports all of them
 EXPORTS = [
-    "vrc_ctx_create", "vrc_ctx_destroy", "vrc_ctx_set_stream", "vrc_set_option", "vrc_get_option",
+    "vrc_ctx_create", "vrc_ctx_destroy", "vrc_ctx_set_stream", "vrc_set_option", "vrc_get_option", "vrc_set_ray_lod",
     "vrc_pool_create", "vrc_pool_destroy", "vrc_pool_copy_to_slot", "vrc_pool_copy_to_slot_device",
     "vrc_pool_release_slot", "vrc_pool_info", "vrc_pool_synchronize", "vrc_pool_read_region",
     "vrc_pool_histogram",
@@ -81,6 +81,7 @@ def load_library(path=None):
     L.vrc_ctx_destroy.restype = None
     L.vrc_ctx_set_stream.argtypes = [vp, vp]
     L.vrc_set_option.argtypes = [vp, C.c_int, C.c_int64]
+    L.vrc_set_ray_lod.argtypes = [vp, C.c_int, C.c_float, C.c_float]
     L.vrc_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
     L.vrc_pool_create.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_size_t, u32x3, C.c_size_t,
                                   C.POINTER(vp)]

@@ -626,6 +626,7 @@ static float fetch_trilinear( const uint8_t* atlas, int voxelBytes, const uint32
     return c0 * ( 1.0f - w[2] ) + c1 * w[2];
 }
 
+struct lod_grid;
 typedef struct
 {
     const uint8_t* atlas;
@@ -640,6 +641,7 @@ typedef struct
     const orc_node_data* nodes;
     const orc_render_data* render;
     orc_options opt;
+    const struct lod_grid* lod; /* rayLod only */
 } job_t;
 
 /* one pixel: Renderer.cu:106-229 */
@@ -892,6 +894,302 @@ static uint64_t raycast_pixel_gl( const job_t* j, uint32_t x, uint32_t y )
     return nSamples;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * EXTENSION: per-ray adaptive LOD (BASELINE C5).  Not in the reference, which selects the LOD per
+ * brick on the host: SelectVisibles.cpp:52-68 calls a brick fine enough when
+ *     worldSpacePerVoxel / worldSpacePerPixel * near / (near + distance) <= screenSpaceError
+ * at the point of its box nearest to the near plane.  Definition used here (the HIP kernel's
+ * vrc_pixel_ray_lod must reproduce it):
+ *   - nodes form a hierarchy: level(i) = log2( voxel size of node i / finest voxel size in the
+ *     list ), voxel size = aabbSize.x / (textureSize.x * atlasDim.x); boxes of one level do not
+ *     overlap, all boxes are aligned to cells of the smallest box size;
+ *   - along a ray eye-space depth / near = t / tNearPlane, so level j is fine enough from
+ *     T_j = tNearPlane * lodBase * 2^j, lodBase = finest voxel size / (sse * worldSpacePerPixel);
+ *   - the ray walks the cells (3-D DDA).  Entering a cell at te it wants level
+ *     k = #{ j in 1..K-1 : T_j <= te } and takes the brick over that cell at the first level
+ *     present in the order k, k+1, .., K-1, k-1, .., 0;
+ *   - consecutive cells with the same brick are one run [tA, tB]; a run is integrated like a
+ *     reference brick segment (Renderer.cu:195-223) with stepSize * 2^level and opacity exponent
+ *     alphaCorrection * 2^level.
+ * ---------------------------------------------------------------------------------------- */
+#define LOD_MAX_LEVELS 8
+typedef struct lod_grid
+{
+    int K, dim[3];
+    float gmin[3], cell[3], invCell[3];
+    float lodBase;
+    int32_t* tables; /* K * dim.x*dim.y*dim.z, level-major, -1 = none */
+    uint8_t* level;  /* per node */
+} lod_grid;
+
+static int near_int( double v, double tol, long* out )
+{
+    const double r = floor( v + 0.5 );
+    *out = (long)r;
+    return fabs( v - r ) <= tol;
+}
+
+static lod_grid* lod_grid_build( const orc_node_data* nodes, uint32_t n, const uint32_t atlasDim[3],
+                                 float sse, float worldPerPixel )
+{
+    if( n == 0 )
+        return NULL;
+    lod_grid* g = (lod_grid*)calloc( 1, sizeof( lod_grid ) );
+    double* vw = (double*)malloc( n * sizeof( double ) );
+    g->level = (uint8_t*)malloc( n );
+    double vw0 = 0.0, cell[3], gmin[3], gmax[3];
+    for( uint32_t i = 0; i < n; ++i )
+    {
+        const double texVox = floor( (double)nodes[i].textureSize[0] * atlasDim[0] + 0.5 );
+        vw[i] = (double)nodes[i].aabbSize[0] / texVox;
+        vw0 = i == 0 ? vw[i] : fmin( vw0, vw[i] );
+        for( int a = 0; a < 3; ++a )
+        {
+            const double lo = nodes[i].aabbMin[a], sz = nodes[i].aabbSize[a];
+            cell[a] = i == 0 ? sz : fmin( cell[a], sz );
+            gmin[a] = i == 0 ? lo : fmin( gmin[a], lo );
+            gmax[a] = i == 0 ? lo + sz : fmax( gmax[a], lo + sz );
+        }
+    }
+    int ok = 1;
+    g->K = 0;
+    for( uint32_t i = 0; i < n && ok; ++i )
+    {
+        long lv;
+        ok = near_int( log2( vw[i] / vw0 ), 0.05, &lv ) && lv >= 0 && lv < LOD_MAX_LEVELS;
+        g->level[i] = (uint8_t)lv;
+        if( ok && lv + 1 > g->K )
+            g->K = (int)lv + 1;
+    }
+    long dim[3] = { 0, 0, 0 };
+    for( int a = 0; a < 3 && ok; ++a )
+        ok = cell[a] > 0.0 && near_int( ( gmax[a] - gmin[a] ) / cell[a], 1e-3, &dim[a] ) && dim[a] >= 1 &&
+             dim[a] <= 4096;
+    size_t cells = 0;
+    if( ok )
+    {
+        cells = (size_t)dim[0] * dim[1] * dim[2];
+        g->tables = (int32_t*)malloc( cells * g->K * sizeof( int32_t ) );
+        for( size_t i = 0; i < cells * g->K; ++i )
+            g->tables[i] = -1;
+    }
+    for( uint32_t i = 0; i < n && ok; ++i )
+    {
+        long i0[3], cnt[3];
+        for( int a = 0; a < 3 && ok; ++a )
+            ok = near_int( ( (double)nodes[i].aabbMin[a] - gmin[a] ) / cell[a], 1e-3, &i0[a] ) &&
+                 near_int( (double)nodes[i].aabbSize[a] / cell[a], 1e-3, &cnt[a] ) && cnt[a] >= 1 &&
+                 i0[a] >= 0 && i0[a] + cnt[a] <= dim[a];
+        if( !ok )
+            break;
+        int32_t* table = g->tables + (size_t)g->level[i] * cells;
+        for( long z = i0[2]; z < i0[2] + cnt[2]; ++z )
+            for( long y = i0[1]; y < i0[1] + cnt[1]; ++y )
+                for( long x = i0[0]; x < i0[0] + cnt[0]; ++x )
+                {
+                    int32_t* c = &table[( (size_t)z * dim[1] + y ) * dim[0] + x];
+                    if( *c != -1 )
+                        ok = 0;
+                    *c = (int32_t)i;
+                }
+    }
+    free( vw );
+    if( !ok )
+    {
+        free( g->tables );
+        free( g->level );
+        free( g );
+        return NULL;
+    }
+    for( int a = 0; a < 3; ++a )
+    {
+        g->dim[a] = (int)dim[a];
+        g->gmin[a] = (float)gmin[a];
+        g->cell[a] = (float)cell[a];
+        g->invCell[a] = (float)( 1.0 / cell[a] );
+    }
+    g->lodBase = (float)( vw0 / ( (double)sse * (double)worldPerPixel ) );
+    return g;
+}
+
+static void lod_grid_free( lod_grid* g )
+{
+    if( !g )
+        return;
+    free( g->tables );
+    free( g->level );
+    free( g );
+}
+
+/* integrate one run [tA, tB] of the ray through one brick; returns 1 on early exit */
+static int integrate_run( const job_t* j, const orc_node_data* nodeData, int level, f3 origin, f3 dir,
+                          float tA, float tB, float color[4], uint64_t* nSamples )
+{
+    const orc_render_data* renderData = j->render;
+    const float r0 = renderData->dataSourceRange[0], r1 = renderData->dataSourceRange[1];
+    const float multiplyer = 1.0f / ( r1 - r0 );
+    const float addedValue = -r0 / ( r1 - r0 );
+    const float scale = (float)( 1u << level );
+    const float alphaCorrection =
+        (float)renderData->maxSamplesPerRay / (float)renderData->samplesPerRay * scale;
+    const float stepSize = (float)( 1.0 / (double)(float)renderData->samplesPerRay ) * scale;
+
+    const f3 boxMin = { nodeData->aabbMin[0], nodeData->aabbMin[1], nodeData->aabbMin[2] };
+    const f3 boxSize = { nodeData->aabbSize[0], nodeData->aabbSize[1], nodeData->aabbSize[2] };
+    const f3 texMin = { nodeData->textureMin[0], nodeData->textureMin[1], nodeData->textureMin[2] };
+    const f3 texSize = { nodeData->textureSize[0], nodeData->textureSize[1], nodeData->textureSize[2] };
+    const f3 rayStart = { origin.x + dir.x * tA, origin.y + dir.y * tA, origin.z + dir.z * tA };
+    const f3 rayStop = { origin.x + dir.x * tB, origin.y + dir.y * tB, origin.z + dir.z * tB };
+    const f3 diff = { rayStop.x - rayStart.x, rayStop.y - rayStart.y, rayStop.z - rayStart.z };
+    const float d2 = dot3( diff, diff );
+    if( !( d2 > 0.0f ) )
+        return 0;
+    const float dist = sqrtf( d2 );
+    const float inv = 1.0f / dist;
+    const f3 step = { diff.x * inv * stepSize, diff.y * inv * stepSize, diff.z * inv * stepSize };
+    f3 pos = rayStart;
+    for( float travel = dist; travel > 0.0f;
+         pos.x += step.x, pos.y += step.y, pos.z += step.z, travel -= stepSize )
+    {
+        const f3 texPos = { ( ( pos.x - boxMin.x ) / boxSize.x ) * texSize.x + texMin.x,
+                            ( ( pos.y - boxMin.y ) / boxSize.y ) * texSize.y + texMin.y,
+                            ( ( pos.z - boxMin.z ) / boxSize.z ) * texSize.z + texMin.z };
+        const float density = j->opt.filter
+                                  ? fetch_trilinear( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos )
+                                  : fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
+        float transferFn[4];
+        orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, transferFn );
+        orc_composite( transferFn, color, alphaCorrection );
+        ++*nSamples;
+        if( color[3] > EARLY_EXIT )
+            return 1;
+    }
+    return 0;
+}
+
+static uint64_t raycast_pixel_ray_lod( const job_t* j, uint32_t x, uint32_t y )
+{
+    const orc_view_data* viewData = j->view;
+    const lod_grid* g = j->lod;
+    uint64_t nSamples = 0;
+
+    /* ray, global interval, clip planes, near plane: Renderer.cu:106-160 as in raycast_pixel */
+    const f4 pixelEyeSpacePos =
+        eye_space_from_window( (float)x, (float)y, viewData->glViewport, viewData->invProjMatrix );
+    const f4 pixelWorldSpacePos = mat_mul_vec4( viewData->invViewMatrix, pixelEyeSpacePos );
+    const f3 origin = { viewData->eyePosition[0], viewData->eyePosition[1], viewData->eyePosition[2] };
+    const f3 d0 = { pixelWorldSpacePos.x - origin.x, pixelWorldSpacePos.y - origin.y,
+                    pixelWorldSpacePos.z - origin.z };
+    f3 dir = normalize_f3( d0 );
+    if( dir.x == 0.0f ) dir.x = EPSILON;
+    if( dir.y == 0.0f ) dir.y = EPSILON;
+    if( dir.z == 0.0f ) dir.z = EPSILON;
+    float tNearGlobal, tFarGlobal;
+    const f3 globalBoxMin = { viewData->aabbMin[0], viewData->aabbMin[1], viewData->aabbMin[2] };
+    const f3 globalBoxMax = { viewData->aabbMax[0], viewData->aabbMax[1], viewData->aabbMax[2] };
+    if( !intersect_box( origin, dir, globalBoxMin, globalBoxMax, &tNearGlobal, &tFarGlobal ) )
+        return 0;
+    for( uint32_t i = 0; i < j->nPlanes; ++i )
+    {
+        const float* cp = j->clipPlanes + 4 * i;
+        const f3 planeNormal = { cp[0], cp[1], cp[2] };
+        float rn = dot3( dir, planeNormal );
+        if( rn == 0.0f )
+            rn = EPSILON;
+        const float t = -( dot3( planeNormal, origin ) + cp[3] ) / rn;
+        if( rn > 0.0f )
+            tNearGlobal = fmaxf( tNearGlobal, t );
+        else
+            tFarGlobal = fminf( tFarGlobal, t );
+    }
+    if( tNearGlobal > tFarGlobal )
+        return 0;
+    float* px = j->pixelBuffer + ( (size_t)y * j->width + x ) * 4;
+    if( px[3] > EARLY_EXIT )
+        return 0;
+    float color[4] = { px[0], px[1], px[2], px[3] };
+    const f3 e3 = { pixelEyeSpacePos.x, pixelEyeSpacePos.y, pixelEyeSpacePos.z };
+    const f3 nEye = normalize_f3( e3 );
+    const float tNearPlane = -viewData->nearPlane / nEye.z;
+
+    /* the ray's interval inside the cell grid */
+    const f3 gridMin = { g->gmin[0], g->gmin[1], g->gmin[2] };
+    const f3 gridMax = { g->gmin[0] + g->cell[0] * (float)g->dim[0], g->gmin[1] + g->cell[1] * (float)g->dim[1],
+                         g->gmin[2] + g->cell[2] * (float)g->dim[2] };
+    float t0, t1;
+    const int any = intersect_box( origin, dir, gridMin, gridMax, &t0, &t1 );
+    t0 = fmaxf( fmaxf( t0, tNearGlobal ), fmaxf( tNearPlane, 0.0f ) );
+    t1 = fminf( t1, tFarGlobal );
+    if( any && t0 <= t1 )
+    {
+        const float o[3] = { origin.x, origin.y, origin.z };
+        const float d[3] = { dir.x, dir.y, dir.z };
+        const float tBase = tNearPlane * g->lodBase;
+        const size_t cells = (size_t)g->dim[0] * g->dim[1] * g->dim[2];
+        int cell[3], stepDir[3];
+        float tMax[3], tDelta[3];
+        for( int a = 0; a < 3; ++a )
+        {
+            const float invD = 1.0f / d[a];
+            const float p = o[a] + d[a] * t0;
+            int c = (int)floorf( ( p - g->gmin[a] ) * g->invCell[a] );
+            if( c < 0 ) c = 0;
+            if( c > g->dim[a] - 1 ) c = g->dim[a] - 1;
+            cell[a] = c;
+            stepDir[a] = d[a] > 0.0f ? 1 : -1;
+            const float boundary = g->gmin[a] + g->cell[a] * (float)( d[a] > 0.0f ? c + 1 : c );
+            tMax[a] = ( boundary - o[a] ) * invD;
+            tDelta[a] = g->cell[a] * fabsf( invD );
+        }
+        int runNode = -1;
+        float runStart = t0, te = t0;
+        const int maxCells = g->dim[0] + g->dim[1] + g->dim[2] + 3;
+        for( int it = 0;; ++it )
+        {
+            int node = -1;
+            const int inside = it < maxCells && te <= t1 && cell[0] >= 0 && cell[0] < g->dim[0] &&
+                               cell[1] >= 0 && cell[1] < g->dim[1] && cell[2] >= 0 && cell[2] < g->dim[2];
+            if( inside )
+            {
+                int k = 0;
+                float T = tBase;
+                for( int lv = 1; lv < g->K; ++lv )
+                {
+                    T = T + T;
+                    if( T <= te )
+                        ++k;
+                }
+                const size_t c = ( (size_t)cell[2] * g->dim[1] + cell[1] ) * g->dim[0] + cell[0];
+                for( int lv = k; lv < g->K && node < 0; ++lv )
+                    node = g->tables[lv * cells + c];
+                for( int lv = k - 1; lv >= 0 && node < 0; --lv )
+                    node = g->tables[lv * cells + c];
+            }
+            if( node != runNode || !inside )
+            {
+                if( runNode >= 0 &&
+                    integrate_run( j, &j->nodes[runNode], g->level[runNode], origin, dir, runStart,
+                                   fminf( te, t1 ), color, &nSamples ) )
+                    break;
+                runNode = node;
+                runStart = te;
+            }
+            if( !inside )
+                break;
+            const float tNext = fminf( fminf( tMax[0], tMax[1] ), tMax[2] );
+            const int a = ( tMax[0] <= tMax[1] && tMax[0] <= tMax[2] ) ? 0 : ( tMax[1] <= tMax[2] ? 1 : 2 );
+            cell[a] += stepDir[a];
+            tMax[a] += tDelta[a];
+            te = tNext;
+        }
+    }
+    px[0] = color[0];
+    px[1] = color[1];
+    px[2] = color[2];
+    px[3] = color[3];
+    return nSamples;
+}
+
 typedef struct
 {
     const job_t* job;
@@ -912,7 +1210,8 @@ static void* worker_main( void* p )
             break;
         const uint32_t y = (uint32_t)y64;
         for( uint32_t x = 0; x < j->width; ++x )
-            n += j->opt.variant == 1 ? raycast_pixel_gl( j, x, y ) : raycast_pixel( j, x, y );
+            n += j->lod ? raycast_pixel_ray_lod( j, x, y )
+                        : j->opt.variant == 1 ? raycast_pixel_gl( j, x, y ) : raycast_pixel( j, x, y );
     }
     w->samples = n;
     return NULL;
@@ -949,6 +1248,21 @@ uint64_t orc_raycast( const uint8_t* atlas, const uint32_t atlasDim[3], float* p
         job.opt.rowStride = 1;
         job.opt.voxelBytes = 1;
         job.opt.variant = 0;
+        job.opt.rayLod = 0;
+        job.opt.lodScreenSpaceError = job.opt.lodWorldSpacePerPixel = 0.f;
+    }
+    job.lod = NULL;
+    lod_grid* lodGrid = NULL;
+    if( job.opt.rayLod )
+    {
+        if( job.opt.variant != 0 || !( job.opt.lodScreenSpaceError > 0.f ) ||
+            !( job.opt.lodWorldSpacePerPixel > 0.f ) )
+            return UINT64_MAX;
+        lodGrid = lod_grid_build( nodes, nodeCount, atlasDim, job.opt.lodScreenSpaceError,
+                                  job.opt.lodWorldSpacePerPixel );
+        if( !lodGrid )
+            return UINT64_MAX; /* the node list is not a cell-aligned hierarchy */
+        job.lod = lodGrid;
     }
     if( job.opt.rowStride == 0 ) job.opt.rowStride = 1;
     if( job.opt.rowEnd == 0 || job.opt.rowEnd > height ) job.opt.rowEnd = height;
@@ -976,5 +1290,6 @@ uint64_t orc_raycast( const uint8_t* atlas, const uint32_t atlasDim[3], float* p
     uint64_t total = 0;
     for( int i = 0; i < nt; ++i )
         total += workers[i].samples;
+    lod_grid_free( lodGrid );
     return total;
 }

@@ -96,6 +96,10 @@ typedef struct
                       * (shaders/fragRaycast.glsl:113-215) -- pixel centre at +0.5, hit test
                       * t0 <= t1, first sample of a brick snapped to the global step lattice, clip
                       * planes applied per brick after the snap, no clamp to the global interval */
+    int rayLod;      /* EXTENSION (BASELINE C5), variant 0 only: 1 = per-ray adaptive LOD.  The node
+                      * list is a hierarchy of bricks; the criterion of SelectVisibles.cpp:52-68 is
+                      * applied along the ray instead of per brick (raycast_pixel_ray_lod) */
+    float lodScreenSpaceError, lodWorldSpacePerPixel; /* SelectVisibles.cpp:57-67 */
 } orc_options;
 
 /* ---- NodeId: livre/core/data/NodeId.h:38-49, livre/core/types.h:191-195, mathTypes.h:82 */

@@ -10,13 +10,14 @@
 
 #include "../../libre_amd/csrc/vrc_tables.h"
 
-extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3],
-                               const uint32_t slotDim[3], float* pixelBuffer, uint32_t W,
-                               uint32_t H, const float* planes, uint32_t nPlanes, const float* tf,
-                               const vrc_view_data* view, uint32_t nNodes,
-                               const vrc_node_data* nodes, const vrc_render_data* render,
-                               int fracBits, int kernel, int pixelOffX, int pixelOffY,
-                               uint64_t* samplesOut, int* gridOkOut, int voxelBytes, int variant )
+static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3],
+                        const uint32_t slotDim[3], float* pixelBuffer, uint32_t W,
+                        uint32_t H, const float* planes, uint32_t nPlanes, const float* tf,
+                        const vrc_view_data* view, uint32_t nNodes,
+                        const vrc_node_data* nodes, const vrc_render_data* render,
+                        int fracBits, int kernel, int pixelOffX, int pixelOffY,
+                        uint64_t* samplesOut, int* gridOkOut, int voxelBytes, int variant,
+                        bool rayLod, float lodSse, float lodWorldPerPixel )
 {
     if( voxelBytes != 1 && voxelBytes != 2 )
         return 3;
@@ -57,15 +58,26 @@ extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atla
     lp.rangeMax = render->dataSourceRange[1];
     lp.alphaCorrection = (float)render->maxSamplesPerRay / (float)render->samplesPerRay;
     lp.fracBits = fracBits;
-    std::vector< vrc_f4 > lut( 257 );
-    for( uint32_t d = 0; d < 256; ++d )
-        lut[d] = vrc_lut_entry( tf, d, lp );
-    lut[256] = vrc_f4{ 0.f, 0.f, 0.f, 0.f };
+    /* one classified table per level (per-ray LOD: exponent doubled per level), as vrc_render builds them */
+    const uint32_t lutLevels = rayLod ? (uint32_t)VRC_MAX_LOD_LEVELS : 1u;
+    std::vector< vrc_f4 > lut( lutLevels * VRC_LUT_ENTRIES );
+    for( uint32_t j = 0; j < lutLevels; ++j )
+    {
+        vrc_lut_params lj = lp;
+        lj.alphaCorrection = lp.alphaCorrection * (float)( 1u << j );
+        for( uint32_t d = 0; d < 256; ++d )
+            lut[j * VRC_LUT_ENTRIES + d] = vrc_lut_entry( tf, d, lj );
+        lut[j * VRC_LUT_ENTRIES + 256] = vrc_f4{ 0.f, 0.f, 0.f, 0.f };
+    }
 
     vrc_host_tables t;
     vrc_build_tables( geom, nodes, nNodes, t );
+    if( rayLod )
+        vrc_build_lod_tables( geom, nodes, nNodes, t );
     if( gridOkOut )
-        *gridOkOut = t.gridOk ? 1 : 0;
+        *gridOkOut = ( rayLod ? t.lodOk : t.gridOk ) ? 1 : 0;
+    if( rayLod && ( !t.lodOk || variant != 0 ) )
+        return 2;
     float pl[6][4];
     std::memset( pl, 0, sizeof( pl ) );
     for( uint32_t i = 0; i < nPlanes && i < 6; ++i )
@@ -77,11 +89,16 @@ extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atla
     vrc_fill_frame( f, *view, *render, geom, t.g, pl, nPlanes, nNodes, W, H, (float)pixelOffX + centre,
                     (float)pixelOffY + centre );
     f.variant = variant == 1 ? VRC_VARIANT_GL : VRC_VARIANT_CUDA;
+    if( rayLod )
+    {
+        f.lodLevels = t.lodLevels;
+        f.lodBase = (float)( t.finestVoxelWorld / ( (double)lodSse * (double)lodWorldPerPixel ) );
+    }
 
     /* kernel: 1 reference order, 2 grid DDA, 3/4 the same with fixed-point stepping (u8 only),
      * 5/6 the same with the trilinear filter, 7/8 point sampling with per-sample
      * classification (the only point-sampling form for 16-bit voxels) */
-    const bool dda = kernel == 2 || kernel == 4 || kernel == 6 || kernel == 8;
+    const bool dda = !rayLod && ( kernel == 2 || kernel == 4 || kernel == 6 || kernel == 8 );
     const int mode = ( kernel == 5 || kernel == 6 ) ? VRC_MODE_TRILINEAR
                      : ( ( kernel == 7 || kernel == 8 ) ? VRC_MODE_POINT : VRC_MODE_TABLE );
     const bool fixed = ( kernel == 3 || kernel == 4 ) && !t.clamp;
@@ -112,7 +129,21 @@ extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atla
         else if( t.clamp ) vrc_pixel_reference_order< true, true, false, MODE, T >( ARGS_REF( A ) ); \
         else vrc_pixel_reference_order< false, true, false, MODE, T >( ARGS_REF( A ) );              \
     }
-            if( mode == VRC_MODE_TRILINEAR && voxelBytes == 1 ) CLASSIFY( VRC_MODE_TRILINEAR, uint8_t, atlas.data() )
+#define RAYLOD( FIXED, MODE, T, A )                                                                     \
+    {                                                                                                \
+        if( t.clamp ) vrc_pixel_ray_lod< true, true, false, MODE, T >( ARGS_DDA( A ) );              \
+        else vrc_pixel_ray_lod< false, true, FIXED, MODE, T >( ARGS_DDA( A ) );                      \
+    }
+            if( rayLod )
+            {
+                if( mode == VRC_MODE_TRILINEAR && voxelBytes == 1 ) RAYLOD( false, VRC_MODE_TRILINEAR, uint8_t, atlas.data() )
+                else if( mode == VRC_MODE_TRILINEAR ) RAYLOD( false, VRC_MODE_TRILINEAR, uint16_t, atlas16.data() )
+                else if( mode == VRC_MODE_POINT && voxelBytes == 1 ) RAYLOD( false, VRC_MODE_POINT, uint8_t, atlas.data() )
+                else if( mode == VRC_MODE_POINT ) RAYLOD( false, VRC_MODE_POINT, uint16_t, atlas16.data() )
+                else if( fixed ) RAYLOD( true, VRC_MODE_TABLE, uint8_t, atlas.data() )
+                else RAYLOD( false, VRC_MODE_TABLE, uint8_t, atlas.data() )
+            }
+            else if( mode == VRC_MODE_TRILINEAR && voxelBytes == 1 ) CLASSIFY( VRC_MODE_TRILINEAR, uint8_t, atlas.data() )
             else if( mode == VRC_MODE_TRILINEAR ) CLASSIFY( VRC_MODE_TRILINEAR, uint16_t, atlas16.data() )
             else if( mode == VRC_MODE_POINT && voxelBytes == 1 ) CLASSIFY( VRC_MODE_POINT, uint8_t, atlas.data() )
             else if( mode == VRC_MODE_POINT ) CLASSIFY( VRC_MODE_POINT, uint16_t, atlas16.data() )
@@ -129,6 +160,7 @@ extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atla
                 else vrc_pixel_reference_order< false, true, false, VRC_MODE_TABLE, uint8_t >( ARGS_REF( atlas.data() ) );
             }
 #undef CLASSIFY
+#undef RAYLOD
 #undef ARGS_DDA
 #undef ARGS_REF
             total += n;
@@ -136,4 +168,32 @@ extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atla
     if( samplesOut )
         *samplesOut = total;
     return 0;
+}
+
+extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3],
+                               const uint32_t slotDim[3], float* pixelBuffer, uint32_t W,
+                               uint32_t H, const float* planes, uint32_t nPlanes, const float* tf,
+                               const vrc_view_data* view, uint32_t nNodes,
+                               const vrc_node_data* nodes, const vrc_render_data* render,
+                               int fracBits, int kernel, int pixelOffX, int pixelOffY,
+                               uint64_t* samplesOut, int* gridOkOut, int voxelBytes, int variant )
+{
+    return render_impl( atlasRowMajor, atlasDim, slotDim, pixelBuffer, W, H, planes, nPlanes, tf, view,
+                        nNodes, nodes, render, fracBits, kernel, pixelOffX, pixelOffY, samplesOut,
+                        gridOkOut, voxelBytes, variant, false, 0.f, 0.f );
+}
+
+/* per-ray adaptive LOD (vrc_pixel_ray_lod): kernel 1/3 = classified tables with float / fixed-point
+ * stepping, 5 = trilinear, 7 = point sampling with per-sample classification */
+extern "C" int harness_render_ray_lod( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3],
+                                       const uint32_t slotDim[3], float* pixelBuffer, uint32_t W,
+                                       uint32_t H, const float* planes, uint32_t nPlanes, const float* tf,
+                                       const vrc_view_data* view, uint32_t nNodes,
+                                       const vrc_node_data* nodes, const vrc_render_data* render,
+                                       int fracBits, int kernel, uint64_t* samplesOut, int* lodOkOut,
+                                       int voxelBytes, float screenSpaceError, float worldSpacePerPixel )
+{
+    return render_impl( atlasRowMajor, atlasDim, slotDim, pixelBuffer, W, H, planes, nPlanes, tf, view,
+                        nNodes, nodes, render, fracBits, kernel, 0, 0, samplesOut, lodOkOut, voxelBytes, 0,
+                        true, screenSpaceError, worldSpacePerPixel );
 }

@@ -36,8 +36,11 @@ class GpuScene:
                     slots=list(sl), free=fs.value)
 
     def render(self, kernel=vrc.KERNEL_AUTO, frac_bits=8, count=True, passes=None, stepping=1,
-               filter_mode=0, variant=0):
+               filter_mode=0, variant=0, ray_lod=None):
         L, s = self.L, self.s
+        # ray_lod = (screenSpaceError, worldSpacePerPixel): per-ray adaptive LOD over the hierarchy s.nodes
+        vrc.check(L, L.vrc_set_ray_lod(self.ctx, 1 if ray_lod else 0, ray_lod[0] if ray_lod else 0.0,
+                                       ray_lod[1] if ray_lod else 0.0))
         vrc.check(L, L.vrc_set_option(self.ctx, vrc.OPT_KERNEL, kernel))
         vrc.check(L, L.vrc_set_option(self.ctx, vrc.OPT_TF_FRAC_BITS, frac_bits))
         vrc.check(L, L.vrc_set_option(self.ctx, vrc.OPT_COUNT_SAMPLES, 1 if count else 0))

@@ -53,7 +53,8 @@ class LODNode(C.Structure):
 class Options(C.Structure):
     _fields_ = [("tfFracBits", C.c_int), ("filter", C.c_int), ("nThreads", C.c_int),
                 ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32), ("rowStride", C.c_uint32),
-                ("voxelBytes", C.c_int), ("variant", C.c_int)]
+                ("voxelBytes", C.c_int), ("variant", C.c_int), ("rayLod", C.c_int),
+                ("lodScreenSpaceError", C.c_float), ("lodWorldSpacePerPixel", C.c_float)]
 
 
 def build_oracle():
@@ -373,18 +374,27 @@ def build_scene(voxels=(64, 64, 64), block=16, viewport=(64, 64), spr=0, alpha=0
     return s
 
 
-def oracle_render(s, frac_bits=8, threads=8, rows=None, fb=None, filter_mode=0, variant=0):
-    """Run the oracle integrator on a scene. Returns (rgba[H,W,4], samples)."""
+def world_space_per_pixel(s, top=0.05, bottom=-0.05):
+    """SelectVisibles.cpp:55-57: (frustum.top - frustum.bottom) / window height, for default_proj."""
+    return (top - bottom) / float(s.H)
+
+
+def oracle_render(s, frac_bits=8, threads=8, rows=None, fb=None, filter_mode=0, variant=0, ray_lod=None):
+    """Run the oracle integrator on a scene. Returns (rgba[H,W,4], samples).
+    ray_lod = (screenSpaceError, worldSpacePerPixel): per-ray adaptive LOD over a node hierarchy."""
     L = lib()
     if fb is None:
         fb = np.zeros((s.H, s.W, 4), dtype=np.float32)
-    opt = Options(frac_bits, filter_mode, threads, 0, s.H, 1, s.atlas.dtype.itemsize, variant)
+    opt = Options(frac_bits, filter_mode, threads, 0, s.H, 1, s.atlas.dtype.itemsize, variant,
+                  1 if ray_lod else 0, ray_lod[0] if ray_lod else 0.0, ray_lod[1] if ray_lod else 0.0)
     if rows is not None:
         opt.rowBegin, opt.rowEnd, opt.rowStride = rows
     n = L.orc_raycast(s.atlas.ctypes.data, u32x3(*s.atlas_dim), fb.ctypes.data, s.W, s.H,
                       s.planes.ctypes.data if len(s.planes) else None, len(s.planes),
                       s.tf.ctypes.data, C.byref(s.view), s.n_nodes, s.nodes, C.byref(s.render),
                       C.byref(opt))
+    if int(n) == 2 ** 64 - 1:
+        raise RuntimeError("orc_raycast: the node list is not a cell-aligned hierarchy")
     return fb, int(n)
 
 
@@ -404,6 +414,39 @@ def harness_render(s, kernel=2, frac_bits=8, fb=None, sanitize=False, pixel_off=
     if rc != 0:
         raise RuntimeError("harness_render failed: %d" % rc)
     return fb, int(samples.value), bool(grid_ok.value)
+
+
+def harness_render_ray_lod(s, ray_lod, kernel=1, frac_bits=8, sanitize=False):
+    """Host build of vrc_pixel_ray_lod (vrc_core.h) + vrc_build_lod_tables (vrc_tables.h)."""
+    H = harness(sanitize)
+    fb = np.zeros((s.H, s.W, 4), dtype=np.float32)
+    samples = C.c_uint64(0)
+    ok = C.c_int(0)
+    H.harness_render_ray_lod.restype = C.c_int
+    rc = H.harness_render_ray_lod(C.c_void_p(s.atlas.ctypes.data), u32x3(*s.atlas_dim), u32x3(*s.slot_dim),
+                                  C.c_void_p(fb.ctypes.data), C.c_uint32(s.W), C.c_uint32(s.H),
+                                  C.c_void_p(s.planes.ctypes.data if len(s.planes) else None),
+                                  C.c_uint32(len(s.planes)), C.c_void_p(s.tf.ctypes.data), C.byref(s.view),
+                                  C.c_uint32(s.n_nodes), s.nodes, C.byref(s.render), C.c_int(frac_bits),
+                                  C.c_int(kernel), C.byref(samples), C.byref(ok),
+                                  C.c_int(s.atlas.dtype.itemsize), C.c_float(ray_lod[0]),
+                                  C.c_float(ray_lod[1]))
+    if rc != 0:
+        raise RuntimeError("harness_render_ray_lod failed: %d" % rc)
+    return fb, int(samples.value), bool(ok.value)
+
+
+def all_level_ids(vi, levels=None):
+    """NodeIds of every brick of the given levels (default: the whole tree): the resident
+    hierarchy per-ray LOD renders from."""
+    ids = []
+    for level in (range(vi.depth) if levels is None else levels):
+        dims = [vi.rootBlocks[a] << level for a in range(3)]
+        for x in range(dims[0]):
+            for y in range(dims[1]):
+                for z in range(dims[2]):
+                    ids.append(pack(level, x, y, z, 0))
+    return ids
 
 
 def compare(a, b):

@@ -537,3 +537,113 @@ def test_concurrent_uploads_are_thread_safe(vrc):
         assert (out == s.bricks[nid]).all()
     L.vrc_pool_destroy(pool)
     L.vrc_ctx_destroy(ctx)
+
+
+# ---- per-ray adaptive LOD (EXTENSION, BASELINE C5; vrc_set_ray_lod) ---------------------------------------
+
+def _hierarchy(voxels=(64, 64, 64), block=16, levels=None, **kw):
+    vi = orc.mem_volume_info(voxels[0], voxels[1], voxels[2], block)
+    return orc.build_scene(voxels=voxels, block=block, ids=orc.all_level_ids(vi, levels), **kw)
+
+
+def _lod_parity(got, want, what):
+    mx, mean, over = orc.compare(got, want)
+    npix = got.shape[0] * got.shape[1]
+    assert mx <= 5 * scenes.MAX_ABS and mean <= 4 * scenes.MEAN_ABS and over * npix <= max(3.0, 5e-3 * npix), \
+        "%s: max|d|=%.3g mean|d|=%.3g over=%.4f" % (what, mx, mean, over)
+
+
+@pytest.mark.parametrize("sse", [0.5, 1.3, 1.7, 2.5, 6.0])
+def test_ray_lod_matches_oracle(vrc, sse):
+    s = _hierarchy(viewport=(160, 120), volume="hash", spin=(0.4, 0.3))
+    lod = (sse, orc.world_space_per_pixel(s))
+    want, n_want = orc.oracle_render(s, ray_lod=lod)
+    with _gpu(s) as g:
+        for stepping in (1, 0):
+            got, n_got, st = g.render(ray_lod=lod, stepping=stepping)
+            assert st.kernel_variant == vrc.KERNEL_RAY_LOD
+            _lod_parity(got, want, "sse %g stepping %d" % (sse, stepping))
+            assert abs(n_got - n_want) <= 3e-4 * n_want + 16
+        uncounted, _, _ = g.render(ray_lod=lod, count=False)
+        assert (uncounted == g.render(ray_lod=lod)[0]).all()
+        # switching the mode off again renders the list as the reference would: every brick of it
+        with pytest.raises(Exception):
+            g.render(kernel=vrc.KERNEL_GRID_DDA)  # nested boxes are no partition
+
+
+@pytest.mark.parametrize("filter_mode,dtype", [(1, "u8"), (1, "u16"), (0, "u16")])
+def test_ray_lod_per_sample_classification_modes(vrc, filter_mode, dtype):
+    s = _hierarchy(viewport=(96, 80), volume="hash", spin=(-0.7, 0.2), dtype=dtype, alpha=0.3)
+    lod = (1.6, orc.world_space_per_pixel(s))
+    want, n_want = orc.oracle_render(s, ray_lod=lod, filter_mode=filter_mode)
+    with _gpu(s) as g:
+        got, n_got, st = g.render(ray_lod=lod, filter_mode=filter_mode)
+        assert st.kernel_variant == vrc.KERNEL_RAY_LOD
+        _lod_parity(got, want, "filter %d %s" % (filter_mode, dtype))
+        assert abs(n_got - n_want) <= 3e-4 * n_want + 16
+
+
+def test_ray_lod_small_bound_equals_the_leaf_render(vrc):
+    s = _hierarchy(viewport=(128, 96), volume="hash", spin=(0.5, -0.2))
+    leaves = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(128, 96), volume="hash", spin=(0.5, -0.2),
+                             spr=s.render.samplesPerRay)
+    with _gpu(leaves) as g:
+        want, n_want, _ = g.render(kernel=vrc.KERNEL_GRID_DDA)
+    with _gpu(s) as g:
+        got, n_got, _ = g.render(ray_lod=(0.01, orc.world_space_per_pixel(s)))
+    _lod_parity(got, want, "leaves")
+    assert abs(n_got - n_want) <= 3e-4 * n_want + 16
+
+
+def test_ray_lod_partial_hierarchy_clip_planes_eye_inside(vrc):
+    vi = orc.mem_volume_info(64, 64, 64, 16)
+    ids = orc.all_level_ids(vi, [0, 1])
+    ids += [orc.pack(2, x, y, z, 0) for x in range(2) for y in range(2) for z in range(2, 4)]
+    s = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(96, 96), volume="hash", ids=ids,
+                        eye=(0.1, -0.2, 0.45), spin=(0.3, 0.6), planes=[[0.0, 0.0, 1.0, 0.3], [0.6, 0.8, 0.0, 0.25]])
+    lod = (0.8, orc.world_space_per_pixel(s))
+    want, n_want = orc.oracle_render(s, ray_lod=lod)
+    with _gpu(s) as g:
+        got, n_got, _ = g.render(ray_lod=lod)
+    _lod_parity(got, want, "partial hierarchy")
+    assert abs(n_got - n_want) <= 3e-4 * n_want + 16
+
+
+def test_ray_lod_refusals(vrc):
+    s = _hierarchy(viewport=(32, 32), volume="hash")
+    lod = (1.0, orc.world_space_per_pixel(s))
+    with _gpu(s) as g:
+        with pytest.raises(Exception):
+            g.render(ray_lod=lod, variant=1)  # cudaRaycaster rules only
+        with pytest.raises(Exception):
+            g.render(ray_lod=lod, kernel=vrc.KERNEL_LDS)
+        assert g.L.vrc_set_ray_lod(g.ctx, 1, 0.0, 1.0) != 0
+        assert g.L.vrc_set_ray_lod(g.ctx, 1, 1.0, -1.0) != 0
+        g.render(ray_lod=lod)
+    vi = orc.mem_volume_info(64, 64, 64, 16)
+    dup = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(16, 16),
+                          ids=orc.all_level_ids(vi, [2]) + [orc.pack(2, 0, 0, 0, 0)])
+    with _gpu(dup) as g:
+        with pytest.raises(Exception):
+            g.render(ray_lod=lod)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_ray_lod_random_views(vrc, seed):
+    rng = np.random.default_rng(7100 + seed)
+    vox = [int(rng.choice([32, 64, 96])) for _ in range(3)]
+    block = int(rng.choice([16, 32]))
+    vox = [max(v, block) // block * block for v in vox]
+    kw = dict(voxels=tuple(vox), block=block, viewport=(int(rng.integers(40, 200)), int(rng.integers(40, 160))),
+              volume=str(rng.choice(["hash", "mem"])),
+              spin=(float(rng.uniform(-3.1, 3.1)), float(rng.uniform(-1.5, 1.5))),
+              alpha=float(rng.choice([0.05, 0.3, 1.0])))
+    if rng.random() < 0.3:
+        kw["eye"] = (float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-0.4, 0.4)), float(rng.uniform(0.1, 0.9)))
+    s = _hierarchy(**kw)
+    lod = (float(rng.uniform(0.3, 4.0)) * vox[0] / 64.0 * 48.0 / s.H, orc.world_space_per_pixel(s))
+    want, n_want = orc.oracle_render(s, threads=8, ray_lod=lod)
+    with _gpu(s) as g:
+        got, n_got, _ = g.render(ray_lod=lod)
+    _lod_parity(got, want, "seed %d %r lod %r" % (seed, kw, lod))
+    assert abs(n_got - n_want) <= 3e-4 * n_want + 16
