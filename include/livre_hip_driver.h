@@ -42,6 +42,7 @@ typedef struct
     uint32_t samples_per_ray;
     double kernel_ms_sum;     /* raycast kernel time summed over the launches since the last */
     uint32_t kernel_launches; /* lvh_app_get_stats call (HIP events on the render stream)   */
+    uint32_t ray_lod;         /* 1: the frame was rendered with per-ray LOD (lvh_app_set_ray_lod) */
 } lvh_frame_stats;
 
 const char* lvh_last_error( void );
@@ -64,6 +65,11 @@ int lvh_app_set_option( lvh_app* app, int vrc_option, int64_t value );
  * livre/eq/Channel.cpp:284, and its CUDA renderer ignores the field; 16-bit volumes are an
  * extension here and default to (0,65535)) */
 int lvh_app_set_data_range( lvh_app* app, float lo, float hi );
+/* EXTENSION (BASELINE C5): per-ray adaptive LOD.  The pipeline makes the ancestors of the visible
+ * set (SelectVisibles cut at --sse) resident as well and every ray applies the screen-space-error
+ * rule where it is (vrc_set_ray_lod).  Frames whose hierarchy does not fit the atlas in one pass,
+ * and trees with ragged border bricks, are rendered with the per-brick cut (stats.ray_lod = 0). */
+int lvh_app_set_ray_lod( lvh_app* app, int enable );
 /* Frames in flight: the application keeps n Renderer("hip") instances (each with its own device
  * context, stream and pixel buffer) over ONE pipeline (one brick atlas, one pair of caches), as
  * RenderPipelinePlugin::render( Renderer&, ... ) allows; Equalizer's default latency of one frame

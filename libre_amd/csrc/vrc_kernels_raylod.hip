@@ -14,11 +14,16 @@
  */
 #include "vrc_internal.h"
 
+#ifndef VRC_RL_WAVES
 #define VRC_RL_WAVES 4u
+#endif
 #define VRC_RL_THREADS ( 64u * VRC_RL_WAVES )
 
+#ifndef VRC_RL_MIN_BLOCKS
+#define VRC_RL_MIN_BLOCKS 2
+#endif
 template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T >
-__global__ __launch_bounds__( VRC_RL_THREADS, 2 ) void vrc_k_raycast_raylod(
+__global__ __launch_bounds__( VRC_RL_THREADS, VRC_RL_MIN_BLOCKS ) void vrc_k_raycast_raylod(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ levelTables, const ATLAS_T* __restrict__ atlas,
     const vrc_f4* __restrict__ lutGlobal, const uint32_t lutEntries, const vrc_classifier cls,
@@ -26,7 +31,7 @@ __global__ __launch_bounds__( VRC_RL_THREADS, 2 ) void vrc_k_raycast_raylod(
     const uint32_t* __restrict__ tileOrder, const uint32_t tilesX, const uint32_t nTiles )
 {
     /* MODE_TABLE: lodLevels classified tables of 257 entries; else the padded transfer function */
-    extern __shared__ vrc_f4 lutLevels[];
+    extern __shared__ __attribute__( ( aligned( 16 ) ) ) vrc_f4 lutLevels[]; /* 16: ds_read_b128 per entry */
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     for( uint32_t i = tid; i < lutEntries; i += VRC_RL_THREADS )
@@ -35,9 +40,9 @@ __global__ __launch_bounds__( VRC_RL_THREADS, 2 ) void vrc_k_raycast_raylod(
     if( FIXED )
     {
         const uint32_t cyy = f.sbx * VRC_MB_VOXELS - 64u, czz = f.sbx * f.sby * VRC_MB_VOXELS - 512u;
-        const uint32_t u = tid, q = u >> VRC_MB_SHIFT;
-        if( u < 256u )
+        for( uint32_t u = tid; u < 256u; u += VRC_RL_THREADS )
         {
+            const uint32_t q = u >> VRC_MB_SHIFT;
             vrc_addr_tab[u] = u + 504u * q;
             vrc_addr_tab[256u + u] = 8u * u + cyy * q;
             vrc_addr_tab[512u + u] = 64u * u + czz * q;

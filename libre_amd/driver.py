@@ -21,13 +21,13 @@ class FrameStats(C.Structure):  # lvh_frame_stats
     _fields_ = [("n_available", C.c_uint64), ("n_not_available", C.c_uint64),
                 ("n_render_available", C.c_uint64), ("n_passes", C.c_uint32),
                 ("kernel_ms", C.c_float), ("samples", C.c_uint64), ("samples_per_ray", C.c_uint32),
-                ("kernel_ms_sum", C.c_double), ("kernel_launches", C.c_uint32)]
+                ("kernel_ms_sum", C.c_double), ("kernel_launches", C.c_uint32), ("ray_lod", C.c_uint32)]
 
 
 EXPORTS = [
     "lvh_last_error", "lvh_app_create", "lvh_app_destroy", "lvh_app_set_camera",
     "lvh_app_set_modelview", "lvh_app_set_colormap", "lvh_app_set_clip_planes",
-    "lvh_app_set_bands", "lvh_app_set_frames_in_flight", "lvh_app_select_slot", "lvh_app_set_option", "lvh_app_set_data_range", "lvh_app_set_stream", "lvh_app_set_framebuffer", "lvh_app_render_frame",
+    "lvh_app_set_bands", "lvh_app_set_frames_in_flight", "lvh_app_select_slot", "lvh_app_set_option", "lvh_app_set_data_range", "lvh_app_set_ray_lod", "lvh_app_set_stream", "lvh_app_set_framebuffer", "lvh_app_render_frame",
     "lvh_app_get_stats", "lvh_app_wait_uploads", "lvh_app_synchronize", "lvh_app_volume_info",
     "lvh_app_visible_set", "lvh_app_view_matrices", "lvh_app_cache_stats", "lvh_select_visibles",
     "lvh_selftest_cache", "lvh_selftest_plugin_factory", "lvh_selftest_camera",
@@ -58,6 +58,7 @@ def load_library():
     L.lvh_app_select_slot.argtypes = [vp, C.c_uint32]
     L.lvh_app_set_option.argtypes = [vp, C.c_int, C.c_int64]
     L.lvh_app_set_data_range.argtypes = [vp, C.c_float, C.c_float]
+    L.lvh_app_set_ray_lod.argtypes = [vp, C.c_int]
     L.lvh_app_set_stream.argtypes = [vp, vp]
     L.lvh_app_set_framebuffer.argtypes = [vp, vp]
     L.lvh_app_render_frame.argtypes = [vp, vp, C.POINTER(FrameStats)]
@@ -141,6 +142,10 @@ class App:
     def set_data_range(self, lo, hi):
         """dataSourceRange of a volume that is not uint8 (extension)."""
         check(self.L, self.L.lvh_app_set_data_range(self.h, lo, hi))
+
+    def set_ray_lod(self, enable=True):
+        """Per-ray adaptive LOD (extension): ancestors of the visible set resident, LOD chosen along the ray."""
+        check(self.L, self.L.lvh_app_set_ray_lod(self.h, 1 if enable else 0))
 
     def set_stream(self, stream_handle):
         check(self.L, self.L.lvh_app_set_stream(self.h, stream_handle))

@@ -108,6 +108,7 @@ public:
     const CacheStatistics* textureCacheStatistics() const;
     const CacheStatistics* dataCacheStatistics() const;
     uint32_t lastNumberOfPasses() const;
+    bool lastFrameUsedRayLOD() const; /* per-ray LOD was possible for the last frame */
     /** block until the asynchronous upload pipeline is idle */
     void waitForUploads();
 

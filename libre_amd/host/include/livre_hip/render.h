@@ -100,6 +100,11 @@ struct RendererParameters
     uint32_t samplesPerPixel = 1;
     uint32_t maxGPUCacheMemoryMB = 3072;
     uint32_t maxCPUCacheMemoryMB = 8192;
+    /** EXTENSION (not in rendererParameters.fbs): per-ray adaptive LOD.  The pipeline makes the
+     *  ancestors of the visible set resident too and the renderer applies the screen-space-error
+     *  rule of SelectVisibles along every ray (vrc_set_ray_lod). */
+    bool rayLOD = false;
+    bool getRayLOD() const { return rayLOD; }
     uint32_t getMaxLOD() const { return maxLOD; }
     uint32_t getMinLOD() const { return minLOD; }
     float getSSE() const { return screenSpaceError; }

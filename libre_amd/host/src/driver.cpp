@@ -227,6 +227,12 @@ int lvh_app_set_data_range( lvh_app* app, float lo, float hi )
     app->dataRange[1] = hi;
     return 0;
 }
+int lvh_app_set_ray_lod( lvh_app* app, int enable )
+{
+    if( !app ) return fail( "NULL argument" );
+    app->vrParameters.rayLOD = enable != 0;
+    return 0;
+}
 int lvh_app_set_stream( lvh_app* app, void* s )
 {
     if( !app ) return fail( "NULL argument" );
@@ -263,6 +269,7 @@ static void fillStats( lvh_app* app, lvh_frame_stats* s, bool sync )
     s->n_not_available = app->lastStats.nNotAvailable;
     s->n_render_available = app->lastStats.nRenderAvailable;
     s->n_passes = app->hipPipeline().lastNumberOfPasses();
+    s->ray_lod = app->hipPipeline().lastFrameUsedRayLOD() ? 1u : 0u;
     s->samples_per_ray = app->renderer().getComputedSamplesPerRay();
     if( sync )
         app->renderer().kernelStats( &s->kernel_ms, &s->kernel_ms_sum, &s->kernel_launches, &s->samples );

@@ -3,6 +3,7 @@
  * reference function by function (citations inline); device work is the C ABI of vrc_hip.h. */
 #include "livre_hip/hip.h"
 
+#include <unordered_set>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -383,6 +384,12 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
         rData.dataSourceRange[0] = renderInputs.dataSourceRange[0];
         rData.dataSourceRange[1] = renderInputs.dataSourceRange[1];
     }
+    /* per-ray LOD (extension): SelectVisibles.cpp:55-57 worldSpacePerPixel of this frame */
+    const bool rayLod = renderInputs.vrParameters.getRayLOD();
+    throwOnVrcError( vrc_set_ray_lod( _ctx, rayLod ? 1 : 0, renderInputs.vrParameters.getSSE(),
+                                      ( frustum.top() - frustum.bottom() ) /
+                                          float( renderInputs.pixelViewPort[3] ) ),
+                     "vrc_set_ray_lod" );
     throwOnVrcError( vrc_render( _ctx, &viewData, nodeDatas.data(), uint32_t( nodeDatas.size() ),
                                  &rData, pool ),
                      "vrc_render" );
@@ -492,6 +499,33 @@ struct HipRaycastPipeline::Impl
         return visitor.getVisibles();
     }
 
+    /* per-ray LOD (extension): the visible set plus every ancestor of it down to minLOD, each id
+     * once -- the hierarchy the ray-LOD kernel picks levels from.  Only for trees whose bricks
+     * all have the nominal size (the kernel's cell grid needs aligned boxes): false otherwise. */
+    bool withAncestors( const RenderInputs& in, NodeIds& ids ) const
+    {
+        const VolumeInformation& info = in.dataSource.getVolumeInfo();
+        const Vector3ui nominal = info.maximumBlockSize - info.overlap * 2u;
+        std::unordered_set< Identifier > seen;
+        NodeIds all;
+        for( const NodeId& id : ids )
+        {
+            NodeId current = id;
+            while( current.isValid() && seen.insert( current.getId() ).second )
+            {
+                const LODNode node = in.dataSource.getNode( current );
+                if( !node.isValid() || node.getBlockSize() != nominal )
+                    return false;
+                all.push_back( current );
+                if( current.isRoot() || current.getLevel() <= in.vrParameters.getMinLOD() )
+                    break;
+                current = current.getParent();
+            }
+        }
+        ids.swap( all );
+        return true;
+    }
+
     /* DataUploadFilter.cpp:35-49 then CudaTextureUploadFilter.cpp:43-60, for a list of cache
      * misses, on nUploadThreads loaders; element k of the result belongs to ids[k] (empty if
      * the brick could not be made resident) */
@@ -595,6 +629,22 @@ struct HipRaycastPipeline::Impl
         NodeIds nodeIds = visibleSet( in );
         const uint32_t maxNodesPerPass =
             uint32_t( _texturePool->getTextureMem() / _texturePool->getSlotMemSize() );
+        /* per-ray LOD: one pass over the visible set and its ancestors; when that does not fit the
+         * atlas (or the tree is ragged) the frame is rendered with the reference's per-brick cut */
+        bool rayLod = in.vrParameters.getRayLOD();
+        if( rayLod )
+        {
+            NodeIds hierarchy = nodeIds;
+            rayLod = withAncestors( in, hierarchy ) && hierarchy.size() <= maxNodesPerPass;
+            if( rayLod )
+                nodeIds.swap( hierarchy );
+            else if( std::getenv( "LIVRE_HIP_TRACE" ) )
+                std::fprintf( stderr, "[livre_hip] per-ray LOD not possible for this frame (ragged tree or atlas too small): per-brick cut\n" );
+        }
+        RenderInputs plain( in );
+        plain.vrParameters.rayLOD = false;
+        const RenderInputs& inputs = rayLod ? in : plain;
+        _lastRayLod = rayLod;
         const uint32_t numberOfPasses =
             uint32_t( std::ceil( float( nodeIds.size() ) / float( maxNodesPerPass ) ) );
         if( numberOfPasses > 1 )
@@ -629,7 +679,7 @@ struct HipRaycastPipeline::Impl
             const auto tU0 = std::chrono::steady_clock::now();
             const ConstCacheObjects objects = upload( nodesPerPass, in );
             const auto tU1 = std::chrono::steady_clock::now();
-            renderer.render( in, objects, renderStages );
+            renderer.render( inputs, objects, renderStages );
             if( std::getenv( "LIVRE_HIP_TRACE" ) )
                 std::fprintf( stderr, "[livre_hip] pass %u: upload %.2f ms, render call %.2f ms (%zu bricks)\n", i,
                               std::chrono::duration< double, std::milli >( tU1 - tU0 ).count(),
@@ -644,7 +694,7 @@ struct HipRaycastPipeline::Impl
             }
         }
         if( numberOfPasses == 0 ) /* nothing visible: still begin/end the frame */
-            renderer.render( in, ConstCacheObjects(), RENDER_BEGIN | RENDER_END );
+            renderer.render( inputs, ConstCacheObjects(), RENDER_BEGIN | RENDER_END );
         statistics.nAvailable = nodeIds.size();
         statistics.nNotAvailable = 0;
         statistics.nRenderAvailable = statistics.nAvailable;
@@ -654,8 +704,32 @@ struct HipRaycastPipeline::Impl
      * the visible set in the background, ask for a redraw until everything is available */
     void renderAsync( RenderStatistics& statistics, Renderer& renderer, const RenderInputs& in )
     {
-        const NodeIds visibles = visibleSet( in );
-        const ConstCacheObjects objects = generateRenderingSet( *_hipCache, visibles, statistics );
+        NodeIds visibles = visibleSet( in );
+        ConstCacheObjects objects;
+        const uint32_t maxNodes = uint32_t( _texturePool->getTextureMem() / _texturePool->getSlotMemSize() );
+        NodeIds hierarchy = visibles;
+        const bool rayLod = in.vrParameters.getRayLOD() && withAncestors( in, hierarchy ) &&
+                            hierarchy.size() <= maxNodes;
+        _lastRayLod = rayLod;
+        if( rayLod )
+        {
+            /* every resident brick of the hierarchy: the kernel falls back to coarser levels where
+             * a brick is still missing, the job generateRenderingSet does for the per-brick cut */
+            visibles.swap( hierarchy );
+            for( const NodeId& id : visibles )
+            {
+                const ConstCacheObjectPtr obj = _hipCache->get( id.getId() );
+                if( obj )
+                    objects.push_back( obj );
+                obj ? ++statistics.nAvailable : ++statistics.nNotAvailable;
+            }
+            statistics.nRenderAvailable = objects.size();
+        }
+        else
+            objects = generateRenderingSet( *_hipCache, visibles, statistics );
+        RenderInputs plain( in );
+        plain.vrParameters.rayLOD = false;
+        const RenderInputs& inputs = rayLod ? in : plain;
         const bool allAvailable = statistics.nNotAvailable == 0;
         if( !allAvailable )
         {
@@ -678,7 +752,7 @@ struct HipRaycastPipeline::Impl
                 } );
             }
         }
-        renderer.render( in, objects, RENDER_ALL );
+        renderer.render( inputs, objects, RENDER_ALL );
         if( in.redrawFilter ) /* RedrawFilter, livre/eq/Channel.cpp:64-90 */
             in.redrawFilter( allAvailable );
     }
@@ -716,6 +790,7 @@ struct HipRaycastPipeline::Impl
     std::atomic< bool > _asyncBusy{ false };
     std::mutex _initMutex;
     uint32_t _lastPasses;
+    bool _lastRayLod = false;
 };
 
 HipRaycastPipeline::HipRaycastPipeline( const std::string& name )
@@ -744,5 +819,6 @@ const CacheStatistics* HipRaycastPipeline::dataCacheStatistics() const
     return _impl->_dataCache ? &_impl->_dataCache->getStatistics() : nullptr;
 }
 uint32_t HipRaycastPipeline::lastNumberOfPasses() const { return _impl->_lastPasses; }
+bool HipRaycastPipeline::lastFrameUsedRayLOD() const { return _impl->_lastRayLod; }
 void HipRaycastPipeline::waitForUploads() { _impl->_asyncUploadExecutor.wait(); }
 }

@@ -103,6 +103,7 @@ int vrc_pre_render( vrc_ctx* c, const vrc_view_data* v ) { c->w = v->glViewport[
 int vrc_set_framebuffer( vrc_ctx*, void*, uint32_t, uint32_t ) { return VRC_OK; }
 int vrc_get_framebuffer( vrc_ctx* c, void** d, uint32_t* w, uint32_t* h ) { if( d ) *d = nullptr; if( w ) *w = c->w; if( h ) *h = c->h; return VRC_OK; }
 int vrc_set_row_map( vrc_ctx*, const uint32_t*, uint32_t ) { return VRC_OK; }
+int vrc_set_ray_lod( vrc_ctx*, int, float, float ) { return VRC_OK; }
 int vrc_render( vrc_ctx*, const vrc_view_data*, const vrc_node_data*, uint32_t, const vrc_render_data*, vrc_pool* ) { return VRC_OK; }
 int vrc_post_render( vrc_ctx*, float* ) { return VRC_OK; }
 int vrc_synchronize( vrc_ctx* ) { return VRC_OK; }

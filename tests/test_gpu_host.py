@@ -1,5 +1,8 @@
 """GPU tests of the C++ host plugin (RenderPipeline("hip") through the flat driver API):
 frames against the oracle, synchronous / asynchronous / multipass behaviour, sort-first tiles."""
+import ctypes as C
+import os
+
 import numpy as np
 import pytest
 
@@ -421,3 +424,84 @@ def test_random_sort_first_layouts_reassemble_the_frame(drv, seed):
                 out[y0:y0 + h] = fb[off:off + h]
                 off += h
     assert (out == full).all(), (seed, W, H, world, bpr, mode)
+
+
+def _with_ancestors(ids):
+    seen, out = set(), []
+    for nid in ids:
+        cur = int(nid)
+        while cur not in seen:
+            seen.add(cur)
+            out.append(cur)
+            if (cur & 0xF) == 0:
+                break
+            cur = int(orc.lib().orc_nodeid_parent(C.c_uint64(cur)))
+    return out
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_per_ray_lod_through_the_plugin_matches_the_oracle(drv, seed):
+    # EXTENSION (BASELINE C5): the pipeline makes the ancestors of the SelectVisibles cut resident and
+    # the renderer applies the screen-space-error rule along every ray; the oracle renders the
+    # same hierarchy with the same rule
+    from libre_amd import vrc
+    rng = np.random.default_rng(7300 + seed)
+    vox = int(rng.choice([64, 128]))
+    volume = str(rng.choice(["mem", "hash"]))
+    W, H = int(rng.integers(40, 120)), int(rng.integers(40, 120))
+    eye = (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)), float(rng.uniform(0.6, 1.8)))
+    spin = (float(rng.uniform(-3.1, 3.1)), float(rng.uniform(-1.2, 1.2)))
+    sse = float(rng.choice([0.5, 1.0, 2.0, 3.0])) * vox / 64.0 * 48.0 / H
+    uri = "%s://#%d,%d,%d,16" % (volume, vox, vox, vox)
+    with drv.App(uri, W, H, synchronous=bool(seed % 2 == 0), sse=sse, gpu_cache_mb=64) as app:
+        app.set_camera(position=eye, spin=spin)
+        app.set_colormap(orc.linear_ramp_tf(0.3))
+        app.set_option(vrc.OPT_COUNT_SAMPLES, 1)
+        app.set_ray_lod(True)
+        ids = app.visible_set()
+        fb, st = app.render_frame()
+        for _ in range(200):  # asynchronous mode: until the whole hierarchy is resident
+            if st.n_not_available == 0:
+                break
+            app.wait_uploads()
+            fb, st = app.render_frame()
+        assert st.n_not_available == 0
+        if not ids:
+            assert (fb == 0).all()
+            return
+        assert st.ray_lod == 1 and st.n_passes <= 1
+        hierarchy = _with_ancestors(ids)
+        assert st.n_available == len(hierarchy)
+        s = orc.build_scene(voxels=(vox, vox, vox), block=16, viewport=(W, H), ids=hierarchy, spin=spin, eye=eye,
+                            volume=volume, alpha=0.3)
+        assert st.samples_per_ray == s.render.samplesPerRay
+        want, n_want = orc.oracle_render(s, threads=8, ray_lod=(sse, orc.world_space_per_pixel(s)))
+        mx, mean, over = orc.compare(fb, want)
+        assert mx <= 5 * scenes.MAX_ABS and mean <= 4 * scenes.MEAN_ABS and over <= 1e-2, (
+            "seed %d %s eye %r spin %r sse %g levels %r: max %.3g mean %.3g over %.4f" % (
+                seed, uri, eye, spin, sse, sorted({i & 0xF for i in hierarchy}), mx, mean, over))
+        assert abs(int(app.stats().samples) - n_want) <= 5e-4 * n_want + 16
+        # fewer samples than the per-brick cut of the same frame costs
+        app.set_ray_lod(False)
+        _, st2 = app.render_frame()
+        assert st2.ray_lod == 0
+        assert int(app.stats().samples) >= n_want - 16
+
+
+def test_per_ray_lod_falls_back_when_the_hierarchy_does_not_fit(drv):
+    from libre_amd import vrc
+    with drv.App("hash://#128,128,128,16", 64, 64, synchronous=True, sse=0.5, gpu_cache_mb=1) as app:
+        app.set_colormap(orc.linear_ramp_tf(0.3))
+        ref, st_ref = app.render_frame()
+        assert st_ref.n_passes > 1
+        app.set_ray_lod(True)
+        fb, st = app.render_frame()
+        assert st.ray_lod == 0 and st.n_passes == st_ref.n_passes
+        assert np.abs(fb - ref).max() <= 1e-6
+    # ragged tree (border bricks smaller than the nominal size): per-brick cut as well
+    with drv.App("uvf://" + os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mouse_reduced.uvf"),
+                 64, 64, synchronous=True, sse=1.0) as app:
+        ref, _ = app.render_frame()
+        app.set_ray_lod(True)
+        fb, st = app.render_frame()
+        assert st.ray_lod == 0 and np.abs(fb - ref).max() <= 1e-6

@@ -31,15 +31,23 @@ def main():
     ap.add_argument("--kernels", type=int, nargs="*", default=None,
                     help="VRC_KERNEL_* codes to time (default: 2 = grid DDA gather kernel)")
     ap.add_argument("--filters", type=int, nargs="*", default=[0], help="0 nearest, 1 trilinear")
+    ap.add_argument("--ray-lod", type=float, default=0.0,
+                    help="screen-space error: time the per-ray LOD kernel on the same node list (add --levels)")
+    ap.add_argument("--levels", type=int, nargs="*", default=None,
+                    help="tree levels in the node list (default: the leaves; e.g. 0 1 2 3 = whole pyramid)")
     a = ap.parse_args()
     t0 = time.time()
+    ids = None
+    if a.levels is not None:
+        ids = orc.all_level_ids(orc.mem_volume_info(a.voxels, a.voxels, a.voxels, a.block), a.levels)
     s = orc.build_scene(voxels=(a.voxels,) * 3, block=a.block, viewport=(a.viewport,) * 2,
-                        volume=a.volume, spin=tuple(a.spin), alpha=a.alpha)
+                        volume=a.volume, spin=tuple(a.spin), alpha=a.alpha, ids=ids)
     print("scene built in %.1fs: %d nodes spr %d atlas %s" % (time.time() - t0, s.n_nodes,
           s.render.samplesPerRay, s.atlas_dim), flush=True)
     with GpuScene(s) as g:
         print("uploaded in %.1fs" % (time.time() - t0), g.info(), flush=True)
-        fb, n, st = g.render(count=True)
+        lod = (a.ray_lod, orc.world_space_per_pixel(s)) if a.ray_lod > 0 else None
+        fb, n, st = g.render(count=True, ray_lod=lod)
         print("samples/frame %d, counted-kernel %.3f ms, variant %d grid %s alpha max %.3f" %
               (n, st.kernel_ms, st.kernel_variant, list(st.grid_dims), fb[..., 3].max()), flush=True)
         L = g.L
@@ -52,6 +60,8 @@ def main():
         kernels = [vrc.KERNEL_GRID_DDA] + ([vrc.KERNEL_REFERENCE_ORDER] if a.ref_order else [])
         if a.kernels:
             kernels = a.kernels
+        if lod:
+            kernels = [vrc.KERNEL_AUTO]
         for k, flt in [(k, flt) for flt in a.filters for k in kernels]:
             vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_KERNEL, k))
             vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_FILTER, flt))
