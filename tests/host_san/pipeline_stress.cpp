@@ -7,15 +7,16 @@
 
 #include "livre_hip_driver.h"
 
-static int run( int synchronous, uint32_t gpuMb, int frames )
+static int run( int synchronous, uint32_t gpuMb, int frames, int rayLod = 0 )
 {
     lvh_params p;
     std::memset( &p, 0, sizeof( p ) );
     p.width = 64;
     p.height = 64;
     p.synchronous = synchronous;
-    p.min_lod = 3;
+    p.min_lod = rayLod ? 0 : 3; /* per-ray LOD: the whole hierarchy above the cut */
     p.max_lod = 3;
+    p.sse = rayLod ? 0.5f : 0.f;
     p.gpu_cache_mb = gpuMb;
     p.cpu_cache_mb = 4;
     lvh_app* app = nullptr;
@@ -25,6 +26,7 @@ static int run( int synchronous, uint32_t gpuMb, int frames )
         return 1;
     }
     lvh_frame_stats st;
+    lvh_app_set_ray_lod( app, rayLod );
     const float pos[3] = { 0.f, 0.f, 1.5f }, look[3] = { 0.f, 0.f, 0.f };
     for( int i = 0; i < frames; ++i )
     {
@@ -50,6 +52,9 @@ int main()
     rc |= run( 1, 2, 4 );     /* 151 slots for 512 bricks: four passes per frame */
     rc |= run( 0, 16, 30 );   /* asynchronous, fits */
     rc |= run( 0, 2, 60 );    /* asynchronous under cache pressure */
+    rc |= run( 1, 16, 6, 1 ); /* per-ray LOD: cut + ancestors, synchronous */
+    rc |= run( 0, 16, 30, 1 ); /* per-ray LOD, asynchronous: render the resident part of the hierarchy */
+    rc |= run( 0, 2, 30, 1 );  /* hierarchy larger than the atlas: falls back to the per-brick cut */
     if( rc == 0 )
         std::printf( "DONE\n" );
     return rc;
