@@ -680,8 +680,10 @@ hipError_t vrc_launch_raycast_lds( const vrc_raycast_args& a, hipStream_t stream
     /* region shape from the view direction in volume space (the ray through the frame centre) */
     const vrc_ray centre = vrc_setup_ray( a.frame, a.frame.width / 2u, (uint32_t)( a.frame.vpH * 0.5f ) );
     bool flat = fabsf( centre.dir.y ) <= 0.94f;
-    if( const char* force = getenv( "VRC_LDS_SHAPE" ) ) /* A/B measurements only (tools/dev_bench.py) */
+#if defined( VRC_DEV_KNOBS ) /* A/B builds only (tools/build_variants.sh): VRC_LDS_SHAPE=flat|deep */
+    if( const char* force = getenv( "VRC_LDS_SHAPE" ) )
         flat = force[0] == 'f';
+#endif
 #define VRC_LDS_LAUNCH( COUNT, LINEAR, SHAPE )                                                        \
     hipLaunchKernelGGL( ( vrc_k_raycast_lds< COUNT, LINEAR, SHAPE > ), grid, block, 0, stream, a.frame, \
                         a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut, a.classifier,            \
