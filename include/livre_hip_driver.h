@@ -67,8 +67,8 @@ int lvh_app_set_option( lvh_app* app, int vrc_option, int64_t value );
 int lvh_app_set_data_range( lvh_app* app, float lo, float hi );
 /* EXTENSION (BASELINE C5): per-ray adaptive LOD.  The pipeline makes the ancestors of the visible
  * set (SelectVisibles cut at --sse) resident as well and every ray applies the screen-space-error
- * rule where it is (vrc_set_ray_lod).  Frames whose hierarchy does not fit the atlas in one pass,
- * and trees with ragged border bricks, are rendered with the per-brick cut (stats.ray_lod = 0). */
+ * rule where it is (vrc_set_ray_lod).  Frames whose hierarchy does not fit the atlas in one pass
+ * are rendered with the per-brick cut (stats.ray_lod = 0). */
 int lvh_app_set_ray_lod( lvh_app* app, int enable );
 /* Frames in flight: the application keeps n Renderer("hip") instances (each with its own device
  * context, stream and pixel buffer) over ONE pipeline (one brick atlas, one pair of caches), as

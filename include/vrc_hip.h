@@ -33,6 +33,8 @@ extern "C" {
 #define VRC_EFULL 3      /* no free slot in the pool: slot = (-1,-1,-1), TexturePool.cu:180-181 */
 #define VRC_ENOMEM 4     /* allocation failed */
 #define VRC_EUNSUPPORTED 5 /* unsupported data type / channel count, TexturePool.cu:66-67 */
+#define VRC_EHIERARCHY 6  /* vrc_set_ray_lod is on and the node list of vrc_render is not a brick hierarchy
+                          * (nothing was rendered; the caller may render its per-brick cut instead) */
 
 typedef struct vrc_ctx vrc_ctx;   /* replaces cuda::Renderer (cuda/Renderer.cuh:69-112) */
 typedef struct vrc_pool vrc_pool; /* replaces cuda::TexturePool (cuda/TexturePool.cuh:42-103) */
@@ -123,12 +125,14 @@ int vrc_get_option( vrc_ctx* ctx, int option, int64_t* value );
  * (livre/core/render/SelectVisibles.cpp:52-68: a brick is fine enough when
  * worldSpacePerVoxel / worldSpacePerPixel * near / (near + distance) <= screenSpaceError at the
  * point of its box nearest to the near plane).  With this on, the node list of vrc_render is a
- * hierarchy of resident bricks (a cut of the octree plus any of its ancestors; boxes of different
- * levels nest, boxes of one level do not overlap, all aligned to the smallest box) and every ray
- * applies that criterion at each brick-sized cell it enters: it samples the coarsest level that is
- * fine enough there (else the next coarser one present, else the next finer), with step and
- * opacity exponent scaled by 2^level.  world_space_per_pixel = (frustum.top - frustum.bottom) /
- * window height, as in SelectVisibles.cpp:57.  cudaRaycaster variant only. */
+ * hierarchy of resident bricks (a cut of the octree plus any of its ancestors): boxes of different
+ * levels nest; every level is a regular grid of bricks anchored at the min corner of all boxes
+ * (border bricks may be smaller, levels need not align with each other: UVF trees), one brick per
+ * cell at most; else VRC_EHIERARCHY.  Every ray applies the criterion where it enters a brick: it
+ * samples the coarsest level that is fine enough there (else the next coarser one present, else
+ * the next finer), with step and opacity exponent scaled by 2^level.  world_space_per_pixel =
+ * (frustum.top - frustum.bottom) / window height, as in SelectVisibles.cpp:57.  cudaRaycaster
+ * variant only. */
 int vrc_set_ray_lod( vrc_ctx* ctx, int enable, float screen_space_error, float world_space_per_pixel );
 
 /* ---- texture pool (brick atlas) ----------------------------------------------------------- */

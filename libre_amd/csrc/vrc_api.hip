@@ -130,7 +130,7 @@ struct vrc_ctx
     uint32_t cachedLodLevels = 0;
     double cachedFinestVoxel = 0.0;
     bool cachedClamp = false;
-    vrc_frame cachedGridFrame; /* only grid* fields are meaningful */
+    vrc_frame cachedGridFrame = {}; /* only grid* / lod* fields are meaningful */
 
     /* sort-first row map */
     uint32_t* dRowMap = nullptr;
@@ -992,7 +992,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     if( c->rayLod )
     {
         if( !c->cachedLodOk )
-            return fail( VRC_EINVAL, "vrc_render: per-ray LOD needs a hierarchy of cell-aligned bricks (levels may nest, bricks of one level may not overlap)" );
+            return fail( VRC_EHIERARCHY, "vrc_render: per-ray LOD needs a brick hierarchy (every level a regular grid of bricks, one brick per cell)" );
         if( c->optVariant != VRC_VARIANT_CUDARAYCASTER )
             return fail( VRC_EINVAL, "vrc_render: per-ray LOD is defined for the cudaRaycaster variant only" );
         if( c->optKernel != VRC_KERNEL_AUTO )

@@ -40,6 +40,10 @@
 #define VRC_EARLY_EXIT 0.999f     /* Renderer.cu:34 */
 #define VRC_EPSILON 0.0000000001f /* Renderer.cu:35 */
 
+/* per-ray LOD: levels of the brick hierarchy; entries of one classified table */
+#define VRC_MAX_LOD_LEVELS 8
+#define VRC_LUT_ENTRIES 257u
+
 /* atlas micro-block: 8x8x8 voxels, x fastest inside the block */
 #define VRC_MB 8u
 #define VRC_MB_SHIFT 3u
@@ -99,10 +103,18 @@ struct vrc_frame
      * every pixel starts from 0 and is stored, hit or miss (the clear of
      * cuda/PixelBufferObject.cu:80 folded into the march: one pass over the frame less) */
     uint32_t clearFirst;
-    /* per-ray LOD (vrc_pixel_ray_lod): number of levels in the node list and
-     * finestVoxelWorldSize / (screenSpaceError * worldSpacePerPixel) */
+    /* per-ray LOD (vrc_pixel_ray_lod): number of levels in the node list,
+     * finestVoxelWorldSize / (screenSpaceError * worldSpacePerPixel), and one brick grid per
+     * level anchored at gridMin (gridDim / cellSize are level 0's): cells per axis, 1 / cell size,
+     * offset of the level's cell -> node table in the table buffer; lodMax = max corner of all
+     * bricks; lodEps = 1 % of the finest voxel */
     uint32_t lodLevels;
     float lodBase;
+    float lodEps;
+    float lodMax[3];
+    float lodInvCell[VRC_MAX_LOD_LEVELS][3];
+    int32_t lodDim[VRC_MAX_LOD_LEVELS][3];
+    uint32_t lodTable[VRC_MAX_LOD_LEVELS];
 };
 
 /* Atlas memory layout.  The logical atlas is the reference's 3-D array of slots
@@ -1078,7 +1090,7 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
 }
 
 /* ------------------------------------------------------------------------------------------
- * EXTENSION: per-ray adaptive LOD (BASELINE C5; VRC_OPT_RAY_LOD).  The reference selects the LOD
+ * EXTENSION: per-ray adaptive LOD (BASELINE C5; vrc_set_ray_lod).  The reference selects the LOD
  * per brick on the host: a brick is fine enough when its voxels, seen from the point of its box
  * nearest to the near plane, are at most screenSpaceError pixels wide
  * (livre/core/render/SelectVisibles.cpp:52-68: pixelPerVoxel * near / (near + distance) <= sse).
@@ -1086,18 +1098,18 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
  * octree plus ancestors, all resident, boxes may nest); with voxel size vw0 * 2^j at level j and
  * eye-space depth / near = t / tNearPlane along a ray, level j is fine enough from
  *     T_j = tNearPlane * lodBase * 2^j,   lodBase = vw0 / (screenSpaceError * worldSpacePerPixel).
- * The ray walks the cells of the finest brick size (the DDA of vrc_pixel_grid_dda); entering a
- * cell at parameter te it wants level k = #{ j >= 1 : T_j <= te } and takes the brick covering
- * the cell at the first level present in the order k, k+1, ..., K-1, k-1, ..., 0.  Consecutive
- * cells with the same brick form one run; a run is marched like a reference brick segment
+ * Every level is a regular grid of bricks (border bricks may be smaller; the levels of a ragged
+ * tree need not align with each other).  The ray hops from brick to brick: at parameter te it
+ * wants level k = #{ j >= 1 : T_j <= te } and takes, at the point o + d*(te + eps), the brick of
+ * the first level that has one there in the order k, k+1, ..., K-1, k-1, ..., 0; the run ends
+ * where the ray leaves that brick's box (the finest level's cell where there is no brick) and
+ * the level is chosen anew.  A run is marched like a reference brick segment
  * (Renderer.cu:195-223: sampling restarts at the run's entry point) with step stepSize * 2^j and
  * opacity exponent alphaCorrection * 2^j (classified table of level j: lut + j * 257; classifier
  * exponent scaled for the per-sample modes), so a level-j brick costs 2^-j of the samples and
  * the opacity of a homogeneous stretch does not depend on the level it is sampled at.
- * gridTable holds one cell -> node table per level, level-major.  CUDA variant only.
+ * gridTable holds the cell -> node table of every level (f.lodTable offsets).  CUDA variant only.
  * ---------------------------------------------------------------------------------------- */
-#define VRC_MAX_LOD_LEVELS 8
-#define VRC_LUT_ENTRIES 257u
 
 VRC_HD vrc_segment vrc_run_segment( const vrc_ray& r, float tA, float tB, float stepSize )
 {
@@ -1149,17 +1161,14 @@ VRC_HD void vrc_pixel_ray_lod( const vrc_frame& f, const vrc_dev_node* __restric
         return;
 
     const vrc_f3 gmin = { f.gridMin[0], f.gridMin[1], f.gridMin[2] };
-    const vrc_f3 gmax = { f.gridMin[0] + f.cellSize[0] * (float)f.gridDim[0],
-                          f.gridMin[1] + f.cellSize[1] * (float)f.gridDim[1],
-                          f.gridMin[2] + f.cellSize[2] * (float)f.gridDim[2] };
+    const vrc_f3 gmax = { f.lodMax[0], f.lodMax[1], f.lodMax[2] };
     float t0, t1;
     const bool any = vrc_intersect_box( r.origin, r.invDir, gmin, gmax, &t0, &t1 );
     t0 = fmaxf( fmaxf( t0, r.tNearGlobal ), fmaxf( r.tNearPlane, 0.0f ) );
     t1 = fminf( t1, r.tFarGlobal );
-    if( any && t0 <= t1 )
+    if( any && t0 < t1 )
     {
         const int K = (int)f.lodLevels;
-        const int cells = f.gridDim[0] * f.gridDim[1] * f.gridDim[2];
         float tBase;
         {
             VRC_STRICT_FP
@@ -1168,86 +1177,85 @@ VRC_HD void vrc_pixel_ray_lod( const vrc_frame& f, const vrc_dev_node* __restric
         const float o[3] = { r.origin.x, r.origin.y, r.origin.z };
         const float d[3] = { r.dir.x, r.dir.y, r.dir.z };
         const float id[3] = { r.invDir.x, r.invDir.y, r.invDir.z };
-        int cell[3], stepDir[3];
-        float tMax[3], tDelta[3];
-#pragma unroll
-        for( int a = 0; a < 3; ++a )
+        const int maxHops = 3 * ( f.gridDim[0] + f.gridDim[1] + f.gridDim[2] ) + 16;
+        float te = t0;
+        for( int hop = 0; hop < maxHops && te < t1; ++hop )
         {
-            const float p = o[a] + d[a] * t0;
-            int c = (int)floorf( ( p - f.gridMin[a] ) * f.invCellSize[a] );
-            c = c < 0 ? 0 : ( c > f.gridDim[a] - 1 ? f.gridDim[a] - 1 : c );
-            cell[a] = c;
-            const bool pos = d[a] > 0.0f;
-            stepDir[a] = pos ? 1 : -1;
-            const float boundary = f.gridMin[a] + f.cellSize[a] * (float)( pos ? c + 1 : c );
-            tMax[a] = ( boundary - o[a] ) * id[a];
-            tDelta[a] = f.cellSize[a] * fabsf( id[a] );
-        }
-        int32_t runNode = -1;
-        float runStart = t0, te = t0;
-        bool done = false;
-        const int maxSteps = f.gridDim[0] + f.gridDim[1] + f.gridDim[2] + 3;
-        for( int it = 0; it <= maxSteps && !done; ++it )
-        {
-            /* the brick for this cell (-1 past the end of the walk: flushes the last run) */
+            int k = 0;
+            float T = tBase;
+            for( int j = 1; j < K; ++j )
+            {
+                T = T + T; /* T_j, exact */
+                k += T <= te ? 1 : 0;
+            }
+            float tp, p[3];
+            {
+                VRC_STRICT_FP
+                tp = te + f.lodEps;
+                p[0] = o[0] + d[0] * tp;
+                p[1] = o[1] + d[1] * tp;
+                p[2] = o[2] + d[2] * tp;
+            }
             int32_t node = -1;
-            if( it < maxSteps && te <= t1 && cell[0] >= 0 && cell[0] < f.gridDim[0] && cell[1] >= 0 &&
-                cell[1] < f.gridDim[1] && cell[2] >= 0 && cell[2] < f.gridDim[2] )
+            for( int s = 0; s < K && node < 0; ++s )
             {
-                int k = 0;
-                float T = tBase;
-                for( int j = 1; j < K; ++j )
+                const int lv = s < K - k ? k + s : K - 1 - s; /* k..K-1, then k-1..0 */
+                int c[3];
+#pragma unroll
+                for( int a = 0; a < 3; ++a )
                 {
-                    T = T + T; /* T_j, exact */
-                    k += T <= te ? 1 : 0;
+                    VRC_STRICT_FP
+                    c[a] = (int)floorf( ( p[a] - f.gridMin[a] ) * f.lodInvCell[lv][a] );
+                    c[a] = c[a] < 0 ? 0 : ( c[a] > f.lodDim[lv][a] - 1 ? f.lodDim[lv][a] - 1 : c[a] );
                 }
-                const int c = ( cell[2] * f.gridDim[1] + cell[1] ) * f.gridDim[0] + cell[0];
-                for( int j = k; j < K && node < 0; ++j )
-                    node = gridTable[j * cells + c];
-                for( int j = k - 1; j >= 0 && node < 0; --j )
-                    node = gridTable[j * cells + c];
+                node = gridTable[f.lodTable[lv] + ( c[2] * f.lodDim[lv][1] + c[1] ) * f.lodDim[lv][0] + c[0]];
             }
-            else
-                done = true;
-            if( node != runNode || done )
+            /* where the ray leaves the brick (no brick here: the finest level's grid cell) */
+            vrc_dev_node n;
+            float bmin[3], bmax[3];
+            if( node >= 0 )
             {
-                if( runNode >= 0 )
+                n = nodes[node];
+#pragma unroll
+                for( int a = 0; a < 3; ++a )
                 {
-                    const float tB = fminf( te, t1 );
-                    const vrc_dev_node n = nodes[runNode];
-                    const float scale = (float)( 1u << n.level );
-                    const float levelStep = f.stepSize * scale;
-                    const vrc_segment s = vrc_run_segment( r, runStart, tB, levelStep );
-                    vrc_classifier lc = cls;
-                    lc.alphaCorrection = cls.alphaCorrection * scale;
-                    const vrc_f4* ll = MODE == VRC_MODE_TABLE ? lut + n.level * VRC_LUT_ENTRIES : lut;
-                    if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP >(
-                            f, n, s, atlas, ll, lc, color, nSamples, levelStep ) )
-                        break;
+                    bmin[a] = n.aabbMin[a];
+                    bmax[a] = n.aabbMin[a] + n.aabbSize[a];
                 }
-                runNode = node;
-                runStart = te;
-            }
-            if( done )
-                break;
-            /* advance to the next cell along the ray */
-            const float tNext = fminf( fminf( tMax[0], tMax[1] ), tMax[2] );
-            if( tMax[0] <= tMax[1] && tMax[0] <= tMax[2] )
-            {
-                cell[0] += stepDir[0];
-                tMax[0] += tDelta[0];
-            }
-            else if( tMax[1] <= tMax[2] )
-            {
-                cell[1] += stepDir[1];
-                tMax[1] += tDelta[1];
             }
             else
             {
-                cell[2] += stepDir[2];
-                tMax[2] += tDelta[2];
+#pragma unroll
+                for( int a = 0; a < 3; ++a )
+                {
+                    VRC_STRICT_FP
+                    int c = (int)floorf( ( p[a] - f.gridMin[a] ) * f.invCellSize[a] );
+                    c = c < 0 ? 0 : ( c > f.gridDim[a] - 1 ? f.gridDim[a] - 1 : c );
+                    bmin[a] = f.gridMin[a] + f.cellSize[a] * (float)c;
+                    bmax[a] = f.gridMin[a] + f.cellSize[a] * (float)( c + 1 );
+                }
             }
-            te = tNext;
+            float tB;
+            {
+                VRC_STRICT_FP
+                float tX = ( ( d[0] > 0.0f ? bmax[0] : bmin[0] ) - o[0] ) * id[0];
+                tX = fminf( tX, ( ( d[1] > 0.0f ? bmax[1] : bmin[1] ) - o[1] ) * id[1] );
+                tX = fminf( tX, ( ( d[2] > 0.0f ? bmax[2] : bmin[2] ) - o[2] ) * id[2] );
+                tB = fminf( fmaxf( tX, tp ), t1 ); /* always forward */
+            }
+            if( node >= 0 )
+            {
+                const float scale = (float)( 1u << n.level );
+                const float levelStep = f.stepSize * scale;
+                const vrc_segment s = vrc_run_segment( r, te, tB, levelStep );
+                vrc_classifier lc = cls;
+                lc.alphaCorrection = cls.alphaCorrection * scale;
+                const vrc_f4* ll = MODE == VRC_MODE_TABLE ? lut + n.level * VRC_LUT_ENTRIES : lut;
+                if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP >( f, n, s, atlas, ll, lc, color,
+                                                                             nSamples, levelStep ) )
+                    break;
+            }
+            te = tB;
         }
     }
     pixelBuffer[pixelPos] = color;

@@ -26,7 +26,7 @@ struct vrc_host_tables
     std::vector< int32_t > grid;
     bool gridOk = false;
     bool clamp = false;
-    vrc_frame g; /* grid fields only */
+    vrc_frame g = {}; /* grid and lod* fields only */
     /* per-ray LOD (vrc_build_lod_tables): one cell -> node table per level in `grid` */
     bool lodOk = false;
     uint32_t lodLevels = 0;
@@ -164,11 +164,13 @@ inline void vrc_build_tables( const vrc_atlas_geom& p, const vrc_node_data* in, 
 }
 
 /* Per-ray LOD tables (vrc_pixel_ray_lod): the node list is a hierarchy -- boxes of different
- * levels may nest, boxes of one level may not overlap.  Level of a node = log2 of its voxel size
- * over the finest voxel size in the list (robust for the smaller bricks at the border of ragged
- * trees, whose box size says nothing about their level).  Cells have the size of the smallest
- * box; t.grid holds lodLevels tables of gridDim cells, level-major.  Overwrites t.grid / t.g;
- * t.lodOk = false (and t.grid empty) when the list does not fit this form. */
+ * levels may nest, a level is a regular grid of bricks anchored at the min corner of all boxes,
+ * with at most one brick per cell (border bricks may be smaller than the cell; the levels of a
+ * ragged tree such as UVF's need not align with each other).  Level of a node = rank of its voxel
+ * size among the sizes in the list (sizes within 5 % are one level), robust for ragged border
+ * bricks whose box size says nothing about their level.  t.grid holds the cell -> node table of
+ * every level, t.g the grids (lod* fields; gridMin / gridDim / cellSize = level 0).  Overwrites
+ * t.grid / t.g; t.lodOk = false (and t.grid empty) when the list does not fit this form. */
 inline void vrc_build_lod_tables( const vrc_atlas_geom& p, const vrc_node_data* in, uint32_t n,
                                   vrc_host_tables& t )
 {
@@ -178,7 +180,7 @@ inline void vrc_build_lod_tables( const vrc_atlas_geom& p, const vrc_node_data* 
     if( n == 0 || t.nodes.size() != n )
         return;
     std::vector< double > vw( n );
-    double vw0 = 0.0;
+    double vw0 = 0.0, gmin[3], gmax[3];
     for( uint32_t i = 0; i < n; ++i )
     {
         const double texVox = std::floor( (double)in[i].textureSize[0] * p.atlasDim[0] + 0.5 );
@@ -186,72 +188,86 @@ inline void vrc_build_lod_tables( const vrc_atlas_geom& p, const vrc_node_data* 
             return;
         vw[i] = (double)in[i].aabbSize[0] / texVox;
         vw0 = i == 0 ? vw[i] : std::min( vw0, vw[i] );
-    }
-    uint32_t levels = 0;
-    for( uint32_t i = 0; i < n; ++i )
-    {
-        long lv;
-        if( !vrc_near_int( std::log2( vw[i] / vw0 ), 0.05, &lv ) || lv < 0 || lv >= VRC_MAX_LOD_LEVELS )
-            return;
-        t.nodes[i].level = (uint32_t)lv;
-        levels = std::max( levels, (uint32_t)lv + 1u );
-    }
-    double cell[3], gmin[3], gmax[3];
-    for( int a = 0; a < 3; ++a )
-    {
-        cell[a] = in[0].aabbSize[a];
-        gmin[a] = in[0].aabbMin[a];
-        gmax[a] = (double)in[0].aabbMin[a] + in[0].aabbSize[a];
-    }
-    for( uint32_t i = 1; i < n; ++i )
         for( int a = 0; a < 3; ++a )
         {
-            cell[a] = std::min( cell[a], (double)in[i].aabbSize[a] );
-            gmin[a] = std::min( gmin[a], (double)in[i].aabbMin[a] );
-            gmax[a] = std::max( gmax[a], (double)in[i].aabbMin[a] + in[i].aabbSize[a] );
+            const double lo = in[i].aabbMin[a], hi = lo + (double)in[i].aabbSize[a];
+            gmin[a] = i == 0 ? lo : std::min( gmin[a], lo );
+            gmax[a] = i == 0 ? hi : std::max( gmax[a], hi );
         }
-    long dim[3];
-    for( int a = 0; a < 3; ++a )
-        if( !( cell[a] > 0.0 ) ||
-            !vrc_near_int( ( gmax[a] - gmin[a] ) / cell[a], 1e-3, &dim[a] ) || dim[a] < 1 ||
-            dim[a] > 4096 )
+    }
+    /* levels: clusters of voxel sizes, finest first */
+    double rep[VRC_MAX_LOD_LEVELS];
+    uint32_t levels = 0;
+    for( ;; )
+    {
+        double next = 0.0;
+        for( uint32_t i = 0; i < n; ++i )
+            if( ( levels == 0 || vw[i] > rep[levels - 1] * 1.05 ) && ( next == 0.0 || vw[i] < next ) )
+                next = vw[i];
+        if( next == 0.0 )
+            break;
+        if( levels == VRC_MAX_LOD_LEVELS )
             return;
-    const double cells = (double)dim[0] * dim[1] * dim[2];
-    if( cells * levels > 64.0 * 1024 * 1024 )
-        return;
-    t.grid.assign( (size_t)cells * levels, -1 );
+        rep[levels++] = next;
+    }
+    double cell[VRC_MAX_LOD_LEVELS][3] = {};
     for( uint32_t i = 0; i < n; ++i )
     {
-        long i0[3], cnt[3];
+        uint32_t lv = 0;
+        while( lv + 1 < levels && vw[i] > rep[lv] * 1.05 )
+            ++lv;
+        t.nodes[i].level = lv;
         for( int a = 0; a < 3; ++a )
-            if( !vrc_near_int( ( (double)in[i].aabbMin[a] - gmin[a] ) / cell[a], 1e-3, &i0[a] ) ||
-                !vrc_near_int( (double)in[i].aabbSize[a] / cell[a], 1e-3, &cnt[a] ) || cnt[a] < 1 ||
-                i0[a] < 0 || i0[a] + cnt[a] > dim[a] )
+            cell[lv][a] = std::max( cell[lv][a], (double)in[i].aabbSize[a] );
+    }
+    size_t total = 0;
+    for( uint32_t lv = 0; lv < levels; ++lv )
+    {
+        for( int a = 0; a < 3; ++a )
+        {
+            if( !( cell[lv][a] > 0.0 ) )
+                return;
+            const double cnt = std::ceil( ( gmax[a] - gmin[a] ) / cell[lv][a] - 1e-3 );
+            if( cnt < 1.0 || cnt > 4096.0 )
+                return;
+            t.g.lodDim[lv][a] = (int32_t)cnt;
+            t.g.lodInvCell[lv][a] = (float)( 1.0 / cell[lv][a] );
+        }
+        t.g.lodTable[lv] = (uint32_t)total;
+        total += (size_t)t.g.lodDim[lv][0] * t.g.lodDim[lv][1] * t.g.lodDim[lv][2];
+        if( total > 64u * 1024u * 1024u )
+            return;
+    }
+    t.grid.assign( total, -1 );
+    for( uint32_t i = 0; i < n; ++i )
+    {
+        const uint32_t lv = t.nodes[i].level;
+        long idx[3];
+        for( int a = 0; a < 3; ++a )
+            if( !vrc_near_int( ( (double)in[i].aabbMin[a] - gmin[a] ) / cell[lv][a], 1e-3, &idx[a] ) ||
+                idx[a] < 0 || idx[a] >= t.g.lodDim[lv][a] )
             {
                 t.grid.clear();
                 return;
             }
-        int32_t* table = t.grid.data() + (size_t)t.nodes[i].level * (size_t)cells;
-        for( long z = i0[2]; z < i0[2] + cnt[2]; ++z )
-            for( long y = i0[1]; y < i0[1] + cnt[1]; ++y )
-                for( long x = i0[0]; x < i0[0] + cnt[0]; ++x )
-                {
-                    int32_t& c = table[( (size_t)z * dim[1] + y ) * dim[0] + x];
-                    if( c != -1 ) /* two bricks of one level over the same cell */
-                    {
-                        t.grid.clear();
-                        return;
-                    }
-                    c = (int32_t)i;
-                }
+        int32_t& c = t.grid[t.g.lodTable[lv] +
+                            ( (size_t)idx[2] * t.g.lodDim[lv][1] + idx[1] ) * t.g.lodDim[lv][0] + idx[0]];
+        if( c != -1 ) /* two bricks of one level in one cell */
+        {
+            t.grid.clear();
+            return;
+        }
+        c = (int32_t)i;
     }
     for( int a = 0; a < 3; ++a )
     {
         t.g.gridMin[a] = (float)gmin[a];
-        t.g.cellSize[a] = (float)cell[a];
-        t.g.invCellSize[a] = (float)( 1.0 / cell[a] );
-        t.g.gridDim[a] = (int32_t)dim[a];
+        t.g.lodMax[a] = (float)gmax[a];
+        t.g.cellSize[a] = (float)cell[0][a];
+        t.g.invCellSize[a] = t.g.lodInvCell[0][a];
+        t.g.gridDim[a] = t.g.lodDim[0][a];
     }
+    t.g.lodEps = (float)( vw0 * 0.01 );
     t.lodLevels = levels;
     t.finestVoxelWorld = vw0;
     t.lodOk = true;
@@ -274,6 +290,17 @@ inline void vrc_fill_frame( vrc_frame& f, const vrc_view_data& view, const vrc_r
         f.cellSize[i] = gridFrame.cellSize[i];
         f.invCellSize[i] = gridFrame.invCellSize[i];
         f.gridDim[i] = gridFrame.gridDim[i];
+        f.lodMax[i] = gridFrame.lodMax[i];
+    }
+    f.lodEps = gridFrame.lodEps;
+    for( int lv = 0; lv < VRC_MAX_LOD_LEVELS; ++lv )
+    {
+        f.lodTable[lv] = gridFrame.lodTable[lv];
+        for( int i = 0; i < 3; ++i )
+        {
+            f.lodInvCell[lv][i] = gridFrame.lodInvCell[lv][i];
+            f.lodDim[lv][i] = gridFrame.lodDim[lv][i];
+        }
     }
     f.vpX = (float)view.glViewport[0];
     f.vpY = (float)view.glViewport[1];

@@ -89,10 +89,13 @@ public:
     void kernelStats( float* lastMs, double* sumMs, uint32_t* launches, uint64_t* samples );
     void synchronize();
     uint32_t getComputedSamplesPerRay() const { return _computedSamplesPerRay; }
+    /** the last render() went through the per-ray LOD kernel (false: per-brick cut) */
+    bool lastRenderUsedRayLOD() const { return _lastRayLod; }
 
 private:
     vrc_ctx* _ctx;
     uint32_t _computedSamplesPerRay;
+    bool _lastRayLod = false;
 };
 
 /** renderers/cudaRaycaster/CudaRaycastPipeline.h:37-60 */

@@ -269,7 +269,7 @@ static void fillStats( lvh_app* app, lvh_frame_stats* s, bool sync )
     s->n_not_available = app->lastStats.nNotAvailable;
     s->n_render_available = app->lastStats.nRenderAvailable;
     s->n_passes = app->hipPipeline().lastNumberOfPasses();
-    s->ray_lod = app->hipPipeline().lastFrameUsedRayLOD() ? 1u : 0u;
+    s->ray_lod = ( app->hipPipeline().lastFrameUsedRayLOD() && app->renderer().lastRenderUsedRayLOD() ) ? 1u : 0u;
     s->samples_per_ray = app->renderer().getComputedSamplesPerRay();
     if( sync )
         app->renderer().kernelStats( &s->kernel_ms, &s->kernel_ms_sum, &s->kernel_launches, &s->samples );

@@ -330,6 +330,7 @@ void HipRaycastRenderer::preRender( const RenderInputs& renderInputs, const Cons
 
 void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCacheObjects& renderData )
 {
+    _lastRayLod = false;
     if( renderData.empty() ) /* CudaRaycastRenderer.cpp:157-158 */
         return;
     /* CudaRaycastRenderer.cpp:160-163: sort front to back by distance of the box centre.
@@ -390,9 +391,24 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
                                       ( frustum.top() - frustum.bottom() ) /
                                           float( renderInputs.pixelViewPort[3] ) ),
                      "vrc_set_ray_lod" );
-    throwOnVrcError( vrc_render( _ctx, &viewData, nodeDatas.data(), uint32_t( nodeDatas.size() ),
-                                 &rData, pool ),
-                     "vrc_render" );
+    int rc = vrc_render( _ctx, &viewData, nodeDatas.data(), uint32_t( nodeDatas.size() ), &rData, pool );
+    _lastRayLod = rayLod && rc == VRC_OK;
+    if( rayLod && rc == VRC_EHIERARCHY )
+    {
+        /* the bricks do not form level grids (a tree the table builder does not know): render the
+         * per-brick cut, i.e. the list without the ancestors the pipeline added */
+        std::unordered_set< Identifier > parents;
+        for( const auto& kv : keyed )
+            for( const NodeId& parent : NodeId( kv.second->getId() ).getParents() )
+                parents.insert( parent.getId() );
+        std::vector< vrc_node_data > cut;
+        for( size_t i = 0; i < keyed.size(); ++i )
+            if( !parents.count( keyed[i].second->getId() ) )
+                cut.push_back( nodeDatas[i] );
+        throwOnVrcError( vrc_set_ray_lod( _ctx, 0, 1.0f, 1.0f ), "vrc_set_ray_lod" );
+        rc = vrc_render( _ctx, &viewData, cut.data(), uint32_t( cut.size() ), &rData, pool );
+    }
+    throwOnVrcError( rc, "vrc_render" );
 }
 
 void HipRaycastRenderer::postRender( const RenderInputs&, const ConstCacheObjects& )
@@ -500,12 +516,10 @@ struct HipRaycastPipeline::Impl
     }
 
     /* per-ray LOD (extension): the visible set plus every ancestor of it down to minLOD, each id
-     * once -- the hierarchy the ray-LOD kernel picks levels from.  Only for trees whose bricks
-     * all have the nominal size (the kernel's cell grid needs aligned boxes): false otherwise. */
+     * once -- the hierarchy the ray-LOD kernel picks levels from.  false if a node is missing
+     * from the tree. */
     bool withAncestors( const RenderInputs& in, NodeIds& ids ) const
     {
-        const VolumeInformation& info = in.dataSource.getVolumeInfo();
-        const Vector3ui nominal = info.maximumBlockSize - info.overlap * 2u;
         std::unordered_set< Identifier > seen;
         NodeIds all;
         for( const NodeId& id : ids )
@@ -514,7 +528,7 @@ struct HipRaycastPipeline::Impl
             while( current.isValid() && seen.insert( current.getId() ).second )
             {
                 const LODNode node = in.dataSource.getNode( current );
-                if( !node.isValid() || node.getBlockSize() != nominal )
+                if( !node.isValid() )
                     return false;
                 all.push_back( current );
                 if( current.isRoot() || current.getLevel() <= in.vrParameters.getMinLOD() )

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvrc_hip.so")
 
-VRC_OK, VRC_EINVAL, VRC_EHIP, VRC_EFULL, VRC_ENOMEM, VRC_EUNSUPPORTED = range(6)
+VRC_OK, VRC_EINVAL, VRC_EHIP, VRC_EFULL, VRC_ENOMEM, VRC_EUNSUPPORTED, VRC_EHIERARCHY = range(7)
 OPT_KERNEL, OPT_FILTER, OPT_TF_FRAC_BITS, OPT_COUNT_SAMPLES, OPT_TILE_ORDER, OPT_STEPPING, OPT_VARIANT = range(1, 8)
 VARIANT_CUDARAYCASTER, VARIANT_GLRAYCASTER = 0, 1
 FILTER_NEAREST, FILTER_TRILINEAR = 0, 1

@@ -900,25 +900,31 @@ static uint64_t raycast_pixel_gl( const job_t* j, uint32_t x, uint32_t y )
  *     worldSpacePerVoxel / worldSpacePerPixel * near / (near + distance) <= screenSpaceError
  * at the point of its box nearest to the near plane.  Definition used here (the HIP kernel's
  * vrc_pixel_ray_lod must reproduce it):
- *   - nodes form a hierarchy: level(i) = log2( voxel size of node i / finest voxel size in the
- *     list ), voxel size = aabbSize.x / (textureSize.x * atlasDim.x); boxes of one level do not
- *     overlap, all boxes are aligned to cells of the smallest box size;
+ *   - nodes form a hierarchy.  Voxel size of a node = aabbSize.x / (textureSize.x * atlasDim.x);
+ *     sizes within 5 % of each other are one level, levels numbered from the finest (0); a level
+ *     is a regular grid of bricks of its largest box size anchored at the min corner of all
+ *     boxes (border bricks may be smaller: ragged trees such as UVF's, whose levels do not
+ *     align with each other, are fine), one brick per grid cell at most;
  *   - along a ray eye-space depth / near = t / tNearPlane, so level j is fine enough from
  *     T_j = tNearPlane * lodBase * 2^j, lodBase = finest voxel size / (sse * worldSpacePerPixel);
- *   - the ray walks the cells (3-D DDA).  Entering a cell at te it wants level
- *     k = #{ j in 1..K-1 : T_j <= te } and takes the brick over that cell at the first level
- *     present in the order k, k+1, .., K-1, k-1, .., 0;
- *   - consecutive cells with the same brick are one run [tA, tB]; a run is integrated like a
- *     reference brick segment (Renderer.cu:195-223) with stepSize * 2^level and opacity exponent
- *     alphaCorrection * 2^level.
+ *   - the ray hops from brick to brick.  At parameter te it wants level
+ *     k = #{ j in 1..K-1 : T_j <= te } and takes, at the point o + d*(te + eps), the brick of the
+ *     first level that has one there in the order k, k+1, .., K-1, k-1, .., 0; the run ends where
+ *     the ray leaves that brick's box (or the finest level's grid cell where there is no brick),
+ *     and the level is chosen anew there.  eps = 1 % of the finest voxel;
+ *   - a run is integrated like a reference brick segment (Renderer.cu:195-223) with
+ *     stepSize * 2^level and opacity exponent alphaCorrection * 2^level.
  * ---------------------------------------------------------------------------------------- */
 #define LOD_MAX_LEVELS 8
 typedef struct lod_grid
 {
-    int K, dim[3];
-    float gmin[3], cell[3], invCell[3];
-    float lodBase;
-    int32_t* tables; /* K * dim.x*dim.y*dim.z, level-major, -1 = none */
+    int K;
+    int dim[LOD_MAX_LEVELS][3];
+    float gmin[3], gmax[3];
+    float cell[LOD_MAX_LEVELS][3], invCell[LOD_MAX_LEVELS][3];
+    size_t offset[LOD_MAX_LEVELS];
+    float lodBase, eps;
+    int32_t* tables; /* per level dim.x*dim.y*dim.z entries at offset[level], -1 = none */
     uint8_t* level;  /* per node */
 } lod_grid;
 
@@ -929,6 +935,15 @@ static int near_int( double v, double tol, long* out )
     return fabs( v - r ) <= tol;
 }
 
+static void lod_grid_free( lod_grid* g )
+{
+    if( !g )
+        return;
+    free( g->tables );
+    free( g->level );
+    free( g );
+}
+
 static lod_grid* lod_grid_build( const orc_node_data* nodes, uint32_t n, const uint32_t atlasDim[3],
                                  float sse, float worldPerPixel )
 {
@@ -937,7 +952,7 @@ static lod_grid* lod_grid_build( const orc_node_data* nodes, uint32_t n, const u
     lod_grid* g = (lod_grid*)calloc( 1, sizeof( lod_grid ) );
     double* vw = (double*)malloc( n * sizeof( double ) );
     g->level = (uint8_t*)malloc( n );
-    double vw0 = 0.0, cell[3], gmin[3], gmax[3];
+    double gmin[3], gmax[3], vw0 = 0.0;
     for( uint32_t i = 0; i < n; ++i )
     {
         const double texVox = floor( (double)nodes[i].textureSize[0] * atlasDim[0] + 0.5 );
@@ -945,80 +960,95 @@ static lod_grid* lod_grid_build( const orc_node_data* nodes, uint32_t n, const u
         vw0 = i == 0 ? vw[i] : fmin( vw0, vw[i] );
         for( int a = 0; a < 3; ++a )
         {
-            const double lo = nodes[i].aabbMin[a], sz = nodes[i].aabbSize[a];
-            cell[a] = i == 0 ? sz : fmin( cell[a], sz );
+            const double lo = nodes[i].aabbMin[a], hi = lo + (double)nodes[i].aabbSize[a];
             gmin[a] = i == 0 ? lo : fmin( gmin[a], lo );
-            gmax[a] = i == 0 ? lo + sz : fmax( gmax[a], lo + sz );
+            gmax[a] = i == 0 ? hi : fmax( gmax[a], hi );
         }
     }
+    /* levels: clusters of voxel sizes, finest first */
+    double rep[LOD_MAX_LEVELS];
     int ok = 1;
     g->K = 0;
+    for( ;; )
+    {
+        /* the smallest size not within 5 % of (or below) the last level's */
+        double next = 0.0;
+        for( uint32_t i = 0; i < n; ++i )
+            if( ( g->K == 0 || vw[i] > rep[g->K - 1] * 1.05 ) && ( next == 0.0 || vw[i] < next ) )
+                next = vw[i];
+        if( next == 0.0 )
+            break;
+        if( g->K == LOD_MAX_LEVELS )
+        {
+            ok = 0;
+            break;
+        }
+        rep[g->K++] = next;
+    }
+    double cell[LOD_MAX_LEVELS][3];
+    memset( cell, 0, sizeof( cell ) );
     for( uint32_t i = 0; i < n && ok; ++i )
     {
-        long lv;
-        ok = near_int( log2( vw[i] / vw0 ), 0.05, &lv ) && lv >= 0 && lv < LOD_MAX_LEVELS;
+        int lv = 0;
+        while( lv + 1 < g->K && vw[i] > rep[lv] * 1.05 )
+            ++lv;
         g->level[i] = (uint8_t)lv;
-        if( ok && lv + 1 > g->K )
-            g->K = (int)lv + 1;
+        for( int a = 0; a < 3; ++a )
+            cell[lv][a] = fmax( cell[lv][a], (double)nodes[i].aabbSize[a] );
     }
-    long dim[3] = { 0, 0, 0 };
-    for( int a = 0; a < 3 && ok; ++a )
-        ok = cell[a] > 0.0 && near_int( ( gmax[a] - gmin[a] ) / cell[a], 1e-3, &dim[a] ) && dim[a] >= 1 &&
-             dim[a] <= 4096;
-    size_t cells = 0;
+    size_t total = 0;
+    for( int lv = 0; lv < g->K && ok; ++lv )
+        for( int a = 0; a < 3 && ok; ++a )
+        {
+            ok = cell[lv][a] > 0.0;
+            if( !ok )
+                break;
+            const double cnt = ceil( ( gmax[a] - gmin[a] ) / cell[lv][a] - 1e-3 );
+            ok = cnt >= 1.0 && cnt <= 4096.0;
+            g->dim[lv][a] = (int)cnt;
+            g->cell[lv][a] = (float)cell[lv][a];
+            g->invCell[lv][a] = (float)( 1.0 / cell[lv][a] );
+            if( a == 2 )
+            {
+                g->offset[lv] = total;
+                total += (size_t)g->dim[lv][0] * g->dim[lv][1] * g->dim[lv][2];
+            }
+        }
     if( ok )
     {
-        cells = (size_t)dim[0] * dim[1] * dim[2];
-        g->tables = (int32_t*)malloc( cells * g->K * sizeof( int32_t ) );
-        for( size_t i = 0; i < cells * g->K; ++i )
+        g->tables = (int32_t*)malloc( total * sizeof( int32_t ) );
+        for( size_t i = 0; i < total; ++i )
             g->tables[i] = -1;
     }
     for( uint32_t i = 0; i < n && ok; ++i )
     {
-        long i0[3], cnt[3];
+        const int lv = g->level[i];
+        long idx[3];
         for( int a = 0; a < 3 && ok; ++a )
-            ok = near_int( ( (double)nodes[i].aabbMin[a] - gmin[a] ) / cell[a], 1e-3, &i0[a] ) &&
-                 near_int( (double)nodes[i].aabbSize[a] / cell[a], 1e-3, &cnt[a] ) && cnt[a] >= 1 &&
-                 i0[a] >= 0 && i0[a] + cnt[a] <= dim[a];
+            ok = near_int( ( (double)nodes[i].aabbMin[a] - gmin[a] ) / cell[lv][a], 1e-3, &idx[a] ) &&
+                 idx[a] >= 0 && idx[a] < g->dim[lv][a];
         if( !ok )
             break;
-        int32_t* table = g->tables + (size_t)g->level[i] * cells;
-        for( long z = i0[2]; z < i0[2] + cnt[2]; ++z )
-            for( long y = i0[1]; y < i0[1] + cnt[1]; ++y )
-                for( long x = i0[0]; x < i0[0] + cnt[0]; ++x )
-                {
-                    int32_t* c = &table[( (size_t)z * dim[1] + y ) * dim[0] + x];
-                    if( *c != -1 )
-                        ok = 0;
-                    *c = (int32_t)i;
-                }
+        int32_t* c = &g->tables[g->offset[lv] +
+                                ( (size_t)idx[2] * g->dim[lv][1] + idx[1] ) * g->dim[lv][0] + idx[0]];
+        if( *c != -1 ) /* two bricks of one level in one cell */
+            ok = 0;
+        *c = (int32_t)i;
     }
     free( vw );
     if( !ok )
     {
-        free( g->tables );
-        free( g->level );
-        free( g );
+        lod_grid_free( g );
         return NULL;
     }
     for( int a = 0; a < 3; ++a )
     {
-        g->dim[a] = (int)dim[a];
         g->gmin[a] = (float)gmin[a];
-        g->cell[a] = (float)cell[a];
-        g->invCell[a] = (float)( 1.0 / cell[a] );
+        g->gmax[a] = (float)gmax[a];
     }
     g->lodBase = (float)( vw0 / ( (double)sse * (double)worldPerPixel ) );
+    g->eps = (float)( vw0 * 0.01 );
     return g;
-}
-
-static void lod_grid_free( lod_grid* g )
-{
-    if( !g )
-        return;
-    free( g->tables );
-    free( g->level );
-    free( g );
 }
 
 /* integrate one run [tA, tB] of the ray through one brick; returns 1 on early exit */
@@ -1112,75 +1142,71 @@ static uint64_t raycast_pixel_ray_lod( const job_t* j, uint32_t x, uint32_t y )
     const f3 nEye = normalize_f3( e3 );
     const float tNearPlane = -viewData->nearPlane / nEye.z;
 
-    /* the ray's interval inside the cell grid */
+    /* the ray's interval inside the box of all bricks */
     const f3 gridMin = { g->gmin[0], g->gmin[1], g->gmin[2] };
-    const f3 gridMax = { g->gmin[0] + g->cell[0] * (float)g->dim[0], g->gmin[1] + g->cell[1] * (float)g->dim[1],
-                         g->gmin[2] + g->cell[2] * (float)g->dim[2] };
+    const f3 gridMax = { g->gmax[0], g->gmax[1], g->gmax[2] };
     float t0, t1;
     const int any = intersect_box( origin, dir, gridMin, gridMax, &t0, &t1 );
     t0 = fmaxf( fmaxf( t0, tNearGlobal ), fmaxf( tNearPlane, 0.0f ) );
     t1 = fminf( t1, tFarGlobal );
-    if( any && t0 <= t1 )
+    if( any && t0 < t1 )
     {
         const float o[3] = { origin.x, origin.y, origin.z };
         const float d[3] = { dir.x, dir.y, dir.z };
+        const float invD[3] = { 1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z };
         const float tBase = tNearPlane * g->lodBase;
-        const size_t cells = (size_t)g->dim[0] * g->dim[1] * g->dim[2];
-        int cell[3], stepDir[3];
-        float tMax[3], tDelta[3];
-        for( int a = 0; a < 3; ++a )
+        const int maxHops = 3 * ( g->dim[0][0] + g->dim[0][1] + g->dim[0][2] ) + 16;
+        float te = t0;
+        for( int hop = 0; hop < maxHops && te < t1; ++hop )
         {
-            const float invD = 1.0f / d[a];
-            const float p = o[a] + d[a] * t0;
-            int c = (int)floorf( ( p - g->gmin[a] ) * g->invCell[a] );
-            if( c < 0 ) c = 0;
-            if( c > g->dim[a] - 1 ) c = g->dim[a] - 1;
-            cell[a] = c;
-            stepDir[a] = d[a] > 0.0f ? 1 : -1;
-            const float boundary = g->gmin[a] + g->cell[a] * (float)( d[a] > 0.0f ? c + 1 : c );
-            tMax[a] = ( boundary - o[a] ) * invD;
-            tDelta[a] = g->cell[a] * fabsf( invD );
-        }
-        int runNode = -1;
-        float runStart = t0, te = t0;
-        const int maxCells = g->dim[0] + g->dim[1] + g->dim[2] + 3;
-        for( int it = 0;; ++it )
-        {
+            int k = 0;
+            float T = tBase;
+            for( int lv = 1; lv < g->K; ++lv )
+            {
+                T = T + T;
+                if( T <= te )
+                    ++k;
+            }
+            const float tp = te + g->eps;
+            const float p[3] = { o[0] + d[0] * tp, o[1] + d[1] * tp, o[2] + d[2] * tp };
             int node = -1;
-            const int inside = it < maxCells && te <= t1 && cell[0] >= 0 && cell[0] < g->dim[0] &&
-                               cell[1] >= 0 && cell[1] < g->dim[1] && cell[2] >= 0 && cell[2] < g->dim[2];
-            if( inside )
+            for( int s = 0; s < g->K && node < 0; ++s )
             {
-                int k = 0;
-                float T = tBase;
-                for( int lv = 1; lv < g->K; ++lv )
+                const int lv = s < g->K - k ? k + s : g->K - 1 - s; /* k..K-1, then k-1..0 */
+                int c[3];
+                for( int a = 0; a < 3; ++a )
                 {
-                    T = T + T;
-                    if( T <= te )
-                        ++k;
+                    c[a] = (int)floorf( ( p[a] - g->gmin[a] ) * g->invCell[lv][a] );
+                    if( c[a] < 0 ) c[a] = 0;
+                    if( c[a] > g->dim[lv][a] - 1 ) c[a] = g->dim[lv][a] - 1;
                 }
-                const size_t c = ( (size_t)cell[2] * g->dim[1] + cell[1] ) * g->dim[0] + cell[0];
-                for( int lv = k; lv < g->K && node < 0; ++lv )
-                    node = g->tables[lv * cells + c];
-                for( int lv = k - 1; lv >= 0 && node < 0; --lv )
-                    node = g->tables[lv * cells + c];
+                node = g->tables[g->offset[lv] + ( (size_t)c[2] * g->dim[lv][1] + c[1] ) * g->dim[lv][0] + c[0]];
             }
-            if( node != runNode || !inside )
-            {
-                if( runNode >= 0 &&
-                    integrate_run( j, &j->nodes[runNode], g->level[runNode], origin, dir, runStart,
-                                   fminf( te, t1 ), color, &nSamples ) )
-                    break;
-                runNode = node;
-                runStart = te;
-            }
-            if( !inside )
+            /* where the ray leaves the brick (no brick here: the finest level's grid cell) */
+            float bmin[3], bmax[3];
+            if( node >= 0 )
+                for( int a = 0; a < 3; ++a )
+                {
+                    bmin[a] = j->nodes[node].aabbMin[a];
+                    bmax[a] = j->nodes[node].aabbMin[a] + j->nodes[node].aabbSize[a];
+                }
+            else
+                for( int a = 0; a < 3; ++a )
+                {
+                    int c = (int)floorf( ( p[a] - g->gmin[a] ) * g->invCell[0][a] );
+                    if( c < 0 ) c = 0;
+                    if( c > g->dim[0][a] - 1 ) c = g->dim[0][a] - 1;
+                    bmin[a] = g->gmin[a] + g->cell[0][a] * (float)c;
+                    bmax[a] = g->gmin[a] + g->cell[0][a] * (float)( c + 1 );
+                }
+            float tX = ( ( d[0] > 0.0f ? bmax[0] : bmin[0] ) - o[0] ) * invD[0];
+            tX = fminf( tX, ( ( d[1] > 0.0f ? bmax[1] : bmin[1] ) - o[1] ) * invD[1] );
+            tX = fminf( tX, ( ( d[2] > 0.0f ? bmax[2] : bmin[2] ) - o[2] ) * invD[2] );
+            const float tB = fminf( fmaxf( tX, tp ), t1 ); /* always forward */
+            if( node >= 0 &&
+                integrate_run( j, &j->nodes[node], g->level[node], origin, dir, te, tB, color, &nSamples ) )
                 break;
-            const float tNext = fminf( fminf( tMax[0], tMax[1] ), tMax[2] );
-            const int a = ( tMax[0] <= tMax[1] && tMax[0] <= tMax[2] ) ? 0 : ( tMax[1] <= tMax[2] ? 1 : 2 );
-            cell[a] += stepDir[a];
-            tMax[a] += tDelta[a];
-            te = tNext;
+            te = tB;
         }
     }
     px[0] = color[0];
@@ -1261,7 +1287,7 @@ uint64_t orc_raycast( const uint8_t* atlas, const uint32_t atlasDim[3], float* p
         lodGrid = lod_grid_build( nodes, nodeCount, atlasDim, job.opt.lodScreenSpaceError,
                                   job.opt.lodWorldSpacePerPixel );
         if( !lodGrid )
-            return UINT64_MAX; /* the node list is not a cell-aligned hierarchy */
+            return UINT64_MAX; /* the node list is not a brick hierarchy */
         job.lod = lodGrid;
     }
     if( job.opt.rowStride == 0 ) job.opt.rowStride = 1;

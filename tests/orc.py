@@ -394,7 +394,7 @@ def oracle_render(s, frac_bits=8, threads=8, rows=None, fb=None, filter_mode=0, 
                       s.tf.ctypes.data, C.byref(s.view), s.n_nodes, s.nodes, C.byref(s.render),
                       C.byref(opt))
     if int(n) == 2 ** 64 - 1:
-        raise RuntimeError("orc_raycast: the node list is not a cell-aligned hierarchy")
+        raise RuntimeError("orc_raycast: the node list is not a brick hierarchy")
     return fb, int(n)
 
 

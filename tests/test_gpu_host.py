@@ -498,10 +498,28 @@ def test_per_ray_lod_falls_back_when_the_hierarchy_does_not_fit(drv):
         fb, st = app.render_frame()
         assert st.ray_lod == 0 and st.n_passes == st_ref.n_passes
         assert np.abs(fb - ref).max() <= 1e-6
-    # ragged tree (border bricks smaller than the nominal size): per-brick cut as well
-    with drv.App("uvf://" + os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mouse_reduced.uvf"),
-                 64, 64, synchronous=True, sse=1.0) as app:
-        ref, _ = app.render_frame()
-        app.set_ray_lod(True)
-        fb, st = app.render_frame()
-        assert st.ray_lod == 0 and np.abs(fb - ref).max() <= 1e-6
+
+
+def test_per_ray_lod_on_the_uvf_fixture(drv):
+    # BASELINE C5's input format: a ragged UVF tree (75x75x138 voxels, 28^3 bricks, two levels whose brick
+    # grids do not align) rendered with per-ray LOD + early ray termination through the plugin
+    from libre_amd import vrc
+    uri = "uvf://" + os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mouse_reduced.uvf")
+    for sse, alpha in ((1.0, 0.3), (1.6, 1.0), (0.4, 0.3)):
+        with drv.App(uri, 112, 96, synchronous=True, sse=sse, gpu_cache_mb=8) as app:
+            app.set_camera(spin=(0.6, 0.3))
+            app.set_colormap(orc.linear_ramp_tf(alpha))
+            app.set_option(vrc.OPT_COUNT_SAMPLES, 1)
+            app.set_ray_lod(True)
+            ids = app.visible_set()
+            fb, st = app.render_frame()
+            assert st.ray_lod == 1
+            hierarchy = _with_ancestors(ids)
+            assert st.n_available == len(hierarchy)
+            s = orc.scene_from_datasource(drv, uri, hierarchy, (112, 96), spin=(0.6, 0.3), alpha=alpha)
+            assert s.render.samplesPerRay == st.samples_per_ray
+            want, n_want = orc.oracle_render(s, threads=8, ray_lod=(sse, orc.world_space_per_pixel(s)))
+            assert want[..., 3].max() > 0.3
+            mx, mean, over = orc.compare(fb, want)
+            assert mx <= 5 * scenes.MAX_ABS and mean <= 4 * scenes.MEAN_ABS and over <= 1e-2, (sse, mx, mean, over)
+            assert abs(int(app.stats().samples) - n_want) <= 5e-4 * n_want + 16

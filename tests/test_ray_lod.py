@@ -167,3 +167,57 @@ def test_random_views(seed):
         assert ok
         _parity(got, want, "seed %d k%d %r lod %r" % (seed, kernel, kw, lod))
         assert abs(n_got - n_want) <= 3e-4 * n_want + 16, (seed, kernel, kw)
+
+
+# ---- ragged trees: the reference's UVF fixture (75x75x138 voxels, bricks of 28^3, two levels whose
+# ---- brick grids do not align: 38 voxels at the coarse level stand for 75) -------------------------------
+
+def _uvf_hierarchy(viewport, **kw):
+    import os
+    from libre_amd import driver
+    driver.load_library()
+    uri = "uvf://" + os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mouse_reduced.uvf")
+    info = driver.datasource_info(uri)
+    ids = []
+    for level in range(info["depth"]):
+        for x in range(info["root_blocks"][0] << level):
+            for y in range(info["root_blocks"][1] << level):
+                for z in range(info["root_blocks"][2] << level):
+                    nid = orc.pack(level, x, y, z, 0)
+                    if driver.datasource_node(uri, nid)["valid"]:
+                        ids.append(nid)
+    return orc.scene_from_datasource(driver, uri, ids, viewport, **kw), ids
+
+
+@pytest.mark.parametrize("sse", [0.4, 1.0, 1.6, 4.0])
+def test_ragged_uvf_tree(sse):
+    s, ids = _uvf_hierarchy((56, 48), spin=(0.6, 0.3), alpha=0.3)
+    assert len(ids) == 45 + 12
+    lod = (sse, orc.world_space_per_pixel(s))
+    want, n_want = orc.oracle_render(s, ray_lod=lod)
+    assert want[..., 3].max() > 0.3
+    for kernel in (1, 3, 5):
+        if kernel == 5:
+            want, n_want = orc.oracle_render(s, ray_lod=lod, filter_mode=1)
+        got, n_got, ok = orc.harness_render_ray_lod(s, lod, kernel=kernel)
+        assert ok
+        _parity(got, want, "uvf sse %g kernel %d" % (sse, kernel))
+        assert abs(n_got - n_want) <= 3e-4 * n_want + 16
+
+
+def test_ragged_uvf_tree_level_extremes():
+    # a bound only the fine level meets = the 45 leaves rendered per brick; a bound both meet = the
+    # 12 coarse bricks with doubled step
+    s, ids = _uvf_hierarchy((56, 48), spin=(0.6, 0.3), alpha=0.3)
+    import os
+    from libre_amd import driver
+    uri = "uvf://" + os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mouse_reduced.uvf")
+    leaves = orc.scene_from_datasource(driver, uri, [i for i in ids if (i & 0xF) == 1], (56, 48), spin=(0.6, 0.3),
+                                       alpha=0.3)
+    wpp = orc.world_space_per_pixel(s)
+    fine, n_fine = orc.oracle_render(s, ray_lod=(0.01, wpp))
+    want, n_want = orc.oracle_render(leaves)
+    _parity(fine, want, "uvf leaves")
+    assert abs(n_fine - n_want) <= 3e-4 * n_want + 16
+    coarse, n_coarse = orc.oracle_render(s, ray_lod=(1e3, wpp))
+    assert abs(2 * n_coarse - n_fine) <= 0.1 * n_fine
