@@ -10,8 +10,7 @@
 
 #include "render.h"
 
-struct vrc_ctx;
-struct vrc_pool;
+#include "vrc_hip.h" /* vrc_node_data */
 
 namespace livre
 {
@@ -96,6 +95,14 @@ private:
     vrc_ctx* _ctx;
     uint32_t _computedSamplesPerRay;
     bool _lastRayLod = false;
+    /* render(): the sorted node list of the last call, kept while the bricks and the model-view matrix repeat */
+    std::vector< const CacheObject* > _sortedFor;
+    std::vector< Identifier > _sortedForIds;
+    std::vector< Vector3f > _sortedForTex;
+    std::vector< Identifier > _sortedIds;
+    std::vector< vrc_node_data > _sortedNodes;
+    Matrix4f _sortedMV;
+    vrc_pool* _sortedPool = nullptr;
 };
 
 /** renderers/cudaRaycaster/CudaRaycastPipeline.h:37-60 */

@@ -336,7 +336,20 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
     /* CudaRaycastRenderer.cpp:160-163: sort front to back by distance of the box centre.
      * (keys are precomputed; the reference recomputes them inside the comparator) */
     const Frustum& frustum = renderInputs.frameInfo.frustum;
+    /* the same bricks seen through the same model-view matrix sort into the same list: a frame
+     * that repeats the last one (a standing camera, the ranks of a sort-first frame at a high
+     * frame rate) skips the 512 transforms, the sort and the fill (~30 us of host time) */
+    bool sameList = _sortedFor.size() == renderData.size() && _sortedMV == frustum.getMVMatrix();
+    for( size_t i = 0; sameList && i < renderData.size(); ++i )
+    {
+        /* same object: same address, and -- an address can be recycled -- same brick in the same slot */
+        const HipTextureObject& obj = static_cast< const HipTextureObject& >( *renderData[i] );
+        sameList = _sortedFor[i] == renderData[i].get() && _sortedForIds[i] == obj.getId() &&
+                   _sortedForTex[i] == obj.getTexPosition();
+    }
     std::vector< std::pair< float, ConstCacheObjectPtr > > keyed;
+    if( !sameList )
+    {
     keyed.reserve( renderData.size() );
     for( const auto& obj : renderData )
     {
@@ -346,11 +359,17 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
     std::stable_sort( keyed.begin(), keyed.end(),
                       []( const std::pair< float, ConstCacheObjectPtr >& a,
                           const std::pair< float, ConstCacheObjectPtr >& b ) { return a.first < b.first; } );
+    }
 
     const VolumeInformation& volInfo = renderInputs.dataSource.getVolumeInfo();
-    std::vector< vrc_node_data > nodeDatas;
+    std::vector< vrc_node_data >& nodeDatas = _sortedNodes;
+    vrc_pool* pool = _sortedPool;
+    if( !sameList )
+    {
+    nodeDatas.clear();
     nodeDatas.reserve( keyed.size() );
-    vrc_pool* pool = nullptr;
+    _sortedIds.clear();
+    pool = nullptr;
     for( const auto& kv : keyed )
     {
         const ConstHipTextureObjectPtr hipObject =
@@ -367,8 +386,21 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
             nd.aabbSize[i] = sz[i];
         }
         nodeDatas.push_back( nd );
+        _sortedIds.push_back( kv.second->getId() );
         if( !pool )
             pool = hipObject->getTexturePool()._getHipTexturePool();
+    }
+    _sortedPool = pool;
+    _sortedMV = frustum.getMVMatrix();
+    _sortedFor.resize( renderData.size() );
+    _sortedForIds.resize( renderData.size() );
+    _sortedForTex.resize( renderData.size() );
+    for( size_t i = 0; i < renderData.size(); ++i )
+    {
+        _sortedFor[i] = renderData[i].get();
+        _sortedForIds[i] = renderData[i]->getId();
+        _sortedForTex[i] = static_cast< const HipTextureObject& >( *renderData[i] ).getTexPosition();
+    }
     }
     const vrc_view_data viewData = makeViewData( renderInputs );
     vrc_render_data rData; /* CudaRaycastRenderer.cpp:199-206 */
@@ -398,12 +430,12 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
         /* the bricks do not form level grids (a tree the table builder does not know): render the
          * per-brick cut, i.e. the list without the ancestors the pipeline added */
         std::unordered_set< Identifier > parents;
-        for( const auto& kv : keyed )
-            for( const NodeId& parent : NodeId( kv.second->getId() ).getParents() )
+        for( const Identifier id : _sortedIds )
+            for( const NodeId& parent : NodeId( id ).getParents() )
                 parents.insert( parent.getId() );
         std::vector< vrc_node_data > cut;
-        for( size_t i = 0; i < keyed.size(); ++i )
-            if( !parents.count( keyed[i].second->getId() ) )
+        for( size_t i = 0; i < _sortedIds.size(); ++i )
+            if( !parents.count( _sortedIds[i] ) )
                 cut.push_back( nodeDatas[i] );
         throwOnVrcError( vrc_set_ray_lod( _ctx, 0, 1.0f, 1.0f ), "vrc_set_ray_lod" );
         rc = vrc_render( _ctx, &viewData, cut.data(), uint32_t( cut.size() ), &rData, pool );
@@ -637,9 +669,67 @@ struct HipRaycastPipeline::Impl
         return cacheObjects;
     }
 
+    /* what the visible set of a frame depends on (visibleSet()); a frame whose key equals the
+     * last one's and whose bricks were all resident in one pass is rendered from the kept
+     * brick list: no tree traversal, no 512 cache look-ups (~35 us of host time, which is what
+     * bounds the frame rate of a rank that renders an eighth of a sort-first frame) */
+    struct FrameKey
+    {
+        Matrix4f mv, proj;
+        int32_t windowHeight = 0;
+        float sse = 0.f;
+        uint32_t minLOD = 0, maxLOD = 0, timeStep = 0;
+        Range range{ { 0.f, 0.f } };
+        std::vector< Vector4f > planes;
+        const DataSource* dataSource = nullptr;
+        bool rayLOD = false;
+        bool operator==( const FrameKey& o ) const
+        {
+            if( !( mv == o.mv ) || !( proj == o.proj ) || windowHeight != o.windowHeight || sse != o.sse ||
+                minLOD != o.minLOD || maxLOD != o.maxLOD || timeStep != o.timeStep || range != o.range ||
+                dataSource != o.dataSource || rayLOD != o.rayLOD || planes.size() != o.planes.size() )
+                return false;
+            for( size_t i = 0; i < planes.size(); ++i )
+                for( int k = 0; k < 4; ++k )
+                    if( planes[i][k] != o.planes[i][k] )
+                        return false;
+            return true;
+        }
+    };
+    static FrameKey frameKey( const RenderInputs& in )
+    {
+        FrameKey k;
+        k.mv = in.frameInfo.frustum.getMVMatrix();
+        k.proj = in.frameInfo.frustum.getProjMatrix();
+        k.windowHeight = in.pixelViewPort[3];
+        k.sse = in.vrParameters.getSSE();
+        k.minLOD = in.vrParameters.getMinLOD();
+        k.maxLOD = in.vrParameters.getMaxLOD();
+        k.timeStep = in.frameInfo.timeStep;
+        k.range = in.renderDataRange;
+        k.planes = in.renderSettings.getClipPlanes().getPlanes();
+        k.dataSource = &in.dataSource;
+        k.rayLOD = in.vrParameters.getRayLOD();
+        return k;
+    }
+
     /* CudaRaycastPipeline.cpp:129-206 */
     void renderSync( RenderStatistics& statistics, Renderer& renderer, const RenderInputs& in )
     {
+        const FrameKey key = frameKey( in );
+        if( _keptValid && key == _keptKey )
+        {
+            RenderInputs plainKept( in );
+            plainKept.vrParameters.rayLOD = false;
+            renderer.render( _lastRayLod ? in : plainKept, _keptObjects, RENDER_ALL );
+            statistics.nAvailable = _keptObjects.size();
+            statistics.nNotAvailable = 0;
+            statistics.nRenderAvailable = statistics.nAvailable;
+            return;
+        }
+        /* the kept bricks are referenced, hence not evictable: let go before anything is loaded */
+        _keptValid = false;
+        _keptObjects.clear();
         NodeIds nodeIds = visibleSet( in );
         const uint32_t maxNodesPerPass =
             uint32_t( _texturePool->getTextureMem() / _texturePool->getSlotMemSize() );
@@ -694,6 +784,12 @@ struct HipRaycastPipeline::Impl
             const ConstCacheObjects objects = upload( nodesPerPass, in );
             const auto tU1 = std::chrono::steady_clock::now();
             renderer.render( inputs, objects, renderStages );
+            if( numberOfPasses == 1 && objects.size() == nodeIds.size() )
+            {
+                _keptObjects = objects;
+                _keptKey = key;
+                _keptValid = true;
+            }
             if( std::getenv( "LIVRE_HIP_TRACE" ) )
                 std::fprintf( stderr, "[livre_hip] pass %u: upload %.2f ms, render call %.2f ms (%zu bricks)\n", i,
                               std::chrono::duration< double, std::milli >( tU1 - tU0 ).count(),
@@ -792,6 +888,7 @@ struct HipRaycastPipeline::Impl
         _asyncUploadExecutor.wait();
         _uploadExecutor.wait();
         /* texture objects release their slots into the pool: drop them before the pool */
+        _keptObjects.clear();
         _hipCache.reset();
         _dataCache.reset();
         _texturePool.reset();
@@ -805,6 +902,9 @@ struct HipRaycastPipeline::Impl
     std::mutex _initMutex;
     uint32_t _lastPasses;
     bool _lastRayLod = false;
+    FrameKey _keptKey;
+    ConstCacheObjects _keptObjects;
+    bool _keptValid = false;
 };
 
 HipRaycastPipeline::HipRaycastPipeline( const std::string& name )

@@ -523,3 +523,44 @@ def test_per_ray_lod_on_the_uvf_fixture(drv):
             mx, mean, over = orc.compare(fb, want)
             assert mx <= 5 * scenes.MAX_ABS and mean <= 4 * scenes.MEAN_ABS and over <= 1e-2, (sse, mx, mean, over)
             assert abs(int(app.stats().samples) - n_want) <= 5e-4 * n_want + 16
+
+
+def test_repeated_frames_take_the_kept_brick_list_and_stay_correct(drv):
+    # a frame whose visible-set inputs repeat is rendered from the kept brick list and the kept sorted
+    # node table (no tree traversal, no cache look-ups, no sort); anything that changes the frame
+    # must still change it: transfer function (not part of the key: applied per frame), camera,
+    # screen-space error, clip planes, per-ray LOD
+    from libre_amd import vrc
+
+    def fresh(setup):
+        with drv.App("hash://#64,64,64,16", 96, 80, synchronous=True, sse=1.0) as a:
+            setup(a)
+            return a.render_frame()[0]
+
+    with drv.App("hash://#64,64,64,16", 96, 80, synchronous=True, sse=1.0) as app:
+        app.set_colormap(orc.linear_ramp_tf(0.3))
+        first, st = app.render_frame()
+        for _ in range(3):
+            again, st2 = app.render_frame()
+            assert (again == first).all() and st2.n_available == st.n_available
+        app.set_colormap(orc.linear_ramp_tf(1.0))
+        got, _ = app.render_frame()
+        assert np.abs(got - first).max() > 0.05
+        assert (got == fresh(lambda a: a.set_colormap(orc.linear_ramp_tf(1.0)))).all()
+        app.set_camera(spin=(0.4, 0.2))
+        got, _ = app.render_frame()
+        assert (got == fresh(lambda a: (a.set_colormap(orc.linear_ramp_tf(1.0)), a.set_camera(spin=(0.4, 0.2))))).all()
+        app.set_clip_planes([[0.0, 0.0, 1.0, 0.2]])
+        got, _ = app.render_frame()
+        assert (got == fresh(lambda a: (a.set_colormap(orc.linear_ramp_tf(1.0)), a.set_camera(spin=(0.4, 0.2)),
+                                        a.set_clip_planes([[0.0, 0.0, 1.0, 0.2]])))).all()
+        app.set_clip_planes([])
+        app.set_ray_lod(True)
+        lod, st3 = app.render_frame()
+        assert st3.ray_lod == 1
+        lod2, st4 = app.render_frame()  # kept path keeps the mode
+        assert st4.ray_lod == 1 and (lod2 == lod).all()
+        app.set_ray_lod(False)
+        back, st5 = app.render_frame()
+        assert st5.ray_lod == 0
+        assert (back == fresh(lambda a: (a.set_colormap(orc.linear_ramp_tf(1.0)), a.set_camera(spin=(0.4, 0.2))))).all()
