@@ -97,6 +97,20 @@ public:
         return it == _cacheMap.end() ? ObjectPtr() : it->second->obj;
     }
 
+    /** get() for a list of ids under ONE read lock (a frame asks for hundreds of bricks): out[k]
+     *  belongs to ids[k], empty where the object is not in the cache */
+    template < class IdRange > void getMany( const IdRange& ids, std::vector< ObjectPtr >& out ) const
+    {
+        out.clear();
+        out.reserve( ids.size() );
+        std::shared_lock< std::shared_timed_mutex > lock( _mutex );
+        for( const auto& id : ids )
+        {
+            const auto it = _cacheMap.find( CacheId( id ) );
+            out.push_back( it == _cacheMap.end() ? ObjectPtr() : it->second->obj );
+        }
+    }
+
     /** Cache.ipp:146-195: create-if-absent; constructor runs outside the map lock, under the
      *  entry's own lock, so concurrent loads of the same id construct once and of different
      *  ids run in parallel; a CacheLoadException yields an empty pointer (Cache.ipp:98-115). */

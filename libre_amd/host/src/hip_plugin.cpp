@@ -347,18 +347,20 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
         sameList = _sortedFor[i] == renderData[i].get() && _sortedForIds[i] == obj.getId() &&
                    _sortedForTex[i] == obj.getTexPosition();
     }
-    std::vector< std::pair< float, ConstCacheObjectPtr > > keyed;
+    /* (distance, index into renderData): sorting indices moves no reference counts */
+    std::vector< std::pair< float, uint32_t > > keyed;
     if( !sameList )
     {
     keyed.reserve( renderData.size() );
-    for( const auto& obj : renderData )
+    for( uint32_t i = 0; i < renderData.size(); ++i )
     {
-        const Boxf& box = static_cast< const HipTextureObject& >( *obj ).getWorldBox();
-        keyed.push_back( { ( frustum.getMVMatrix() * box.getCenter() ).length(), obj } );
+        const Boxf& box = static_cast< const HipTextureObject& >( *renderData[i] ).getWorldBox();
+        keyed.push_back( { ( frustum.getMVMatrix() * box.getCenter() ).length(), i } );
     }
     std::stable_sort( keyed.begin(), keyed.end(),
-                      []( const std::pair< float, ConstCacheObjectPtr >& a,
-                          const std::pair< float, ConstCacheObjectPtr >& b ) { return a.first < b.first; } );
+                      []( const std::pair< float, uint32_t >& a, const std::pair< float, uint32_t >& b ) {
+                          return a.first < b.first;
+                      } );
     }
 
     const VolumeInformation& volInfo = renderInputs.dataSource.getVolumeInfo();
@@ -372,8 +374,7 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
     pool = nullptr;
     for( const auto& kv : keyed )
     {
-        const ConstHipTextureObjectPtr hipObject =
-            std::static_pointer_cast< const HipTextureObject >( kv.second );
+        const HipTextureObject* hipObject = static_cast< const HipTextureObject* >( renderData[kv.second].get() );
         const Boxf& aabb = hipObject->getWorldBox();
         vrc_node_data nd;
         const Vector3f tp = hipObject->getTexPosition(), ts = hipObject->getTexSize(),
@@ -386,7 +387,7 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
             nd.aabbSize[i] = sz[i];
         }
         nodeDatas.push_back( nd );
-        _sortedIds.push_back( kv.second->getId() );
+        _sortedIds.push_back( hipObject->getId() );
         if( !pool )
             pool = hipObject->getTexturePool()._getHipTexturePool();
     }
@@ -645,13 +646,21 @@ struct HipRaycastPipeline::Impl
     {
         ConstCacheObjects cacheObjects;
         NodeIds notAvailable;
+        std::vector< CacheId > ids;
+        ids.reserve( nodeIds.size() );
         for( const NodeId& nodeId : nodeIds )
+            ids.push_back( nodeId.getId() );
+        std::vector< HipTextureCache::ObjectPtr > resident;
+        _hipCache->getMany( ids, resident ); /* one read lock for the frame's texture-cache hits */
+        cacheObjects.reserve( nodeIds.size() );
+        for( size_t k = 0; k < nodeIds.size(); ++k )
         {
+            const NodeId& nodeId = nodeIds[k];
             /* texture-cache hit, or the brick is in the CPU cache and only needs its upload
              * (CudaRenderUploadFilter.cpp:70-84 asks cache.load() for both and lets the
              * constructor throw when the data is missing; a C++ throw costs ~150 us in a
              * process with hundreds of loaded DSOs, so the miss is tested for instead) */
-            ConstCacheObjectPtr obj = _hipCache->get( nodeId.getId() );
+            ConstCacheObjectPtr obj = std::move( resident[k] );
             if( !obj && _dataCache->get( nodeId.getId() ) )
                 obj = _hipCache->load( nodeId.getId(), *_dataCache, in.dataSource, *_texturePool );
             if( obj )
