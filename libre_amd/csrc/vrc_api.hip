@@ -53,6 +53,7 @@ struct vrc_pool
     uint32_t atlasDim[3] = { 0, 0, 0 };
     size_t slotBytes = 0, atlasBytes = 0;
     void* dAtlas = nullptr;
+    bool bigAtlas = false; /* more than 2^32 voxels */
 
     std::mutex mutex; /* free list + staging ring index + upload event + render fences */
     /* slot position + "was in use before" flag: a released slot may still be read by a march
@@ -387,11 +388,9 @@ int vrc_pool_create( vrc_ctx* c, size_t bytesPerVoxel, int isSigned, int isFloat
     for( int a = 0; a < 3; ++a )
         p->atlasDim[a] = p->slots[a] * p->slotDim[a];
     p->atlasBytes = (size_t)p->atlasDim[0] * p->atlasDim[1] * p->atlasDim[2] * p->elemBytes;
-    if( p->atlasBytes / p->elemBytes >= 0xFFFFFFFFull )
-    {
-        delete p;
-        return fail( VRC_EINVAL, "vrc_pool_create: atlas exceeds 2^32 voxels" );
-    }
+    /* more than 2^32 voxels: slot bases become 64-bit (BIG kernel instances; the LDS-staged and the
+     * per-ray LOD kernels, whose slot bases are 32-bit, are not offered for such a pool) */
+    p->bigAtlas = p->atlasBytes / p->elemBytes >= 0xFFFFFFFFull;
 
     /* cuda/TexturePool.cu:137-144: i,j,k descending, k innermost; slots are popped from the back */
     for( int i = (int)p->slots[0] - 1; i >= 0; --i )
@@ -529,7 +528,7 @@ static int pool_upload( vrc_pool* p, const void* src, bool srcIsDevice, const ui
                 lay.slots[a] = p->slots[a];
                 lay.slotDim[a] = p->slotDim[a];
             }
-            const uint32_t base = vrc_slot_base( lay, o[0] / p->slotDim[0], o[1] / p->slotDim[1],
+            const uint64_t base = vrc_slot_base( lay, o[0] / p->slotDim[0], o[1] / p->slotDim[1],
                                                  o[2] / p->slotDim[2] );
             uint8_t* const slotPtr = (uint8_t*)p->dAtlas + (size_t)base * p->elemBytes;
             e = vrc_launch_repack_brick( devSrc, slotPtr, p->elemBytes, size, p->slotDim, p->uploadStream );
@@ -672,7 +671,7 @@ int vrc_pool_histogram( vrc_pool* p, const float slot[3], const uint32_t origin[
         lay.slots[a] = p->slots[a];
         lay.slotDim[a] = p->slotDim[a];
     }
-    const uint32_t base = vrc_slot_base( lay, o[0] / p->slotDim[0], o[1] / p->slotDim[1], o[2] / p->slotDim[2] );
+    const uint64_t base = vrc_slot_base( lay, o[0] / p->slotDim[0], o[1] / p->slotDim[1], o[2] / p->slotDim[2] );
     unsigned long long* dBins = nullptr;
     VRC_HIP_CHECK( hipMalloc( &dBins, binCount * sizeof( unsigned long long ) ) );
     /* on the upload stream: ordered after the brick's own upload */
@@ -997,6 +996,8 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
             return fail( VRC_EINVAL, "vrc_render: per-ray LOD is defined for the cudaRaycaster variant only" );
         if( c->optKernel != VRC_KERNEL_AUTO )
             return fail( VRC_EINVAL, "vrc_render: per-ray LOD has its own kernel; leave VRC_OPT_KERNEL at AUTO" );
+        if( pool->bigAtlas )
+            return fail( VRC_EHIERARCHY, "vrc_render: per-ray LOD is not available in atlases of more than 2^32 voxels" );
     }
     bool useDda = c->cachedGridOk;
     if( c->optKernel == VRC_KERNEL_REFERENCE_ORDER )
@@ -1005,7 +1006,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         return fail( VRC_EINVAL, "vrc_render: node set is not grid-aligned; GRID_DDA unavailable" );
     /* LDS-staged kernel: brick-grid DDA + unclamped sampler (overlap >= 1).  AUTO takes it for
      * the trilinear filter (eight taps per sample), the gather kernel for point sampling. */
-    const bool ldsEligible = c->cachedGridOk && !c->cachedClamp && pool->elemBytes == 1;
+    const bool ldsEligible = c->cachedGridOk && !c->cachedClamp && pool->elemBytes == 1 && !pool->bigAtlas;
     if( c->optKernel == VRC_KERNEL_LDS && !ldsEligible )
         return fail( VRC_EINVAL, "vrc_render: the LDS kernel needs a grid-aligned node set of 8-bit bricks with overlap >= 1" );
     const bool useLds = !c->rayLod && ( c->optKernel == VRC_KERNEL_LDS ||
@@ -1081,6 +1082,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     a.fixedStepping = c->optStepping != 0;
     a.linear = linear;
     a.elemBytes = pool->elemBytes;
+    a.bigAtlas = pool->bigAtlas;
     a.classifier = vrc_make_classifier( lp );
 
     /* order the march after every brick upload issued so far (fixes quirk Q9) */

@@ -65,9 +65,10 @@ struct vrc_dev_node
     float aabbSize[3];
     float voxPerWorld[3]; /* texSize*atlasDim/aabbSize: atlas voxels per world unit */
     float localOrigin[3]; /* atlas-voxel coordinate of aabbMin, relative to the slot origin */
-    uint32_t slotBase;    /* element offset of the brick's slot in the atlas buffer */
+    uint32_t slotBase;    /* element offset of the brick's slot in the atlas buffer, low 32 bits */
     uint32_t level;       /* per-ray LOD: 0 = the finest voxel size in the node list, +1 per doubling */
-    uint32_t pad[2];
+    uint32_t slotBaseHi;  /* high 32 bits: non-zero only in atlases of more than 2^32 voxels (BIG kernels) */
+    uint32_t pad;
 };
 
 /* Frame constants, derived on the host exactly as Renderer.cu:159-170 does per thread. */
@@ -138,15 +139,16 @@ VRC_HD uint32_t vrc_slot_local_index( uint32_t x, uint32_t y, uint32_t z, uint32
     return blk * VRC_MB_VOXELS + inner;
 }
 
-/* element offset of slot (i,j,k) */
-VRC_HD uint32_t vrc_slot_base( const vrc_layout& l, uint32_t i, uint32_t j, uint32_t k )
+/* element offset of slot (i,j,k): 64 bits, an atlas may hold more than 2^32 voxels (it is sized
+ * for the GPU's memory, not for a 32-bit index; the reference truncates, quirk Q12) */
+VRC_HD uint64_t vrc_slot_base( const vrc_layout& l, uint32_t i, uint32_t j, uint32_t k )
 {
-    const uint32_t slotVoxels = l.slotDim[0] * l.slotDim[1] * l.slotDim[2];
-    return ( ( k * l.slots[1] + j ) * l.slots[0] + i ) * slotVoxels;
+    const uint64_t slotVoxels = (uint64_t)l.slotDim[0] * l.slotDim[1] * l.slotDim[2];
+    return ( ( (uint64_t)k * l.slots[1] + j ) * l.slots[0] + i ) * slotVoxels;
 }
 
 /* physical element index of logical atlas voxel (x,y,z) */
-VRC_HD uint32_t vrc_atlas_index( const vrc_layout& l, uint32_t x, uint32_t y, uint32_t z )
+VRC_HD uint64_t vrc_atlas_index( const vrc_layout& l, uint32_t x, uint32_t y, uint32_t z )
 {
     const uint32_t i = x / l.slotDim[0], j = y / l.slotDim[1], k = z / l.slotDim[2];
     return vrc_slot_base( l, i, j, k ) +
@@ -928,12 +930,23 @@ VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n,
 #define VRC_MODE_TRILINEAR 1
 #define VRC_MODE_POINT 2
 
-template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP >
+/* BIG: the atlas holds more than 2^32 voxels.  Offsets inside a slot stay 32-bit; the slot's
+ * 64-bit base moves into the lane's atlas pointer (one 64-bit add per gather instead of a 32-bit
+ * one), so the default kernels keep their scalar base + 32-bit offset addressing. */
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP, bool BIG = false >
 VRC_HD bool vrc_march_brick( const vrc_frame& f, const vrc_dev_node& n, const vrc_segment& s,
                              const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
                              const vrc_classifier& cls, vrc_f4& color, uint32_t& nSamples,
                              float levelStep = 0.0f )
 {
+    if( BIG )
+    {
+        vrc_dev_node local = n;
+        local.slotBase = 0u;
+        const ATLAS_T* slot = atlas + ( ( (uint64_t)n.slotBaseHi << 32 ) | n.slotBase );
+        return vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, false >( f, local, s, slot, lut, cls,
+                                                                                color, nSamples, levelStep );
+    }
     if( MODE != VRC_MODE_TABLE )
         return vrc_march_segment_linear< CLAMP, COUNT, MODE == VRC_MODE_TRILINEAR, ATLAS_T >(
             f, n, s, atlas, lut, cls, color, nSamples, levelStep );
@@ -941,7 +954,7 @@ VRC_HD bool vrc_march_brick( const vrc_frame& f, const vrc_dev_node& n, const vr
                                                                    levelStep );
 }
 
-template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP >
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP, bool BIG = false >
 VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
                                        const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
                                        const vrc_classifier& cls,
@@ -971,7 +984,7 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
                 break;
             continue;
         }
-        if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP >( f, n, s, atlas, lut, cls, color,
+        if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >( f, n, s, atlas, lut, cls, color,
                                                                      nSamples ) )
             break;
     }
@@ -984,7 +997,7 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
  * For a regular single-LOD grid the along-ray order equals the reference's host order for
  * every pair of bricks that share a ray ("brick order").
  * ---------------------------------------------------------------------------------------- */
-template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP >
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP, bool BIG = false >
 VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
                                 const int32_t* __restrict__ gridTable,
                                 const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
@@ -1055,7 +1068,7 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
                 bool stop;
                 if( vrc_brick_segment( f, r, n, f.stepSize, &s, &stop ) )
                 {
-                    if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP >( f, n, s, atlas, lut,
+                    if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >( f, n, s, atlas, lut,
                                                                                  cls, color, nSamples ) )
                         break;
                 }
@@ -1139,7 +1152,7 @@ VRC_HD vrc_segment vrc_run_segment( const vrc_ray& r, float tA, float tB, float 
     return s;
 }
 
-template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP >
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP, bool BIG = false >
 VRC_HD void vrc_pixel_ray_lod( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
                                const int32_t* __restrict__ gridTable,
                                const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
@@ -1251,7 +1264,7 @@ VRC_HD void vrc_pixel_ray_lod( const vrc_frame& f, const vrc_dev_node* __restric
                 vrc_classifier lc = cls;
                 lc.alphaCorrection = cls.alphaCorrection * scale;
                 const vrc_f4* ll = MODE == VRC_MODE_TABLE ? lut + n.level * VRC_LUT_ENTRIES : lut;
-                if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP >( f, n, s, atlas, ll, lc, color,
+                if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >( f, n, s, atlas, ll, lc, color,
                                                                              nSamples, levelStep ) )
                     break;
             }

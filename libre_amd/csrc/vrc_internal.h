@@ -55,6 +55,7 @@ struct vrc_raycast_args
     uint32_t elemBytes; /* voxel size: 1 (u8) or 2 (u16; classified per sample).  lut holds the padded
                          * transfer function whenever samples are classified one by one */
     vrc_classifier classifier;
+    bool bigAtlas; /* more than 2^32 voxels: node slot bases are 64-bit (BIG kernel instances) */
 };
 
 /* heaviest-first tile schedule for the frame (order: one uint32 per 8x8 tile; scratch:

@@ -398,7 +398,8 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t*
  * times over (4 waves per SIMD); 16 (2 waves per SIMD) halves the dependent round trips of a ray
  * and wins when a launch is no more than about one wave per SIMD slot and the longest ray's
  * latency sets the time -- the per-rank share of a sort-first frame from 4 ranks up. */
-template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP >
+template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP,
+           bool BIG = false >
 __global__ __launch_bounds__( VRC_WG_THREADS, GROUP > 8 ? 2 : VRC_MIN_WAVES ) void vrc_k_raycast(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ gridTable, const ATLAS_T* __restrict__ atlas,
@@ -463,10 +464,10 @@ __global__ __launch_bounds__( VRC_WG_THREADS, GROUP > 8 ? 2 : VRC_MIN_WAVES ) vo
     if( px < f.width && py < f.height )
     {
         if( DDA )
-            vrc_pixel_grid_dda< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP >(
+            vrc_pixel_grid_dda< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >(
                 f, nodes, gridTable, atlas, lut, cls, pixelBuffer, px, py, nSamples );
         else
-            vrc_pixel_reference_order< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP >(
+            vrc_pixel_reference_order< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >(
                 f, nodes, atlas, lut, cls, pixelBuffer, px, py, nSamples );
     }
     if( COUNT )
@@ -481,7 +482,8 @@ __global__ __launch_bounds__( VRC_WG_THREADS, GROUP > 8 ? 2 : VRC_MIN_WAVES ) vo
     }
 }
 
-template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP >
+template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP,
+           bool BIG = false >
 static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream )
 {
     const uint32_t tilesX = ( a.frame.width + VRC_TILE_W - 1 ) / VRC_TILE_W;
@@ -489,7 +491,7 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
     const uint32_t nTiles = tilesX * tilesY;
     if( nTiles == 0 )
         return hipSuccess;
-    hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP > ),
+    hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG > ),
                         dim3( ( nTiles + VRC_WAVES_PER_WG - 1u ) / VRC_WAVES_PER_WG ),
                         dim3( VRC_WG_THREADS ), 0, stream, a.frame, a.nodes, a.gridTable,
                         (const ATLAS_T*)a.atlas, a.lut, a.classifier, a.pixelBuffer,
@@ -515,9 +517,37 @@ static hipError_t launch_classify( const vrc_raycast_args& a, bool count, hipStr
     }
 }
 
+/* atlases of more than 2^32 voxels: 64-bit slot bases (BIG), float stepping, groups of 8 */
+template < int MODE, typename ATLAS_T >
+static hipError_t launch_big( const vrc_raycast_args& a, bool count, hipStream_t stream )
+{
+    const int key = ( a.gridDda ? 4 : 0 ) | ( a.clamp ? 2 : 0 ) | ( count ? 1 : 0 );
+    switch( key )
+    {
+    case 0: return launch_variant< false, false, false, false, MODE, ATLAS_T, VRC_GROUP, true >( a, stream );
+    case 1: return launch_variant< false, false, true, false, MODE, ATLAS_T, VRC_GROUP, true >( a, stream );
+    case 2: return launch_variant< false, true, false, false, MODE, ATLAS_T, VRC_GROUP, true >( a, stream );
+    case 3: return launch_variant< false, true, true, false, MODE, ATLAS_T, VRC_GROUP, true >( a, stream );
+    case 4: return launch_variant< true, false, false, false, MODE, ATLAS_T, VRC_GROUP, true >( a, stream );
+    case 5: return launch_variant< true, false, true, false, MODE, ATLAS_T, VRC_GROUP, true >( a, stream );
+    case 6: return launch_variant< true, true, false, false, MODE, ATLAS_T, VRC_GROUP, true >( a, stream );
+    default: return launch_variant< true, true, true, false, MODE, ATLAS_T, VRC_GROUP, true >( a, stream );
+    }
+}
+
 hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
 {
     const bool count = a.sampleCounter != nullptr;
+    if( a.bigAtlas )
+    {
+        if( a.elemBytes == 2 )
+            return a.linear ? launch_big< VRC_MODE_TRILINEAR, uint16_t >( a, count, stream )
+                            : launch_big< VRC_MODE_POINT, uint16_t >( a, count, stream );
+        if( a.elemBytes != 1 )
+            return hipErrorInvalidValue;
+        return a.linear ? launch_big< VRC_MODE_TRILINEAR, uint8_t >( a, count, stream )
+                        : launch_big< VRC_MODE_TABLE, uint8_t >( a, count, stream );
+    }
     if( a.elemBytes == 2 )
         return a.linear ? launch_classify< VRC_MODE_TRILINEAR, uint16_t >( a, count, stream )
                         : launch_classify< VRC_MODE_POINT, uint16_t >( a, count, stream );

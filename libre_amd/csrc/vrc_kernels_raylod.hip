@@ -109,7 +109,7 @@ static hipError_t launch_raylod_classify( const vrc_raycast_args& a, bool count,
 hipError_t vrc_launch_raycast_raylod( const vrc_raycast_args& a, hipStream_t stream )
 {
     if( a.frame.lodLevels < 1 || a.frame.lodLevels > VRC_MAX_LOD_LEVELS || !a.gridTable ||
-        a.frame.variant != VRC_VARIANT_CUDA )
+        a.frame.variant != VRC_VARIANT_CUDA || a.bigAtlas /* 32-bit slot bases only */ )
         return hipErrorInvalidValue;
     const bool count = a.sampleCounter != nullptr;
     if( a.elemBytes == 2 )

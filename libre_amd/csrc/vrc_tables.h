@@ -83,9 +83,11 @@ inline void vrc_build_tables( const vrc_atlas_geom& p, const vrc_node_data* in, 
             lay.slots[a] = p.slots[a];
             lay.slotDim[a] = p.slotDim[a];
         }
-        d.slotBase = vrc_slot_base( lay, slotIdx[0], slotIdx[1], slotIdx[2] );
+        const uint64_t base = vrc_slot_base( lay, slotIdx[0], slotIdx[1], slotIdx[2] );
+        d.slotBase = (uint32_t)base;
+        d.slotBaseHi = (uint32_t)( base >> 32 );
         d.level = 0;
-        d.pad[0] = d.pad[1] = 0;
+        d.pad = 0;
     }
 
     /* brick grid: cells of the finest brick size covering the union of the node boxes */

@@ -647,3 +647,87 @@ def test_ray_lod_random_views(vrc, seed):
         got, n_got, _ = g.render(ray_lod=lod)
     _lod_parity(got, want, "seed %d %r lod %r" % (seed, kw, lod))
     assert abs(n_got - n_want) <= 3e-4 * n_want + 16
+
+
+def test_atlas_of_more_than_2_pow_32_voxels(vrc):
+    # the atlas is sized for the GPU's memory, not for a 32-bit index (the reference truncates, quirk Q12):
+    # a 6 GB pool (4080 x 4080 x 360 voxels); bricks land below and above the 4 Gi-voxel line
+    # (the free list hands out slots z-fastest), are read back bit-exactly and render the frame
+    # of the same scene in a small pool, bit for bit
+    s = scenes.get("hash64_spin")
+    with _gpu(s) as g:
+        want, n_want, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, stepping=0)
+        want_lin, _, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, filter_mode=vrc.FILTER_TRILINEAR)
+        want_ref, _, _ = g.render(kernel=vrc.KERNEL_REFERENCE_ORDER, stepping=0)
+    L = vrc.load_library()
+    ctx, pool = C.c_void_p(), C.c_void_p()
+    vrc.check(L, L.vrc_ctx_create(0, C.byref(ctx)))
+    try:
+        mb = [s.vi.maximumBlockSize[a] for a in range(3)]
+        vrc.check(L, L.vrc_pool_create(ctx, 1, 0, 0, 1, vrc.u32x3(*mb), 6 * 1000 ** 3, C.byref(pool)))
+        sb, ab, fs = C.c_size_t(), C.c_size_t(), C.c_uint32()
+        ad, sl = vrc.u32x3(), vrc.u32x3()
+        vrc.check(L, L.vrc_pool_info(pool, C.byref(sb), ad, C.byref(ab), sl, C.byref(fs)))
+        atlas_dim = list(ad)
+        assert atlas_dim[0] * atlas_dim[1] * atlas_dim[2] > 2 ** 32
+        slot_dim = [atlas_dim[a] // sl[a] for a in range(3)]
+        slots, high = {}, 0
+        for nid in s.ids:
+            brick = s.bricks[nid]
+            slot = vrc.f32x3()
+            vrc.check(L, L.vrc_pool_copy_to_slot(pool, brick.ctypes.data,
+                                                 vrc.u32x3(brick.shape[2], brick.shape[1], brick.shape[0]), slot))
+            slots[nid] = (slot[0], slot[1], slot[2])
+            idx = [int(round(slot[a] * sl[a])) for a in range(3)]
+            base = ((idx[2] * sl[1] + idx[1]) * sl[0] + idx[0]) * slot_dim[0] * slot_dim[1] * slot_dim[2]
+            high += base >= 2 ** 32
+            # read the brick back through the logical atlas coordinates
+            origin = [idx[a] * slot_dim[a] for a in range(3)]
+            out = np.zeros_like(brick)
+            vrc.check(L, L.vrc_pool_read_region(pool, vrc.u32x3(*origin),
+                                                vrc.u32x3(brick.shape[2], brick.shape[1], brick.shape[0]),
+                                                out.ctypes.data))
+            assert (out == brick).all()
+        assert 0 < high < len(s.ids)
+        # node list in the scene's (sorted) order, texture coordinates for THIS atlas
+        nodes = (vrc.NodeData * s.n_nodes)()
+        for k, nid in enumerate(s.sorted_ids):
+            tp, ts = orc.f32x3(), orc.f32x3()
+            orc.lib().orc_texture_object(C.byref(s.vi), C.byref(s.lod[nid]), orc.f32x3(*slots[nid]),
+                                         orc.u32x3(*atlas_dim), tp, ts)
+            for a in range(3):
+                nodes[k].textureMin[a] = tp[a]
+                nodes[k].textureSize[a] = ts[a]
+                nodes[k].aabbMin[a] = s.nodes[k].aabbMin[a]
+                nodes[k].aabbSize[a] = s.nodes[k].aabbSize[a]
+        view = C.cast(C.byref(s.view), C.POINTER(vrc.ViewData))
+        render = C.cast(C.byref(s.render), C.POINTER(vrc.RenderData))
+        vrc.check(L, L.vrc_update(ctx, s.tf.ctypes.data, None, 0))
+        vrc.check(L, L.vrc_set_option(ctx, vrc.OPT_COUNT_SAMPLES, 1))
+
+        def frame(kernel, flt):
+            vrc.check(L, L.vrc_set_option(ctx, vrc.OPT_KERNEL, kernel))
+            vrc.check(L, L.vrc_set_option(ctx, vrc.OPT_FILTER, flt))
+            vrc.check(L, L.vrc_pre_render(ctx, view))
+            vrc.check(L, L.vrc_render(ctx, view, nodes, s.n_nodes, render, pool))
+            fb = np.zeros((s.H, s.W, 4), dtype=np.float32)
+            vrc.check(L, L.vrc_post_render(ctx, fb.ctypes.data))
+            st = vrc.Stats()
+            vrc.check(L, L.vrc_get_stats(ctx, C.byref(st)))
+            return fb, st
+
+        got, st = frame(vrc.KERNEL_AUTO, vrc.FILTER_NEAREST)
+        assert st.kernel_variant == vrc.KERNEL_GRID_DDA and st.samples == n_want
+        assert (got == want).all()
+        got, st = frame(vrc.KERNEL_REFERENCE_ORDER, vrc.FILTER_NEAREST)
+        assert (got == want_ref).all()
+        got, st = frame(vrc.KERNEL_AUTO, vrc.FILTER_TRILINEAR)  # LDS kernel not offered: gather form
+        assert st.kernel_variant == vrc.KERNEL_GRID_DDA
+        assert np.abs(got - want_lin).max() <= 1e-6
+        assert L.vrc_set_option(ctx, vrc.OPT_KERNEL, vrc.KERNEL_LDS) == 0
+        vrc.check(L, L.vrc_pre_render(ctx, view))
+        assert L.vrc_render(ctx, view, nodes, s.n_nodes, render, pool) != 0  # refused, loudly
+    finally:
+        if pool:
+            L.vrc_pool_destroy(pool)
+        L.vrc_ctx_destroy(ctx)
