@@ -15,6 +15,10 @@ from libre_amd import driver, vrc  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+# texture cache that holds the finest level (bricks with overlap, 2 bytes per voxel) and a CPU cache of the same size:
+# 2048^3 -> 24 GiB, an atlas of more than 2^32 voxels (64-bit slot bases)
+GPU_MB = int(sys.argv[3]) if len(sys.argv) > 3 else max(6144, int(1.2 * 2 * (N / B) ** 3 * (B + 8) ** 3 / 2 ** 20))
+CPU_MB = max(8192, GPU_MB + 2048)
 path = "/tmp/vol_u16_%d.raw" % N
 if not os.path.exists(path) or os.path.getsize(path) != 2 * N ** 3:
     t0 = time.perf_counter()
@@ -39,7 +43,7 @@ probe = driver.App(uri, 1024, 1024)
 depth = probe.volume_info()["depth"]
 probe.close()
 with driver.App(uri, 1024, 1024, synchronous=True, min_lod=depth - 1, max_lod=depth - 1,
-                gpu_cache_mb=6144, cpu_cache_mb=8192) as app:
+                gpu_cache_mb=GPU_MB, cpu_cache_mb=CPU_MB) as app:
     app.set_colormap(tf)
     t0 = time.perf_counter()
     _, st = app.render_frame(readback=False)
@@ -65,7 +69,7 @@ with driver.App(uri, 1024, 1024, synchronous=True, min_lod=depth - 1, max_lod=de
         print("uint16 %s kernel: %.3f ms per frame = %.1f Gsamples/s" % (name, ms, n / ms / 1e6), flush=True)
 
 # 2. asynchronous, LOD cut by screen-space error, camera orbiting: upload overlapped with the march
-with driver.App(uri, 1024, 1024, synchronous=False, sse=4.0, gpu_cache_mb=6144, cpu_cache_mb=8192) as app:
+with driver.App(uri, 1024, 1024, synchronous=False, sse=4.0, gpu_cache_mb=GPU_MB, cpu_cache_mb=CPU_MB) as app:
     app.set_colormap(tf)
     t0 = time.perf_counter()
     frames = 0
