@@ -4,6 +4,7 @@
  *   hash:// build-defined seeded-noise volume ("Volume N" of SURVEY 8d), bricked like mem://
  * Registered at load time through static PluginRegisterer objects, as the reference does
  * (MemoryDataSource.cpp:46, RawDataSource.cpp:50). */
+#include <thread>
 #include <algorithm>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -397,14 +398,39 @@ private:
             for( int a = 0; a < 3; ++a )
                 lv.dim[a] = ( pd[a] + 1 ) / 2; /* voxels 0, 2, 4, ... of the level below */
             lv.data.reset( new uint8_t[size_t( lv.dim[0] ) * lv.dim[1] * lv.dim[2] * bpv] );
-            for( int64_t z = 0; z < lv.dim[2]; ++z )
-                for( int64_t y = 0; y < lv.dim[1]; ++y )
-                {
-                    const uint8_t* row = prev + size_t( ( ( 2 * z ) * pd[1] + 2 * y ) * pd[0] ) * bpv;
-                    uint8_t* out = lv.data.get() + size_t( ( z * lv.dim[1] + y ) * lv.dim[0] ) * bpv;
-                    for( int64_t x = 0; x < lv.dim[0]; ++x )
-                        std::memcpy( out + x * bpv, row + size_t( 2 * x ) * bpv, bpv );
-                }
+            /* z-slabs on all host cores: level 1 of a 2048^3 uint16 file is 1e9 voxels picked out of
+             * 17 GB (3.2 s on one core) */
+            uint8_t* const dst = lv.data.get();
+            const int64_t d0 = lv.dim[0], d1 = lv.dim[1], d2 = lv.dim[2], p0 = pd[0], p1 = pd[1];
+            auto slab = [=]( int64_t z0, int64_t z1 ) {
+                for( int64_t z = z0; z < z1; ++z )
+                    for( int64_t y = 0; y < d1; ++y )
+                    {
+                        const uint8_t* row = prev + size_t( ( ( 2 * z ) * p1 + 2 * y ) * p0 ) * bpv;
+                        uint8_t* out = dst + size_t( ( z * d1 + y ) * d0 ) * bpv;
+                        if( bpv == 1 )
+                            for( int64_t x = 0; x < d0; ++x )
+                                out[x] = row[2 * x];
+                        else if( bpv == 2 )
+                            for( int64_t x = 0; x < d0; ++x )
+                                std::memcpy( out + 2 * x, row + 4 * x, 2 );
+                        else
+                            for( int64_t x = 0; x < d0; ++x )
+                                std::memcpy( out + x * bpv, row + size_t( 2 * x ) * bpv, bpv );
+                    }
+            };
+            const int64_t nThreads = std::max< int64_t >(
+                1, std::min< int64_t >( { int64_t( std::thread::hardware_concurrency() ), int64_t( 16 ), d2 / 8 } ) );
+            if( nThreads == 1 )
+                slab( 0, d2 );
+            else
+            {
+                std::vector< std::thread > workers;
+                for( int64_t t = 0; t < nThreads; ++t )
+                    workers.emplace_back( slab, d2 * t / nThreads, d2 * ( t + 1 ) / nThreads );
+                for( std::thread& w : workers )
+                    w.join();
+            }
         }
         return _pyramid[k];
     }
