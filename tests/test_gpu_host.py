@@ -564,3 +564,29 @@ def test_repeated_frames_take_the_kept_brick_list_and_stay_correct(drv):
         back, st5 = app.render_frame()
         assert st5.ray_lod == 0
         assert (back == fresh(lambda a: (a.set_colormap(orc.linear_ramp_tf(1.0)), a.set_camera(spin=(0.4, 0.2))))).all()
+
+
+def test_per_ray_lod_row_bands_are_rows_of_the_full_frame(drv):
+    # BASELINE C5 is sort-first over 8 GPUs: a rank's bands rendered with per-ray LOD in one launch
+    # equal those rows of the full per-ray-LOD frame bit for bit (the level choice depends on the
+    # ray alone), also on the ragged UVF tree
+    uvf = "uvf://" + os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mouse_reduced.uvf")
+    for uri, sse in (("hash://#128,128,128,16", 1.5), (uvf, 1.2)):
+        W, H = 72, 64
+        kw = dict(synchronous=True, sse=sse, gpu_cache_mb=64)
+        with drv.App(uri, W, H, **kw) as full_app:
+            full_app.set_camera(spin=(0.5, 0.35))
+            full_app.set_colormap(orc.linear_ramp_tf(0.3))
+            full_app.set_ray_lod(True)
+            full, st = full_app.render_frame()
+            assert st.ray_lod == 1 and full[..., 3].max() > 0.1
+        bands = [(8, 8), (40, 16), (24, 8)]
+        with drv.App(uri, W, H, **kw) as app:
+            app.set_bands(bands)
+            app.set_camera(spin=(0.5, 0.35))
+            app.set_colormap(orc.linear_ramp_tf(0.3))
+            app.set_ray_lod(True)
+            fb, st = app.render_frame()
+            assert st.ray_lod == 1 and fb.shape == (32, W, 4)
+            want = np.concatenate([full[y0:y0 + h] for (y0, h) in bands], axis=0)
+            assert (fb == want).all()
