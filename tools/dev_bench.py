@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--kernels", type=int, nargs="*", default=None,
                     help="VRC_KERNEL_* codes to time (default: 2 = grid DDA gather kernel)")
     ap.add_argument("--filters", type=int, nargs="*", default=[0], help="0 nearest, 1 trilinear")
+    ap.add_argument("--dtype", default="u8", help="u8 | u16")
     ap.add_argument("--tile-offset", type=int, default=-1,
                     help="render the sub-frame that starts at this pixel offset (x and y) and is 8 pixels smaller: "
                          "moves the 8x8 pixel tiles against the 8^3 micro-blocks of the atlas")
@@ -44,7 +45,7 @@ def main():
     if a.levels is not None:
         ids = orc.all_level_ids(orc.mem_volume_info(a.voxels, a.voxels, a.voxels, a.block), a.levels)
     s = orc.build_scene(voxels=(a.voxels,) * 3, block=a.block, viewport=(a.viewport,) * 2,
-                        volume=a.volume, spin=tuple(a.spin), alpha=a.alpha, ids=ids,
+                        volume=a.volume, spin=tuple(a.spin), alpha=a.alpha, ids=ids, dtype=a.dtype,
                         tile=None if a.tile_offset < 0 else (a.tile_offset, a.tile_offset, a.viewport - 8,
                                                              a.viewport - 8, a.viewport, a.viewport))
     print("scene built in %.1fs: %d nodes spr %d atlas %s" % (time.time() - t0, s.n_nodes,
