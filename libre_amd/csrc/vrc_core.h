@@ -1117,7 +1117,8 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
  * the first level that has one there in the order k, k+1, ..., K-1, k-1, ..., 0; the run ends
  * where the ray leaves that brick's box (the finest level's cell where there is no brick) and
  * the level is chosen anew.  A run is marched like a reference brick segment
- * (Renderer.cu:195-223: sampling restarts at the run's entry point) with step stepSize * 2^j and
+ * (Renderer.cu:195-223: sampling restarts at the run's entry point, here eps inside the brick so
+ * that the first sample does not sit on a voxel face) with step stepSize * 2^j and
  * opacity exponent alphaCorrection * 2^j (classified table of level j: lut + j * 257; classifier
  * exponent scaled for the per-sample modes), so a level-j brick costs 2^-j of the samples and
  * the opacity of a homogeneous stretch does not depend on the level it is sampled at.
@@ -1260,7 +1261,7 @@ VRC_HD void vrc_pixel_ray_lod( const vrc_frame& f, const vrc_dev_node* __restric
             {
                 const float scale = (float)( 1u << n.level );
                 const float levelStep = f.stepSize * scale;
-                const vrc_segment s = vrc_run_segment( r, te, tB, levelStep );
+                const vrc_segment s = vrc_run_segment( r, tp, tB, levelStep ); /* first sample eps inside */
                 vrc_classifier lc = cls;
                 lc.alphaCorrection = cls.alphaCorrection * scale;
                 const vrc_f4* ll = MODE == VRC_MODE_TABLE ? lut + n.level * VRC_LUT_ENTRIES : lut;

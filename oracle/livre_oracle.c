@@ -912,8 +912,10 @@ static uint64_t raycast_pixel_gl( const job_t* j, uint32_t x, uint32_t y )
  *     first level that has one there in the order k, k+1, .., K-1, k-1, .., 0; the run ends where
  *     the ray leaves that brick's box (or the finest level's grid cell where there is no brick),
  *     and the level is chosen anew there.  eps = 1 % of the finest voxel;
- *   - a run is integrated like a reference brick segment (Renderer.cu:195-223) with
- *     stepSize * 2^level and opacity exponent alphaCorrection * 2^level.
+ *   - a run is integrated like a reference brick segment (Renderer.cu:195-223) over
+ *     [te + eps, exit] (the first sample lies eps inside the brick, not on its face, where the
+ *     voxel it reads would hang on the last bit of te) with stepSize * 2^level and opacity
+ *     exponent alphaCorrection * 2^level.
  * ---------------------------------------------------------------------------------------- */
 #define LOD_MAX_LEVELS 8
 typedef struct lod_grid
@@ -1204,7 +1206,7 @@ static uint64_t raycast_pixel_ray_lod( const job_t* j, uint32_t x, uint32_t y )
             tX = fminf( tX, ( ( d[2] > 0.0f ? bmax[2] : bmin[2] ) - o[2] ) * invD[2] );
             const float tB = fminf( fmaxf( tX, tp ), t1 ); /* always forward */
             if( node >= 0 &&
-                integrate_run( j, &j->nodes[node], g->level[node], origin, dir, te, tB, color, &nSamples ) )
+                integrate_run( j, &j->nodes[node], g->level[node], origin, dir, tp, tB, color, &nSamples ) )
                 break;
             te = tB;
         }

@@ -312,11 +312,13 @@ def _fuzz_parity(got, want, what):
     # small differences in many pixels, mean up to ~1.2e-4 seen, hence 4 x MEAN_ABS here.
     mx, mean, over = orc.compare(got, want)
     npix = got.shape[0] * got.shape[1]
-    assert mx <= 3 * scenes.MAX_ABS and mean <= 4 * scenes.MEAN_ABS and over * npix <= max(3.0, 5e-3 * npix), \
+    k = scenes.SOAK_SLACK
+    allowed = max(3.0, 5e-3 * npix) if k == 1.0 else max(12.0, 0.08 * npix)
+    assert mx <= 3 * k * scenes.MAX_ABS and mean <= 4 * k * scenes.MEAN_ABS and over * npix <= allowed, \
         "%s: max|d|=%.3g mean|d|=%.3g over=%.4f" % (what, mx, mean, over)
 
 
-@pytest.mark.parametrize("seed", range(64))
+@pytest.mark.parametrize("seed", range(64 * scenes.FUZZ_SCALE))
 def test_random_views_all_kernel_forms_match_the_oracle(seed):
     # random volumes, cameras (also inside the volume), clip planes, viewports and step sizes:
     # reference order, grid DDA, fixed-point stepping, trilinear, glRaycaster rules

@@ -344,7 +344,7 @@ def test_uvf_volume_through_the_plugin_matches_oracle(drv):
             scenes.assert_parity(lin, want_lin, "uvf lod %d trilinear" % lod)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * scenes.FUZZ_SCALE))
 def test_random_lod_cuts_through_the_plugin_match_the_oracle(drv, seed):
     # random camera (also close to / inside the volume), screen-space error and volume: the
     # plugin's visible set (mixed levels, holes where bricks are culled), its brick order and
@@ -378,13 +378,14 @@ def test_random_lod_cuts_through_the_plugin_match_the_oracle(drv, seed):
         # DESIGN.md section 2 add up to a mean of ~1e-4 (the reference-order kernel and the host
         # build of the same code show the same figure), still isolated pixels
         mx, mean, over = orc.compare(fb, want)
-        assert mx <= 3 * scenes.MAX_ABS and mean <= 4 * scenes.MEAN_ABS and over <= 1e-2, (
+        k = scenes.SOAK_SLACK
+        assert mx <= 3 * k * scenes.MAX_ABS and mean <= 4 * k * scenes.MEAN_ABS and over <= k * 1e-2, (
             "seed %d %s eye %r spin %r sse %g levels %r: max %.3g mean %.3g over %.4f" % (
                 seed, uri, eye, spin, sse, sorted({i & 0xF for i in ids}), mx, mean, over))
         assert abs(int(app.stats().samples) - n_want) <= 5e-4 * n_want + 16
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(8 * scenes.FUZZ_SCALE))
 def test_random_sort_first_layouts_reassemble_the_frame(drv, seed):
     # every rank of a random sort-first layout renders its bands in one launch; the assembled
     # frame must be the full frame bit for bit -- point sampled, trilinear (LDS kernel) and with
@@ -423,7 +424,12 @@ def test_random_sort_first_layouts_reassemble_the_frame(drv, seed):
             for (y0, h) in bands:
                 out[y0:y0 + h] = fb[off:off + h]
                 off += h
-    assert (out == full).all(), (seed, W, H, world, bpr, mode)
+    if mode == 1:
+        # the LDS-staged kernel takes a sample from the staged box or by gathers depending on the lanes that
+        # share its wave; the two code paths contract their multiply-adds differently: the last bit may differ
+        assert np.abs(out - full).max() <= 5e-7, (seed, W, H, world, bpr, mode)
+    else:
+        assert (out == full).all(), (seed, W, H, world, bpr, mode)
 
 
 def _with_ancestors(ids):
@@ -439,7 +445,7 @@ def _with_ancestors(ids):
     return out
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 * scenes.FUZZ_SCALE))
 def test_per_ray_lod_through_the_plugin_matches_the_oracle(drv, seed):
     # EXTENSION (BASELINE C5): the pipeline makes the ancestors of the SelectVisibles cut resident and
     # the renderer applies the screen-space-error rule along every ray; the oracle renders the

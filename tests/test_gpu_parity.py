@@ -331,7 +331,7 @@ def test_c2_full_size_rows_of_the_other_modes(vrc):
     assert abs(n_lin - n_gather) <= 2e-4 * n_lin
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(32 * scenes.FUZZ_SCALE))
 def test_random_views_all_gpu_kernels_match_the_oracle(vrc, seed):
     # the fuzz of tests/test_cpu_harness.py on the device: random volumes, cameras (also inside
     # the volume), clip planes, viewports, step sizes; gather and LDS kernels, both filters,
@@ -354,7 +354,7 @@ def test_random_views_all_gpu_kernels_match_the_oracle(vrc, seed):
             _fuzz_parity(got, want_gl, "seed %d k%d glRaycaster %r" % (seed, k, kw))
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * scenes.FUZZ_SCALE))
 def test_random_views_uint16_and_multipass(vrc, seed):
     # the same fuzz for 16-bit volumes (gather kernels, per-sample classification) and for frames
     # rendered in several passes over random splits of the brick list (accumulating pixel buffer)
@@ -591,8 +591,10 @@ def test_ray_lod_small_bound_equals_the_leaf_render(vrc):
         want, n_want, _ = g.render(kernel=vrc.KERNEL_GRID_DDA)
     with _gpu(s) as g:
         got, n_got, _ = g.render(ray_lod=(0.01, orc.world_space_per_pixel(s)))
-    _lod_parity(got, want, "leaves")
-    assert abs(n_got - n_want) <= 3e-4 * n_want + 16
+    # the runs start 1 % of a voxel inside a brick, the per-brick segments on its face
+    mx, mean, over = orc.compare(got, want)
+    assert mx <= 5 * scenes.MAX_ABS and mean <= 8 * scenes.MEAN_ABS and over <= 0.06, (mx, mean, over)
+    assert abs(n_got - n_want) <= 2e-3 * n_want + 16
 
 
 def test_ray_lod_partial_hierarchy_clip_planes_eye_inside(vrc):
@@ -628,7 +630,7 @@ def test_ray_lod_refusals(vrc):
             g.render(ray_lod=lod)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * scenes.FUZZ_SCALE))
 def test_ray_lod_random_views(vrc, seed):
     rng = np.random.default_rng(7100 + seed)
     vox = [int(rng.choice([32, 64, 96])) for _ in range(3)]

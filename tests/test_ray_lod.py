@@ -18,6 +18,15 @@ def _parity(got, want, what):
         "%s: max|d|=%.3g mean|d|=%.3g over=%.4f" % (what, mx, mean, over)
 
 
+def _close_to_per_brick(got, want, what):
+    # against the reference's per-brick march of the same bricks: the runs start eps (1 % of a voxel)
+    # inside a brick where the per-brick segment starts on its face, so every sample sits that much
+    # further along the ray and a few more nearest-voxel picks differ
+    mx, mean, over = orc.compare(got, want)
+    assert mx <= 5 * scenes.MAX_ABS and mean <= 8 * scenes.MEAN_ABS and over <= 0.06, \
+        "%s: max|d|=%.3g mean|d|=%.3g over=%.4f" % (what, mx, mean, over)
+
+
 def _hierarchy(voxels=(64, 64, 64), block=16, levels=None, **kw):
     vi = orc.mem_volume_info(voxels[0], voxels[1], voxels[2], block)
     return orc.build_scene(voxels=voxels, block=block, ids=orc.all_level_ids(vi, levels), **kw)
@@ -65,8 +74,8 @@ def test_small_error_bound_renders_the_leaves():
     lod = (0.01, orc.world_space_per_pixel(s))
     want, n_want = orc.oracle_render(leaves)
     for got, n_got in (orc.oracle_render(s, ray_lod=lod), orc.harness_render_ray_lod(s, lod, kernel=1)[:2]):
-        _parity(got, want, "leaves")
-        assert abs(n_got - n_want) <= 3e-4 * n_want + 16
+        _close_to_per_brick(got, want, "leaves")
+        assert abs(n_got - n_want) <= 2e-3 * n_want + 16  # a run is eps shorter than the brick segment
 
 
 def test_large_error_bound_renders_the_root_with_scaled_steps():
@@ -107,8 +116,8 @@ def test_missing_levels_fall_back_to_coarser_then_finer():
     only_leaves = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(40, 32), volume="hash")
     a, n_a = orc.oracle_render(only_leaves, ray_lod=(1e3, wpp))
     b, n_b = orc.oracle_render(only_leaves)
-    assert abs(n_a - n_b) <= 3e-4 * n_b + 16
-    _parity(a, b, "leaves only")
+    assert abs(n_a - n_b) <= 2e-3 * n_b + 16
+    _close_to_per_brick(a, b, "leaves only")
 
 
 def test_partial_hierarchy_with_holes():
@@ -146,7 +155,7 @@ def test_two_bricks_of_one_level_over_a_cell_are_refused():
         orc.harness_render_ray_lod(s, lod)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * scenes.FUZZ_SCALE))
 def test_random_views(seed):
     rng = np.random.default_rng(7000 + seed)
     vox = [int(rng.choice([32, 64, 96])) for _ in range(3)]
@@ -217,7 +226,7 @@ def test_ragged_uvf_tree_level_extremes():
     wpp = orc.world_space_per_pixel(s)
     fine, n_fine = orc.oracle_render(s, ray_lod=(0.01, wpp))
     want, n_want = orc.oracle_render(leaves)
-    _parity(fine, want, "uvf leaves")
-    assert abs(n_fine - n_want) <= 3e-4 * n_want + 16
+    _close_to_per_brick(fine, want, "uvf leaves")
+    assert abs(n_fine - n_want) <= 2e-3 * n_want + 16
     coarse, n_coarse = orc.oracle_render(s, ray_lod=(1e3, wpp))
     assert abs(2 * n_coarse - n_fine) <= 0.1 * n_fine
