@@ -95,6 +95,11 @@ typedef struct
 #define VRC_OPT_VARIANT 7         /* which of the reference's two raycasters the frame must match:
                                    * VRC_VARIANT_CUDARAYCASTER (default) | VRC_VARIANT_GLRAYCASTER */
 
+#define VRC_OPT_KERNEL_USED 8      /* read-only (vrc_get_option): VRC_KERNEL_* of the last vrc_render, without the
+                                   * synchronisation vrc_get_stats implies.  Every kernel but REFERENCE_ORDER
+                                   * finds the bricks of a ray through the brick grid: the order of the node
+                                   * list does not matter to it */
+
 #define VRC_VARIANT_CUDARAYCASTER 0 /* renderers/cudaRaycaster/cuda/Renderer.cu:95-230 */
 #define VRC_VARIANT_GLRAYCASTER 1   /* renderers/glRaycaster/shaders/fragRaycast.glsl:113-215: pixel centre
                                      * +0.5, hit test t0 <= t1, first sample of a brick snapped to the

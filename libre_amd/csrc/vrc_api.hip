@@ -301,6 +301,7 @@ int vrc_get_option( vrc_ctx* c, int option, int64_t* value )
     case VRC_OPT_TILE_ORDER: *value = c->optTileOrder; return VRC_OK;
     case VRC_OPT_STEPPING: *value = c->optStepping; return VRC_OK;
     case VRC_OPT_VARIANT: *value = c->optVariant; return VRC_OK;
+    case VRC_OPT_KERNEL_USED: *value = c->stats.kernel_variant; return VRC_OK;
     default: return fail( VRC_EINVAL, "vrc_get_option: unknown option" );
     }
 }

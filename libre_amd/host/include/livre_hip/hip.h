@@ -100,9 +100,12 @@ private:
     std::vector< Identifier > _sortedForIds;
     std::vector< Vector3f > _sortedForTex;
     std::vector< Identifier > _sortedIds;
+    std::vector< uint32_t > _sortedOrder; /* sorted position -> index in the render data */
     std::vector< vrc_node_data > _sortedNodes;
     Matrix4f _sortedMV;
     vrc_pool* _sortedPool = nullptr;
+    bool _orderFree = false; /* the last kernel enumerated bricks through the grid: list order irrelevant */
+    bool _orderExact = true; /* the kept node table is in front-to-back order for _sortedMV */
 };
 
 /** renderers/cudaRaycaster/CudaRaycastPipeline.h:37-60 */

@@ -60,6 +60,62 @@ vrc_ctx* deviceContext()
     return g_deviceCtx;
 }
 
+/** LIVRE_HIP_PROFILE=1: host time of the stages of a frame, summed and printed when the pipeline goes */
+struct StageClock
+{
+    enum Stage { VisibleSet, Upload, PreRender, SortAndFill, DeviceCalls, PostRender, nStages };
+    static bool enabled()
+    {
+        static const bool on = std::getenv( "LIVRE_HIP_PROFILE" ) != nullptr;
+        return on;
+    }
+    static double& sum( Stage s )
+    {
+        static double sums[nStages] = { 0, 0, 0, 0, 0, 0 };
+        return sums[s];
+    }
+    static size_t& frames()
+    {
+        static size_t n = 0;
+        return n;
+    }
+    static size_t& orderKept()
+    {
+        static size_t n = 0;
+        return n;
+    }
+    static size_t& orderSorted()
+    {
+        static size_t n = 0;
+        return n;
+    }
+    explicit StageClock( Stage s ) : _stage( s ), _on( enabled() )
+    {
+        if( _on )
+            _t0 = std::chrono::steady_clock::now();
+    }
+    ~StageClock()
+    {
+        if( _on )
+            sum( _stage ) += std::chrono::duration< double, std::micro >( std::chrono::steady_clock::now() - _t0 ).count();
+    }
+    static void report()
+    {
+        if( !enabled() || frames() == 0 )
+            return;
+        static const char* names[nStages] = { "visible set", "upload / cache look-ups", "preRender", "sort + node table",
+                                              "device calls", "postRender" };
+        std::fprintf( stderr, "[livre_hip] host time per frame over %zu frames (render thread; repeated frames skip the first two):", frames() );
+        for( int i = 0; i < nStages; ++i )
+            std::fprintf( stderr, " %s %.1f us;", names[i], sum( Stage( i ) ) / double( frames() ) );
+        std::fprintf( stderr, " new views of the same bricks: order kept %zu times, sorted anew %zu times\n", orderKept(),
+                      orderSorted() );
+    }
+    Stage _stage;
+    bool _on;
+    std::chrono::steady_clock::time_point _t0;
+};
+
 /** std::thread stand-in for tuyau::PushExecutor: n workers draining a task queue */
 class Executor
 {
@@ -284,6 +340,7 @@ vrc_view_data makeViewData( const RenderInputs& renderInputs ) /* CudaRaycastRen
 
 void HipRaycastRenderer::preRender( const RenderInputs& renderInputs, const ConstCacheObjects& renderData )
 {
+    const StageClock clock( StageClock::PreRender );
     /* update(): cuda/Renderer.cu:245-250 */
     const std::vector< Vector4f >& planes = renderInputs.renderSettings.getClipPlanes().getPlanes();
     if( planes.size() > 6 )
@@ -333,30 +390,70 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
     _lastRayLod = false;
     if( renderData.empty() ) /* CudaRaycastRenderer.cpp:157-158 */
         return;
+    std::unique_ptr< StageClock > clock( new StageClock( StageClock::SortAndFill ) );
     /* CudaRaycastRenderer.cpp:160-163: sort front to back by distance of the box centre.
      * (keys are precomputed; the reference recomputes them inside the comparator) */
     const Frustum& frustum = renderInputs.frameInfo.frustum;
     /* the same bricks seen through the same model-view matrix sort into the same list: a frame
      * that repeats the last one (a standing camera, the ranks of a sort-first frame at a high
      * frame rate) skips the 512 transforms, the sort and the fill (~30 us of host time) */
-    bool sameList = _sortedFor.size() == renderData.size() && _sortedMV == frustum.getMVMatrix();
-    for( size_t i = 0; sameList && i < renderData.size(); ++i )
+    bool sameBricks = _sortedFor.size() == renderData.size();
+    for( size_t i = 0; sameBricks && i < renderData.size(); ++i )
     {
         /* same object: same address, and -- an address can be recycled -- same brick in the same slot */
         const HipTextureObject& obj = static_cast< const HipTextureObject& >( *renderData[i] );
-        sameList = _sortedFor[i] == renderData[i].get() && _sortedForIds[i] == obj.getId() &&
-                   _sortedForTex[i] == obj.getTexPosition();
+        sameBricks = _sortedFor[i] == renderData[i].get() && _sortedForIds[i] == obj.getId() &&
+                     _sortedForTex[i] == obj.getTexPosition();
+    }
+    bool sameList = sameBricks && _sortedMV == frustum.getMVMatrix();
+    int64_t kernelWanted = VRC_KERNEL_AUTO;
+    (void)vrc_get_option( _ctx, VRC_OPT_KERNEL, &kernelWanted );
+    const bool orderFree = _orderFree && kernelWanted != VRC_KERNEL_REFERENCE_ORDER;
+    if( sameList && !_orderExact && !orderFree )
+        sameList = false; /* the kept list is in an older view's order and this kernel marches in list order */
+    if( sameBricks && !sameList && orderFree )
+    {
+        /* the same bricks from another view point, and the last frame's kernel found its bricks
+         * through the brick grid (whether the bricks form a grid does not depend on the camera):
+         * the order of the node list means nothing to it, so the list stays -- no 512 transforms,
+         * no sort, and vrc_render finds the device copy of the table current */
+        sameList = true;
+        _sortedMV = frustum.getMVMatrix();
+        _orderExact = false;
     }
     /* (distance, index into renderData): sorting indices moves no reference counts */
     std::vector< std::pair< float, uint32_t > > keyed;
     if( !sameList )
     {
-    keyed.reserve( renderData.size() );
-    for( uint32_t i = 0; i < renderData.size(); ++i )
-    {
-        const Boxf& box = static_cast< const HipTextureObject& >( *renderData[i] ).getWorldBox();
-        keyed.push_back( { ( frustum.getMVMatrix() * box.getCenter() ).length(), i } );
+        keyed.reserve( renderData.size() );
+        for( uint32_t i = 0; i < renderData.size(); ++i )
+        {
+            const Boxf& box = static_cast< const HipTextureObject& >( *renderData[i] ).getWorldBox();
+            keyed.push_back( { ( frustum.getMVMatrix() * box.getCenter() ).length(), i } );
+        }
     }
+    if( !sameList && sameBricks )
+    {
+        /* the camera moved a little: the last frame's order is still THE stable sort of the new
+         * distances if it is non-decreasing with ties in index order -- then the node table stays
+         * as it is (and vrc_render finds its device copy current: no rebuild, no upload) */
+        bool stillSorted = true;
+        for( size_t k = 1; stillSorted && k < _sortedOrder.size(); ++k )
+        {
+            const float d0 = keyed[_sortedOrder[k - 1]].first, d1 = keyed[_sortedOrder[k]].first;
+            stillSorted = d0 < d1 || ( d0 == d1 && _sortedOrder[k - 1] < _sortedOrder[k] );
+        }
+        if( stillSorted )
+        {
+            sameList = true;
+            _sortedMV = frustum.getMVMatrix();
+            _orderExact = true;
+        }
+        if( StageClock::enabled() )
+            ++( stillSorted ? StageClock::orderKept() : StageClock::orderSorted() );
+    }
+    if( !sameList )
+    {
     std::stable_sort( keyed.begin(), keyed.end(),
                       []( const std::pair< float, uint32_t >& a, const std::pair< float, uint32_t >& b ) {
                           return a.first < b.first;
@@ -371,9 +468,11 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
     nodeDatas.clear();
     nodeDatas.reserve( keyed.size() );
     _sortedIds.clear();
+    _sortedOrder.clear();
     pool = nullptr;
     for( const auto& kv : keyed )
     {
+        _sortedOrder.push_back( kv.second );
         const HipTextureObject* hipObject = static_cast< const HipTextureObject* >( renderData[kv.second].get() );
         const Boxf& aabb = hipObject->getWorldBox();
         vrc_node_data nd;
@@ -393,6 +492,7 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
     }
     _sortedPool = pool;
     _sortedMV = frustum.getMVMatrix();
+    _orderExact = true;
     _sortedFor.resize( renderData.size() );
     _sortedForIds.resize( renderData.size() );
     _sortedForTex.resize( renderData.size() );
@@ -403,6 +503,7 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
         _sortedForTex[i] = static_cast< const HipTextureObject& >( *renderData[i] ).getTexPosition();
     }
     }
+    clock.reset( new StageClock( StageClock::DeviceCalls ) );
     const vrc_view_data viewData = makeViewData( renderInputs );
     vrc_render_data rData; /* CudaRaycastRenderer.cpp:199-206 */
     rData.samplesPerRay = _computedSamplesPerRay;
@@ -442,6 +543,9 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
         rc = vrc_render( _ctx, &viewData, cut.data(), uint32_t( cut.size() ), &rData, pool );
     }
     throwOnVrcError( rc, "vrc_render" );
+    int64_t used = VRC_KERNEL_REFERENCE_ORDER;
+    (void)vrc_get_option( _ctx, VRC_OPT_KERNEL_USED, &used );
+    _orderFree = used != VRC_KERNEL_REFERENCE_ORDER && used != VRC_KERNEL_AUTO;
 }
 
 void HipRaycastRenderer::postRender( const RenderInputs&, const ConstCacheObjects& )
@@ -736,10 +840,28 @@ struct HipRaycastPipeline::Impl
             statistics.nRenderAvailable = statistics.nAvailable;
             return;
         }
+        NodeIds nodeIds;
+        {
+            const StageClock clock( StageClock::VisibleSet );
+            nodeIds = visibleSet( in );
+        }
+        if( _keptValid && key.rayLOD == _keptKey.rayLOD && key.dataSource == _keptKey.dataSource &&
+            key.timeStep == _keptKey.timeStep && key.minLOD == _keptKey.minLOD && nodeIds == _keptVisible )
+        {
+            /* another view of the same bricks (a camera that moves a little): the brick list is kept */
+            _keptKey = key;
+            RenderInputs plainKept( in );
+            plainKept.vrParameters.rayLOD = false;
+            renderer.render( _lastRayLod ? in : plainKept, _keptObjects, RENDER_ALL );
+            statistics.nAvailable = _keptObjects.size();
+            statistics.nNotAvailable = 0;
+            statistics.nRenderAvailable = statistics.nAvailable;
+            return;
+        }
         /* the kept bricks are referenced, hence not evictable: let go before anything is loaded */
         _keptValid = false;
         _keptObjects.clear();
-        NodeIds nodeIds = visibleSet( in );
+        const NodeIds visible = nodeIds;
         const uint32_t maxNodesPerPass =
             uint32_t( _texturePool->getTextureMem() / _texturePool->getSlotMemSize() );
         /* per-ray LOD: one pass over the visible set and its ancestors; when that does not fit the
@@ -790,13 +912,18 @@ struct HipRaycastPipeline::Impl
             const NodeIds nodesPerPass( nodeIds.begin() + startIndex, nodeIds.begin() + endIndex );
             /* createAndExecuteSyncPass, CudaRaycastPipeline.cpp:208-234 */
             const auto tU0 = std::chrono::steady_clock::now();
-            const ConstCacheObjects objects = upload( nodesPerPass, in );
+            ConstCacheObjects objects;
+            {
+                const StageClock clock( StageClock::Upload );
+                objects = upload( nodesPerPass, in );
+            }
             const auto tU1 = std::chrono::steady_clock::now();
             renderer.render( inputs, objects, renderStages );
             if( numberOfPasses == 1 && objects.size() == nodeIds.size() )
             {
                 _keptObjects = objects;
                 _keptKey = key;
+                _keptVisible = visible;
                 _keptValid = true;
             }
             if( std::getenv( "LIVRE_HIP_TRACE" ) )
@@ -894,6 +1021,7 @@ struct HipRaycastPipeline::Impl
 
     ~Impl()
     {
+        StageClock::report();
         _asyncUploadExecutor.wait();
         _uploadExecutor.wait();
         /* texture objects release their slots into the pool: drop them before the pool */
@@ -913,6 +1041,7 @@ struct HipRaycastPipeline::Impl
     bool _lastRayLod = false;
     FrameKey _keptKey;
     ConstCacheObjects _keptObjects;
+    NodeIds _keptVisible; /* the visible set (before the ancestors of per-ray LOD) the kept list was made from */
     bool _keptValid = false;
 };
 
@@ -924,6 +1053,8 @@ HipRaycastPipeline::~HipRaycastPipeline() {}
 
 RenderStatistics HipRaycastPipeline::render( Renderer& renderer, const RenderInputs& renderInputs )
 {
+    if( StageClock::enabled() )
+        ++StageClock::frames();
     RenderStatistics statistics;
     _impl->init( renderInputs );
     if( renderInputs.vrParameters.getSynchronousMode() )

@@ -31,7 +31,12 @@ int vrc_ctx_create( int, vrc_ctx** out ) { *out = new vrc_ctx(); return VRC_OK; 
 void vrc_ctx_destroy( vrc_ctx* c ) { delete c; }
 int vrc_ctx_set_stream( vrc_ctx*, void* ) { return VRC_OK; }
 int vrc_set_option( vrc_ctx* c, int o, int64_t v ) { if( o < 0 || o > 15 ) return VRC_EINVAL; c->opt[o] = v; return VRC_OK; }
-int vrc_get_option( vrc_ctx* c, int o, int64_t* v ) { if( o < 0 || o > 15 ) return VRC_EINVAL; *v = c->opt[o]; return VRC_OK; }
+int vrc_get_option( vrc_ctx* c, int o, int64_t* v )
+{
+    if( o < 0 || o > 15 ) return VRC_EINVAL;
+    *v = o == VRC_OPT_KERNEL_USED ? VRC_KERNEL_GRID_DDA : c->opt[o];
+    return VRC_OK;
+}
 int vrc_pool_create( vrc_ctx*, size_t bpv, int, int, size_t, const uint32_t mb[3], size_t maxBytes, vrc_pool** out )
 {
     vrc_pool* p = new vrc_pool();

@@ -596,3 +596,42 @@ def test_per_ray_lod_row_bands_are_rows_of_the_full_frame(drv):
             assert st.ray_lod == 1 and fb.shape == (32, W, 4)
             want = np.concatenate([full[y0:y0 + h] for (y0, h) in bands], axis=0)
             assert (fb == want).all()
+
+
+def test_moving_camera_keeps_the_brick_list_and_stays_correct(drv):
+    # a camera that moves a little sees the same bricks: the pipeline keeps the brick list and the renderer
+    # its node table (the grid kernels do not care for the order of the list); every frame must be the
+    # frame a fresh application renders from that camera, and the reference-order kernel must get
+    # its sorted list back the moment it is asked for
+    from libre_amd import vrc
+    uri = "hash://#64,64,64,16"
+
+    def fresh(spin, kernel):
+        with drv.App(uri, 80, 64, synchronous=True, sse=1.0) as a:
+            a.set_colormap(orc.linear_ramp_tf(0.3))
+            a.set_option(vrc.OPT_KERNEL, kernel)
+            a.set_camera(spin=spin)
+            return a.render_frame()[0]
+
+    with drv.App(uri, 80, 64, synchronous=True, sse=1.0) as app:
+        app.set_colormap(orc.linear_ramp_tf(0.3))
+        for i, spin in enumerate([(0.0, 0.0), (0.05, 0.02), (0.4, 0.3), (1.7, -0.6), (1.72, -0.6), (3.0, 1.0)]):
+            app.set_camera(spin=spin)
+            got, st = app.render_frame()
+            assert (got == fresh(spin, vrc.KERNEL_AUTO)).all(), spin
+        app.set_option(vrc.OPT_KERNEL, vrc.KERNEL_REFERENCE_ORDER)
+        for spin in [(3.0, 1.0), (2.9, 0.9), (0.3, -1.0)]:
+            app.set_camera(spin=spin)
+            got, _ = app.render_frame()
+            assert (got == fresh(spin, vrc.KERNEL_REFERENCE_ORDER)).all(), spin
+        app.set_option(vrc.OPT_KERNEL, vrc.KERNEL_AUTO)
+        app.set_ray_lod(True)
+        for spin in [(0.3, -1.0), (0.32, -1.0), (1.0, 0.5)]:
+            app.set_camera(spin=spin)
+            got, st = app.render_frame()
+            assert st.ray_lod == 1
+            with drv.App(uri, 80, 64, synchronous=True, sse=1.0) as a:
+                a.set_colormap(orc.linear_ramp_tf(0.3))
+                a.set_ray_lod(True)
+                a.set_camera(spin=spin)
+                assert (got == a.render_frame()[0]).all(), spin
