@@ -142,6 +142,7 @@ struct vrc_ctx
     uint32_t* dTileOrder = nullptr;
     size_t dTileOrderCap = 0;
     bool tileOrderValid = false;
+    uint32_t tileOrderReused = 0; /* frames in a row that kept the schedule of a nearby view */
     vrc_frame tileOrderFrame;
     int64_t optTileOrder = 1;
     int64_t optStepping = 1;
@@ -1057,8 +1058,31 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
             c->dTileOrderCap = nTiles;
             c->tileOrderValid = false;
         }
-        if( !c->tileOrderValid || std::memcmp( &c->tileOrderFrame, &f, sizeof( f ) ) != 0 )
+        /* The schedule is a heuristic (any permutation of the tiles renders the same frame): a camera
+         * that moved a little keeps the last one -- same pixel buffer and volume box, eye and ray
+         * matrices within 2 % -- for at most 15 frames in a row; two small kernels and a memset
+         * less per frame of an orbit. */
+        bool reuse = c->tileOrderValid;
+        if( reuse && std::memcmp( &c->tileOrderFrame, &f, sizeof( f ) ) != 0 )
         {
+            const vrc_frame& o = c->tileOrderFrame;
+            reuse = c->tileOrderReused < 15u && o.width == f.width && o.height == f.height && o.vpW == f.vpW &&
+                    o.vpH == f.vpH && o.vpX == f.vpX && o.vpY == f.vpY && o.pixelOffX == f.pixelOffX &&
+                    o.pixelOffY == f.pixelOffY && o.rowMap == f.rowMap && o.nPlanes == f.nPlanes &&
+                    std::memcmp( o.planes, f.planes, sizeof( f.planes ) ) == 0 &&
+                    std::memcmp( o.aabbMin, f.aabbMin, sizeof( f.aabbMin ) ) == 0 &&
+                    std::memcmp( o.aabbMax, f.aabbMax, sizeof( f.aabbMax ) ) == 0 &&
+                    std::memcmp( o.invProj, f.invProj, sizeof( f.invProj ) ) == 0;
+            for( int i = 0; reuse && i < 3; ++i )
+                reuse = std::fabs( o.eye[i] - f.eye[i] ) <= 0.02f;
+            for( int i = 0; reuse && i < 16; ++i )
+                reuse = std::fabs( o.invView[i] - f.invView[i] ) <= 0.02f;
+            if( reuse )
+                ++c->tileOrderReused;
+        }
+        if( !reuse )
+        {
+            c->tileOrderReused = 0;
             VRC_HIP_CHECK( vrc_launch_tile_order( f, c->dTileOrder, c->dTileOrder + c->dTileOrderCap,
                                                   (uint8_t*)( c->dTileOrder + c->dTileOrderCap + VRC_TILE_SCRATCH_WORDS ),
                                                   c->stream ) );
