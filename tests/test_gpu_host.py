@@ -635,3 +635,68 @@ def test_moving_camera_keeps_the_brick_list_and_stays_correct(drv):
                 a.set_ray_lod(True)
                 a.set_camera(spin=spin)
                 assert (got == a.render_frame()[0]).all(), spin
+
+
+@pytest.mark.parametrize("seed", range(6 * scenes.FUZZ_SCALE))
+def test_random_frame_sequences_equal_fresh_applications(drv, seed):
+    # the pipeline and the renderer keep state between frames (brick list, node table, tile schedule,
+    # classified tables): after any sequence of changes a frame must be the frame a fresh application
+    # renders with the same settings -- bit for bit with the gather kernels
+    from libre_amd import vrc
+    rng = np.random.default_rng(11000 + seed)
+    volume = str(rng.choice(["hash", "mem"]))
+    uri = "%s://#64,64,64,16" % volume
+    W, H = int(rng.integers(24, 72)), int(rng.integers(24, 72))
+    sync = bool(rng.random() < 0.8)
+    state = dict(spin=(0.0, 0.0), eye=(0.0, 0.0, 1.5), alpha=0.3, planes=[], ray_lod=False, kernel=vrc.KERNEL_AUTO,
+                 flt=vrc.FILTER_NEAREST, bands=[])
+    sse = float(rng.choice([0.5, 1.0, 2.0]))
+
+    def apply(app, st):
+        app.set_camera(position=st["eye"], spin=st["spin"])
+        app.set_colormap(orc.linear_ramp_tf(st["alpha"]))
+        app.set_clip_planes(st["planes"])
+        app.set_ray_lod(st["ray_lod"])
+        app.set_option(vrc.OPT_KERNEL, st["kernel"])
+        app.set_option(vrc.OPT_FILTER, st["flt"])
+        app.set_bands(st["bands"])
+        if not st["bands"]:
+            app.height = H
+
+    def settle(app):
+        fb, st = app.render_frame()
+        for _ in range(200):
+            if st.n_not_available == 0:
+                break
+            app.wait_uploads()
+            fb, st = app.render_frame()
+        assert st.n_not_available == 0
+        return fb
+
+    with drv.App(uri, W, H, synchronous=sync, sse=sse, gpu_cache_mb=16) as app:
+        for step in range(8):
+            what = int(rng.integers(0, 8))
+            if what == 0:    # small camera move
+                state["spin"] = (state["spin"][0] + float(rng.uniform(-0.03, 0.03)), state["spin"][1] + float(rng.uniform(-0.03, 0.03)))
+            elif what == 1:  # big camera move
+                state["spin"] = (float(rng.uniform(-3.1, 3.1)), float(rng.uniform(-1.2, 1.2)))
+                state["eye"] = (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)), float(rng.uniform(0.7, 1.8)))
+            elif what == 2:
+                state["alpha"] = float(rng.choice([0.05, 0.3, 1.0]))
+            elif what == 3:
+                state["planes"] = [] if state["planes"] else [[0.0, 0.6, 0.8, float(rng.uniform(0.1, 0.3))]]
+            elif what == 4:
+                state["ray_lod"] = not state["ray_lod"]
+            elif what == 5:
+                state["kernel"] = int(rng.choice([vrc.KERNEL_AUTO, vrc.KERNEL_REFERENCE_ORDER]))
+            elif what == 6:
+                state["bands"] = [] if state["bands"] else [(8, 8), (H - 12, 8)]
+            # what == 7: the same frame again
+            if state["ray_lod"]:
+                state["kernel"] = vrc.KERNEL_AUTO  # per-ray LOD has its own kernel
+            apply(app, state)
+            got = settle(app)
+            with drv.App(uri, W, H, synchronous=True, sse=sse, gpu_cache_mb=16) as ref:
+                apply(ref, state)
+                want = ref.render_frame()[0]
+            assert got.shape == want.shape and (got == want).all(), (seed, step, what, state, sync)
