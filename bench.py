@@ -43,6 +43,12 @@ def parse():
                          "GPU (the kernel fills the chip; the roofline is that of an undisturbed "
                          "launch), 3 when the frame is split over several GPUs and each has idle "
                          "capacity (Equalizer renders ahead too: its default latency is one frame)")
+    ap.add_argument("--gather-batch", type=int, default=0,
+                    help="N>1: frames per RCCL gather (sortfirst.BatchedTileGather); 0 = auto: 3 when every rank "
+                         "has the same number of rows, else 1 (one gather per frame, sortfirst.TileGather)")
+    ap.add_argument("--check-frames", action="store_true",
+                    help="N>1: after the timing, compare the last assembled frame on rank 0 with the full frame "
+                         "rendered by one application (must be bit-identical)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the trilinear-extension measurement")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
@@ -114,11 +120,28 @@ def main():
     bands = layout[rank]
     rows = sum(h for _, h in bands)
     K = a.frames_in_flight if a.frames_in_flight > 0 else (1 if world == 1 else 3)
+    # N>1: B frames share one gather (a collective costs its host issue time whatever it carries, and at
+    # 8 ranks a rank's share of a frame is ~60 us of kernel); 2B renderer slots: batch n+1 is
+    # rendered while batch n is on the wire
+    equal_rows = len({sum(h for _, h in b) for b in layout}) == 1
+    B = a.gather_batch if a.gather_batch > 0 else (3 if (world > 1 and equal_rows) else 1)
+    if world == 1 or not equal_rows:
+        B = 1
+    batched = world > 1 and B > 1
+    if batched:
+        K = 2 * B
     a.warmup = max(a.warmup, K)
     # per in-flight frame: a pixel buffer of this rank's stacked bands (device memory owned by
     # torch), a stream and a tile-gather buffer set
-    fbs = [torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(K)]
+    bgather = sortfirst.BatchedTileGather(layout, W, rank, "cuda", B) if batched else None
+    if batched:
+        fbs = [bgather.send[k // B, k % B] for k in range(K)]
+    else:
+        fbs = [torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(K)]
     streams = [torch.cuda.Stream() for _ in range(K)]
+    gstream = torch.cuda.Stream() if batched else None
+    rendered = [torch.cuda.Event() for _ in range(K)] if batched else None
+    consumed = [None, None]  # per half: event after the gather that last read it
 
     # leaves only: --min-lod = --max-lod = depth-1 (BASELINE.md "single LOD")
     probe = driver.App(uri, W, H, device=local_rank)
@@ -137,10 +160,38 @@ def main():
         app.select_slot(k)
         app.set_stream(streams[k].cuda_stream)
         app.set_framebuffer(fbs[k].data_ptr())
-    gathers = [sortfirst.TileGather(layout, W, rank, "cuda") for _ in range(K)] if world > 1 else None
+    gathers = ([sortfirst.TileGather(layout, W, rank, "cuda") for _ in range(K)]
+               if (world > 1 and not batched) else None)
     counter = [0]
+    last_frame = [None]  # rank 0: the most recently assembled frame (--check-frames)
+
+    def flush(half, n):
+        # one gather + one assembly for the n frames rendered into this half
+        with torch.cuda.stream(gstream):
+            for i in range(n):
+                gstream.wait_event(rendered[half * B + i])
+            bgather.gather(half, n)
+            if rank == 0:
+                last_frame[0] = bgather.assemble(n)[n - 1]
+            ev = torch.cuda.Event()
+            ev.record(gstream)
+            consumed[half] = ev
 
     def frame():
+        if batched:
+            c = counter[0]
+            counter[0] += 1
+            i, half = c % B, (c // B) % 2
+            k = half * B + i
+            with torch.cuda.stream(streams[k]):
+                if consumed[half] is not None:
+                    streams[k].wait_event(consumed[half])  # the gather two batches ago read this buffer
+                app.select_slot(k)
+                app.render_frame(readback=False)
+                rendered[k].record(streams[k])
+            if i == B - 1:
+                flush(half, B)
+            return
         k = counter[0] % K
         counter[0] += 1
         with torch.cuda.stream(streams[k]):
@@ -149,7 +200,14 @@ def main():
             if gathers is not None:  # sort-first assembly: tiles to rank 0 over RCCL/xGMI
                 gathers[k].gather(fbs[k])
                 if rank == 0:
-                    gathers[k].assemble()
+                    last_frame[0] = gathers[k].assemble()
+
+    def drain():
+        # a partial batch at the end of a run of frames
+        if batched and counter[0] % B:
+            n = counter[0] % B
+            flush((counter[0] // B) % 2, n)
+            counter[0] += B - n  # the next frame starts a new batch
 
     def all_slots(fn):
         out = []
@@ -162,6 +220,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     frame()
+    drain()
     torch.cuda.synchronize()
     first_frame_ms = (time.perf_counter() - t0) * 1e3
 
@@ -179,6 +238,7 @@ def main():
 
     for _ in range(a.warmup):
         frame()
+    drain()
     torch.cuda.synchronize()
     all_slots(app.stats)  # reset the kernel-time accumulators
     if world > 1:
@@ -187,6 +247,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         frame()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -205,6 +266,18 @@ def main():
     if world > 1:
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
     kernel_ms_per_frame = float(kt.item()) / a.steps  # slowest rank's kernels per frame
+
+    # --check-frames: the frame assembled from the ranks' bands is the frame one application renders
+    frame_check = None
+    if a.check_frames and world > 1 and rank == 0 and last_frame[0] is not None:
+        with driver.App(uri, W, H, device=local_rank, synchronous=True, min_lod=depth - 1, max_lod=depth - 1,
+                        gpu_cache_mb=3072) as whole:
+            whole.set_camera(spin=tuple(a.spin))
+            whole.set_colormap(linear_ramp(a.alpha))
+            want, _ = whole.render_frame()
+        got = last_frame[0].cpu().numpy()
+        frame_check = {"max_abs_diff": float(np.abs(got - want).max()), "bit_identical": bool((got == want).all()),
+                       "alpha_max": float(got[..., 3].max())}
 
     def extra_trilinear():
         # extension, outside the judged number: the trilinear filter (north star) on the same
@@ -396,8 +469,9 @@ def main():
                                    % (uri, W, H, n_nodes, a.block + 8,
                                       app.stats().samples_per_ray, a.alpha),
                        "parallelism": "sort-first, %d rank(s) x %d interleaved row band(s) in one "
-                                      "launch, RGBA32F gather to rank 0, %d frames in flight"
-                                      % (world, len(bands), K),
+                                      "launch, RGBA32F gather to rank 0 (%d frame(s) per gather), %d frames in flight"
+                                      % (world, len(bands), B, K),
+                       "sort_first_frame_check": frame_check,
                        "samples_per_frame": samples_frame,
                        "first_frame_with_upload_ms": first_frame_ms,
                        "extension_trilinear": trilinear, "moving_camera": moving,

@@ -85,3 +85,60 @@ class TileGather:
                 self.frame[y0:y0 + h].copy_(self.recv[r][off:off + h])
                 off += h
         return self.frame
+
+
+class BatchedTileGather:
+    """The sort-first assembly of `batch` consecutive frames with ONE collective: every rank renders
+    frame i of a batch into send[half, i]; after the batch one gather moves all of them to the
+    display rank and one strided copy places them into `batch` full frames.  A collective costs
+    its issue time on the host whatever it carries; at eight ranks a rank's share of a frame is
+    ~60 us of kernel, less than that issue time, so the frame rate of the node is the rate at
+    which collectives can be issued unless frames share one.  Two halves: batch n+1 is rendered
+    while batch n is on the wire.  Equal row counts per rank (band_layout gives them whenever the
+    frame height divides evenly) are required; otherwise use TileGather per frame."""
+
+    def __init__(self, layout, width, rank, device, batch, dst=0):
+        self.layout, self.width, self.rank, self.dst, self.batch = layout, width, rank, dst, batch
+        self.world = len(layout)
+        counts = [sum(h for _, h in b) for b in layout]
+        if len(set(counts)) != 1:
+            raise ValueError("BatchedTileGather needs the same number of rows on every rank")
+        self.rows = counts[0]
+        self.height = sum(counts)
+        heights = {h for b in layout for _, h in b}
+        self.regular = (len(heights) == 1 and all(
+            bands == [((k * self.world + r) * h, h) for k in range(len(bands))]
+            for r, bands in enumerate(layout) for h in heights))
+        self.send = torch.zeros((2, batch, self.rows, width, 4), dtype=torch.float32, device=device)
+        self.recv_all = None
+        self.frames = None
+        if rank == dst:
+            self.recv_all = torch.empty((self.world, batch, self.rows, width, 4), dtype=torch.float32, device=device)
+            self.frames = torch.zeros((batch, self.height, width, 4), dtype=torch.float32, device=device)
+
+    def gather(self, half, n):
+        """Collective: the first n frames of send[half] of every rank -> recv_all[:, :n] on the display rank."""
+        local = self.send[half, :n]
+        if self.world == 1:
+            if self.rank == self.dst:
+                self.recv_all[0, :n].copy_(local)
+            return
+        recv = [self.recv_all[r, :n] for r in range(self.world)] if self.rank == self.dst else None
+        dist.gather(local, recv, dst=self.dst)
+
+    def assemble(self, n):
+        """Display rank only: the n gathered frames, each band at its rows.  -> frames[:n]"""
+        assert self.rank == self.dst
+        if self.regular:
+            h = self.layout[0][0][1]
+            bpr = len(self.layout[0])
+            src = self.recv_all[:, :n].reshape(self.world, n, bpr, h, self.width, 4).permute(1, 2, 0, 3, 4, 5)
+            self.frames[:n].view(n, bpr, self.world, h, self.width, 4).copy_(src)
+            return self.frames[:n]
+        for r, bands in enumerate(self.layout):
+            off = 0
+            for (y0, h) in bands:
+                self.frames[:n, y0:y0 + h].copy_(self.recv_all[r, :n, off:off + h])
+                off += h
+        return self.frames[:n]
+

@@ -94,3 +94,54 @@ def test_assembly_of_regular_and_ragged_layouts_without_a_process_group():
             tg.recv[r].copy_(rows[:, None, None].expand(-1, 8, 4))
         frame = tg.assemble()
         assert torch.equal(frame[:, 0, 0], torch.arange(height).float())
+
+
+def _batched_worker(rank, world, port, height, width, bands_per_rank, batch, n_frames, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from libre_amd import sortfirst
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    layout = sortfirst.band_layout(height, world, bands_per_rank)
+    g = sortfirst.BatchedTileGather(layout, width, rank, "cpu", batch)
+    frames = []
+    # frame f, row y, column x, channel c = f*1e6 + y*1e3 + x + c/10: every value names its place
+    yy, xx, cc = torch.meshgrid(torch.arange(height), torch.arange(width), torch.arange(4), indexing="ij")
+    base = (yy * 1000 + xx).float() + cc.float() / 10
+    f = 0
+    while f < n_frames:
+        n = min(batch, n_frames - f)
+        half = (f // batch) % 2
+        for i in range(n):
+            rows = torch.cat([base[y0:y0 + h] for (y0, h) in layout[rank]], dim=0) + (f + i) * 1.0e6
+            g.send[half, i].copy_(rows)
+        g.gather(half, n)
+        if rank == 0:
+            frames.append(g.assemble(n).clone())
+        f += n
+    if rank == 0:
+        np.save(out_path, torch.cat(frames, dim=0).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,height,bands,batch,n_frames", [(2, 48, 2, 3, 8), (3, 48, 4, 2, 5), (2, 40, 1, 4, 4)])
+def test_batched_gather_places_every_band_of_every_frame(tmp_path, world, height, bands, batch, n_frames):
+    # several frames per collective (BatchedTileGather): full and partial batches, both halves
+    width = 12
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_batched_worker, args=(world, _free_port(), height, width, bands, batch, n_frames, out),
+             nprocs=world, join=True)
+    got = np.load(out)
+    assert got.shape == (n_frames, height, width, 4)
+    yy, xx, cc = np.meshgrid(np.arange(height), np.arange(width), np.arange(4), indexing="ij")
+    for f in range(n_frames):
+        want = (yy * 1000 + xx).astype(np.float32) + cc.astype(np.float32) / 10 + np.float32(f * 1.0e6)
+        assert (got[f] == want).all(), f
+
+
+def test_batched_gather_refuses_unequal_row_counts():
+    from libre_amd import sortfirst
+    with pytest.raises(ValueError):
+        sortfirst.BatchedTileGather(sortfirst.band_layout(50, 3, 2), 8, 0, "cpu", 2)
