@@ -43,6 +43,10 @@ def parse():
                          "GPU (the kernel fills the chip; the roofline is that of an undisturbed "
                          "launch), 3 when the frame is split over several GPUs and each has idle "
                          "capacity (Equalizer renders ahead too: its default latency is one frame)")
+    ap.add_argument("--ray-lod-sse", type=float, default=0.0,
+                    help="not the judged workload: render with the whole LOD tree and per-ray adaptive LOD at this "
+                         "screen-space error (BASELINE C5's kernel side; combine with --alpha 1.0 for early ray "
+                         "termination and --gpus N for its sort-first form)")
     ap.add_argument("--gather-batch", type=int, default=0,
                     help="N>1: frames per RCCL gather (sortfirst.BatchedTileGather); 0 = auto: 3 when every rank "
                          "has the same number of rows, else 1 (one gather per frame, sortfirst.TileGather)")
@@ -149,8 +153,13 @@ def main():
     probe.close()
     # one application (one atlas, one pair of caches) per rank; its row bands are rendered by
     # ONE kernel launch per frame; K renderer instances give K frames in flight
-    app = driver.App(uri, W, H, device=local_rank, synchronous=True, min_lod=depth - 1,
-                     max_lod=depth - 1, gpu_cache_mb=3072)
+    ray_lod_on = a.ray_lod_sse > 0.0
+    if ray_lod_on:
+        app = driver.App(uri, W, H, device=local_rank, synchronous=True, sse=a.ray_lod_sse, gpu_cache_mb=3072)
+        app.set_ray_lod(True)
+    else:
+        app = driver.App(uri, W, H, device=local_rank, synchronous=True, min_lod=depth - 1,
+                         max_lod=depth - 1, gpu_cache_mb=3072)
     if world > 1:
         app.set_bands(bands)
     app.set_camera(spin=tuple(a.spin))
@@ -270,8 +279,9 @@ def main():
     # --check-frames: the frame assembled from the ranks' bands is the frame one application renders
     frame_check = None
     if a.check_frames and world > 1 and rank == 0 and last_frame[0] is not None:
-        with driver.App(uri, W, H, device=local_rank, synchronous=True, min_lod=depth - 1, max_lod=depth - 1,
-                        gpu_cache_mb=3072) as whole:
+        with driver.App(uri, W, H, device=local_rank, synchronous=True, gpu_cache_mb=3072,
+                        **(dict(sse=a.ray_lod_sse) if ray_lod_on else dict(min_lod=depth - 1, max_lod=depth - 1))) as whole:
+            whole.set_ray_lod(ray_lod_on)
             whole.set_camera(spin=tuple(a.spin))
             whole.set_colormap(linear_ramp(a.alpha))
             want, _ = whole.render_frame()
@@ -425,7 +435,7 @@ def main():
 
     # the extras can never cost the judged line: a failure is reported in their place
     def guarded(fn, default):
-        if world != 1 or a.no_extras:
+        if world != 1 or a.no_extras or ray_lod_on:
             return default
         try:
             return fn()
@@ -444,7 +454,7 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r1_traffic_c2.json")
         if (world == 1 and a.voxels == 1024 and a.block == 128 and a.viewport == 1024
-                and tuple(a.spin) == (0.0, 0.0) and os.path.exists(tpath)):
+                and tuple(a.spin) == (0.0, 0.0) and not ray_lod_on and os.path.exists(tpath)):
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         n_nodes = (a.voxels // a.block) ** 3
         # interior voxels of marched bricks + one RGBA32F write + node table + TF.
@@ -464,10 +474,13 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic (mem:// rule of datasources/memory/MemoryDataSource.cpp:54-57)",
-            "config": {"workload": "C2: %s uint8, %dx%d viewport, leaves only (%d bricks of %d^3), "
-                                   "%d samples/ray, linear-ramp TF alpha=%.3g, default camera"
-                                   % (uri, W, H, n_nodes, a.block + 8,
-                                      app.stats().samples_per_ray, a.alpha),
+            "config": {"workload": ("C2: %s uint8, %dx%d viewport, leaves only (%d bricks of %d^3), "
+                                    "%d samples/ray, linear-ramp TF alpha=%.3g, default camera"
+                                    % (uri, W, H, n_nodes, a.block + 8,
+                                       app.stats().samples_per_ray, a.alpha)) if not ray_lod_on else
+                                   ("NOT the judged workload -- C5 kernel side: %s uint8, %dx%d viewport, whole LOD "
+                                    "tree, per-ray adaptive LOD at screen-space error %g, linear-ramp TF alpha=%.3g"
+                                    % (uri, W, H, a.ray_lod_sse, a.alpha)),
                        "parallelism": "sort-first, %d rank(s) x %d interleaved row band(s) in one "
                                       "launch, RGBA32F gather to rank 0 (%d frame(s) per gather), %d frames in flight"
                                       % (world, len(bands), B, K),
@@ -480,7 +493,8 @@ def main():
                        "extension_per_ray_lod": ray_lod},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "vrc_k_raycast<true,false,false,true,0,unsigned char>",
+                         "kernel": ("vrc_k_raycast_raylod<false,false,true,0,unsigned char>" if ray_lod_on else
+                                    "vrc_k_raycast<true,false,false,true,0,unsigned char>"),
                          "kernel_ms_per_frame": kernel_ms_per_frame,
                          "algorithmic_bytes_per_launch": per_rank_alg,
                          "algorithmic_bytes_per_frame_all_ranks": alg_bytes,
@@ -490,7 +504,7 @@ def main():
                                  "(DESIGN.md section 4); traffic = FETCH_SIZE + WRITE_SIZE bytes per "
                                  "launch from profiles/r1_traffic_c2.json"},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not ray_lod_on:
             try:
                 out["cpu_baseline"] = cpu_baseline(a, samples_frame)
             except Exception as e:  # noqa: BLE001  (the GPU line must survive a broken checker build)
