@@ -30,7 +30,8 @@ static int run( int synchronous, uint32_t gpuMb, int frames, int rayLod = 0 )
     const float pos[3] = { 0.f, 0.f, 1.5f }, look[3] = { 0.f, 0.f, 0.f };
     for( int i = 0; i < frames; ++i )
     {
-        lvh_app_set_camera( app, pos, look, 0.3f + 0.05f * float( i % 7 ), 0.2f );
+        /* every view twice in a row (the repeated frame takes the kept brick list), small and large moves */
+        lvh_app_set_camera( app, pos, look, 0.3f + 0.05f * float( ( i / 2 ) % 7 ) + ( i % 11 == 0 ? 1.5f : 0.f ), 0.2f );
         if( lvh_app_render_frame( app, nullptr, &st ) != 0 )
         {
             std::printf( "render failed: %s\n", lvh_last_error() );
