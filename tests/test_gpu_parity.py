@@ -73,6 +73,10 @@ def test_scene_parity_both_kernels(vrc, golden, name):
         assert abs(n_dda - n_want) <= 2e-4 * n_want + 8
         auto, _, st = g.render(kernel=vrc.KERNEL_AUTO, count=False)
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
+        used = C.c_int64(-1)  # the same answer without the synchronisation of vrc_get_stats
+        vrc.check(g.L, g.L.vrc_get_option(g.ctx, vrc.OPT_KERNEL_USED, C.byref(used)))
+        assert used.value == vrc.KERNEL_GRID_DDA
+        assert g.L.vrc_set_option(g.ctx, vrc.OPT_KERNEL_USED, 1) != 0  # read-only
         # counting samples must not change a single bit of the frame
         assert (auto == dda).all()
         # idempotence: same inputs, same bits
