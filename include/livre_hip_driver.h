@@ -101,6 +101,8 @@ int lvh_select_visibles( const char* volume_uri, const float mv[16], const float
 int lvh_selftest_cache( void );
 int lvh_selftest_plugin_factory( void );
 int lvh_selftest_camera( float out_matrices[4][16] );
+int lvh_selftest_clip_planes( void );         /* tests/core/clipPlanes.cpp:29-59; 0 or the failing line */
+int lvh_selftest_renderer_parameters( void ); /* tests/lib/rendererParameters.cpp:25-59 */
 int lvh_datasource_brick( const char* volume_uri, uint64_t node_id, uint8_t* out, size_t capacity,
                           size_t* n );
 

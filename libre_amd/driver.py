@@ -31,6 +31,7 @@ EXPORTS = [
     "lvh_app_get_stats", "lvh_app_wait_uploads", "lvh_app_synchronize", "lvh_app_volume_info",
     "lvh_app_visible_set", "lvh_app_view_matrices", "lvh_app_cache_stats", "lvh_select_visibles",
     "lvh_selftest_cache", "lvh_selftest_plugin_factory", "lvh_selftest_camera",
+    "lvh_selftest_clip_planes", "lvh_selftest_renderer_parameters",
     "lvh_datasource_brick", "lvh_datasource_info", "lvh_datasource_node",
 ]
 

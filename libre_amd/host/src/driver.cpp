@@ -510,6 +510,52 @@ int lvh_selftest_camera( float out[4][16] )
     return 0;
 }
 
+/* tests/core/clipPlanes.cpp:29-59 (testClipping), statement by statement; returns the line of the first failed check */
+int lvh_selftest_clip_planes( void )
+{
+#define LVH_CHECK( cond ) if( !( cond ) ) return __LINE__
+    const Boxf boxInside( Vector3f( -0.3f, -0.3f, -0.3f ), Vector3f( 0.3f, 0.3f, 0.3f ) );
+    const Boxf boxOutside( Vector3f( 0.8f, 0.8f, 0.8f ), Vector3f( 0.9f, 0.9f, 0.9f ) );
+    const Boxf boxIntersect( Vector3f( -0.3f, -0.3f, -0.3f ), Vector3f( 0.9f, 0.9f, 0.9f ) );
+    ClipPlanes clipPlanes;
+    LVH_CHECK( !clipPlanes.isClipped( boxInside ) );
+    LVH_CHECK( clipPlanes.isClipped( boxOutside ) );
+    LVH_CHECK( !clipPlanes.isClipped( boxIntersect ) );
+    LVH_CHECK( !clipPlanes.isEmpty() );
+    clipPlanes.clear();
+    LVH_CHECK( clipPlanes.isEmpty() );
+    clipPlanes.reset();
+    LVH_CHECK( !clipPlanes.isEmpty() );
+    LVH_CHECK( !clipPlanes.isClipped( boxInside ) );
+    LVH_CHECK( clipPlanes.isClipped( boxOutside ) );
+    LVH_CHECK( !clipPlanes.isClipped( boxIntersect ) );
+    return 0;
+}
+
+/* tests/lib/rendererParameters.cpp:25-44 (defaultValues) and :46-59 (copy) */
+int lvh_selftest_renderer_parameters( void )
+{
+    const RendererParameters params;
+    LVH_CHECK( params.getMaxLOD() == ( 4u << 1 ) + 1u ); /* NODEID_LEVEL_BITS = 4, livre/core/types.h:191 */
+    LVH_CHECK( params.getMinLOD() == 0u );
+    LVH_CHECK( !params.getSynchronousMode() );
+    LVH_CHECK( params.getSamplesPerRay() == 0u );
+    LVH_CHECK( params.getSamplesPerPixel() == 1u );
+    LVH_CHECK( params.getSSE() == 4.0f );
+    LVH_CHECK( params.getMaxGPUCacheMemoryMB() == 3072u );
+    LVH_CHECK( params.getMaxCPUCacheMemoryMB() == 8192u );
+    LVH_CHECK( !params.getRayLOD() ); /* the extension is off unless asked for */
+    RendererParameters changed;
+    changed.maxLOD = 42;
+    const RendererParameters copy( changed );
+    LVH_CHECK( copy.getMaxLOD() == 42u );
+    RendererParameters assigned;
+    assigned = changed;
+    LVH_CHECK( assigned.getMaxLOD() == 42u );
+    return 0;
+#undef LVH_CHECK
+}
+
 int lvh_datasource_brick( const char* uri, uint64_t nodeId, uint8_t* out, size_t cap, size_t* n )
 {
     try

@@ -13,6 +13,8 @@ int main( int argc, char** argv )
     int rc = lvh_selftest_cache(); std::printf("cache %d %s\n", rc, rc ? lvh_last_error() : "");
     rc = lvh_selftest_plugin_factory(); std::printf("factory %d %s\n", rc, rc ? lvh_last_error() : "");
     float m[4][16]; rc = lvh_selftest_camera(m); std::printf("camera %d\n", rc);
+    rc = lvh_selftest_clip_planes(); std::printf("clip planes %d\n", rc);
+    rc = lvh_selftest_renderer_parameters(); std::printf("renderer parameters %d\n", rc);
     size_t n = 0;
     rc = lvh_datasource_brick("raw:///nonexistent.raw#4,4,4,uint8", 0, nullptr, 0, &n); std::printf("raw missing rc=%d %s\n", rc, lvh_last_error());
     rc = lvh_datasource_brick("nosuch://x", 0, nullptr, 0, &n); std::printf("nosuch rc=%d %s\n", rc, lvh_last_error());

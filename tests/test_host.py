@@ -44,6 +44,13 @@ def test_plugin_factory_semantics(drv):
     assert rc == 0, (rc, L.lvh_last_error())
 
 
+def test_clip_planes_and_renderer_parameters_like_the_reference_tests(drv):
+    # tests/core/clipPlanes.cpp:29-59 and tests/lib/rendererParameters.cpp:25-59, statement by statement in C++
+    L = drv.load_library()
+    assert L.lvh_selftest_clip_planes() == 0
+    assert L.lvh_selftest_renderer_parameters() == 0
+
+
 def test_camera_settings_known_answers(drv):
     # tests/eq/settings/cameraSettings.cpp:42-144
     L = drv.load_library()
