@@ -737,3 +737,21 @@ def test_atlas_of_more_than_2_pow_32_voxels(vrc):
         if pool:
             L.vrc_pool_destroy(pool)
         L.vrc_ctx_destroy(ctx)
+
+
+def test_ray_lod_matches_the_committed_frames(vrc):
+    # tests/golden/frames_ray_lod.npz: the per-ray LOD definition pinned between rounds (regular tree at two
+    # error bounds, the ragged UVF fixture)
+    import importlib.util
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden_ray_lod", os.path.join(gdir, "make_golden_ray_lod.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    golden_lod = np.load(os.path.join(gdir, "frames_ray_lod.npz"))
+    for name, s, sse in gen.cases():
+        with _gpu(s) as g:
+            got, n_got, st = g.render(ray_lod=(sse, orc.world_space_per_pixel(s)))
+        assert st.kernel_variant == vrc.KERNEL_RAY_LOD
+        _lod_parity(got, golden_lod[name], name + " gpu vs golden")
+        n_want = int(golden_lod[name + "__samples"][0])
+        assert abs(n_got - n_want) <= 3e-4 * n_want + 16

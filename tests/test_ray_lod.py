@@ -230,3 +230,24 @@ def test_ragged_uvf_tree_level_extremes():
     assert abs(n_fine - n_want) <= 2e-3 * n_want + 16
     coarse, n_coarse = orc.oracle_render(s, ray_lod=(1e3, wpp))
     assert abs(2 * n_coarse - n_fine) <= 0.1 * n_fine
+
+
+def test_oracle_still_matches_the_committed_ray_lod_frames():
+    # tests/golden/frames_ray_lod.npz pins the extension's definition between rounds
+    import importlib.util
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden_ray_lod", os.path.join(gdir, "make_golden_ray_lod.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    golden = np.load(os.path.join(gdir, "frames_ray_lod.npz"))
+    n_cases = 0
+    for name, s, sse in gen.cases():
+        lod = (sse, orc.world_space_per_pixel(s))
+        fb, n = orc.oracle_render(s, threads=8, ray_lod=lod)
+        assert n == int(golden[name + "__samples"][0]), name
+        assert np.allclose(fb, golden[name], atol=1e-6), name
+        got, n_got, ok = orc.harness_render_ray_lod(s, lod, kernel=3)
+        _parity(got, golden[name], name + " host build vs golden")
+        n_cases += 1
+    assert n_cases == 3
