@@ -496,12 +496,14 @@ def scene_from_datasource(drv, uri, ids, viewport, spin=(0.0, 0.0), alpha=0.05, 
     L.orc_make_view_data(s.mv, s.proj, (C.c_uint32 * 4)(0, 0, s.W, s.H), C.byref(vi), C.byref(s.view))
     mv = np.array(list(s.mv), dtype=np.float32).reshape(4, 4).T  # column-major -> rows
     recs = []
+    bricks = {}
     for k, nid in enumerate(ids):
         node = drv.datasource_node(uri, nid)
         assert node["valid"]
         bs = node["block_size"]
         full = [bs[a] + 2 * ov[a] for a in range(3)]
         brick = drv.datasource_brick(uri, nid).reshape(full[2], full[1], full[0])
+        bricks[nid] = np.ascontiguousarray(brick)
         slot = f32x3()
         L.orc_pool_kth_slot(slots, k, slot)
         origin = u32x3()
@@ -525,7 +527,11 @@ def scene_from_datasource(drv, uri, ids, viewport, spin=(0.0, 0.0), alpha=0.05, 
             nd.aabbMin[a] = wb[a]
             nd.aabbSize[a] = np.float32(wb[3 + a]) - np.float32(wb[a])
     s.n_nodes = n
-    s.ids = [r[2] for r in recs]
+    # what tests/gpu_run.GpuScene needs to upload the same bricks into the same slots through the C ABI
+    s.ids = list(ids)                      # upload order = slot order
+    s.sorted_ids = [r[2] for r in recs]    # order of s.nodes
+    s.bricks = bricks
+    s.pool_bytes = blocks * slot_bytes
     max_level = max(unpack(nid)[0] for nid in ids)
     if spr == 0:  # CudaRaycastRenderer.cpp:113-129
         max_dim = float(max(info["voxels"]))
