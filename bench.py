@@ -490,6 +490,11 @@ def main():
                                       % (world, len(bands), B, K),
                        "sort_first_frame_check": frame_check,
                        "samples_per_frame": samples_frame,
+                       "per_frame_work": "every timed frame is a full render_frame call and a full march (frame "
+                                         "cleared, every ray and sample computed, frame written); the camera stands "
+                                         "still, so the plugin keeps its brick list, node table and tile schedule "
+                                         "between identical frames instead of deriving them again (host side only; "
+                                         "moving_camera below is the same path with nothing to keep)",
                        "first_frame_with_upload_ms": first_frame_ms,
                        "extension_trilinear": trilinear, "moving_camera": moving,
                        "with_readback_to_pinned_host": readback,
