@@ -755,3 +755,24 @@ def test_ray_lod_matches_the_committed_frames(vrc):
         _lod_parity(got, golden_lod[name], name + " gpu vs golden")
         n_want = int(golden_lod[name + "__samples"][0])
         assert abs(n_got - n_want) <= 3e-4 * n_want + 16
+
+
+def test_more_bricks_than_the_reference_node_table_holds(vrc):
+    # quirk Q8: the reference kernel's node table has 16384 entries and no bounds check (cuda/Renderer.cu:237,
+    # 261-264); here the table is sized to the list: 32768 bricks of 8^3 voxels, both brick enumerations
+    from test_cpu_harness import _fuzz_parity
+    s = orc.build_scene(voxels=(256, 256, 256), block=8, viewport=(40, 32), volume="hash", spin=(0.4, 0.3), alpha=0.3)
+    assert s.n_nodes == 32768
+    want, n_want = orc.oracle_render(s, threads=8)
+    with _gpu(s) as g:
+        for k in (vrc.KERNEL_GRID_DDA, vrc.KERNEL_REFERENCE_ORDER):
+            got, n_got, st = g.render(kernel=k)
+            assert st.kernel_variant == k
+            # 8-voxel bricks: a brick entry (the reference's sample on the face) every few samples
+            _fuzz_parity(got, want, "32768 bricks k%d" % k)
+            assert abs(n_got - n_want) <= 3e-4 * n_want + 16
+        # the two enumerations agree except where a ray grazes a brick edge: the slab test of the list walk
+        # and the cell walk of the DDA may or may not give such a brick its one sample
+        dda, n_dda, _ = g.render(kernel=vrc.KERNEL_GRID_DDA)
+        ref, n_ref, _ = g.render(kernel=vrc.KERNEL_REFERENCE_ORDER)
+        assert np.abs(dda - ref).max() <= scenes.MAX_ABS and abs(n_dda - n_ref) <= 1e-4 * n_ref + 8
