@@ -562,7 +562,10 @@ hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
      * measured 0.153 -> 0.130 ms for an eighth of the C2 frame, 0.538 -> 0.562 ms for the whole */
     const uint32_t nTilesLaunch = ( ( a.frame.width + VRC_TILE_W - 1 ) / VRC_TILE_W ) *
                                   ( ( a.frame.height + VRC_TILE_H - 1 ) / VRC_TILE_H );
-    const bool smallLaunch = nTilesLaunch <= 6144u;
+#ifndef VRC_SMALL_LAUNCH_TILES
+#define VRC_SMALL_LAUNCH_TILES 6144u
+#endif
+    const bool smallLaunch = nTilesLaunch <= VRC_SMALL_LAUNCH_TILES;
     switch( key )
     {
     case 0: return launch_variant< false, false, false, false, VRC_MODE_TABLE, uint8_t >( a, stream );
