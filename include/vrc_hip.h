@@ -35,6 +35,7 @@ extern "C" {
 #define VRC_EUNSUPPORTED 5 /* unsupported data type / channel count, TexturePool.cu:66-67 */
 #define VRC_EHIERARCHY 6  /* vrc_set_ray_lod is on and the node list of vrc_render is not a brick hierarchy
                           * (nothing was rendered; the caller may render its per-brick cut instead) */
+#define VRC_ECOMM 7       /* RCCL missing or an RCCL call failed (vrc_comm_*, vrc_gather_tiles) */
 
 typedef struct vrc_ctx vrc_ctx;   /* replaces cuda::Renderer (cuda/Renderer.cuh:69-112) */
 typedef struct vrc_pool vrc_pool; /* replaces cuda::TexturePool (cuda/TexturePool.cuh:42-103) */
@@ -213,9 +214,43 @@ int vrc_post_render( vrc_ctx* ctx, float* host_rgba );
 int vrc_synchronize( vrc_ctx* ctx );
 int vrc_get_stats( vrc_ctx* ctx, vrc_stats* out );
 
+/* ---- sort-first tile exchange (multi-GPU) ------------------------------------------------------- */
+/* One process per GPU renders row bands of the frame (vrc_set_row_map); the display rank receives
+ * them over RCCL (xGMI inside a node) directly at their rows of the full frame.  This is the step
+ * eq::Compositor::assembleFrame performs for the reference's sort-first compounds
+ * (livre/eq/Channel.cpp:519-523; tiles: livre/eq/Channel.cpp:272-290) for a host without Equalizer.
+ * No brick data moves between ranks.  RCCL is bound at run time (librccl.so.1); without it every
+ * call below returns VRC_ECOMM except for a world of one rank. */
+typedef struct vrc_comm vrc_comm;
+#define VRC_COMM_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+/* ncclGetUniqueId: called by ONE rank; the caller hands the bytes to every rank (any transport) */
+int vrc_comm_unique_id( uint8_t id_out[VRC_COMM_ID_BYTES] );
+/* ncclCommInitRank on ctx's device; collective over the `world` ranks.  world == 1 needs no id
+ * (may be NULL) and no RCCL. */
+int vrc_comm_create( vrc_ctx* ctx, int rank, int world, const uint8_t id[VRC_COMM_ID_BYTES], vrc_comm** out );
+void vrc_comm_destroy( vrc_comm* comm );
+int vrc_comm_info( const vrc_comm* comm, int* rank, int* world );
+/* one row band of the frame: rows [frame_row, frame_row + rows) are rendered by `rank` */
+typedef struct
+{
+    uint32_t rank;
+    uint32_t frame_row;
+    uint32_t rows;
+} vrc_band;
+/* Collective over the communicator, asynchronous on hip_stream (NULL: ctx's render stream, i.e. behind
+ * the vrc_render calls that produced the bands).  `bands` lists every band of the frame, identical on
+ * all ranks; a rank's bands lie stacked in `local` in list order (what vrc_set_row_map renders),
+ * width x rows RGBA32F each.  On rank `root` band b lands at row bands[b].frame_row of `frame` (its
+ * own bands by device copies); `frame` is ignored elsewhere.  n_frames > 1 moves that many consecutive
+ * frames with one group of sends/receives: frame f of a rank starts local_frame_stride bytes after
+ * frame f-1 in `local`, and frame_stride bytes in `frame`. */
+int vrc_gather_tiles( vrc_ctx* ctx, vrc_comm* comm, const vrc_band* bands, uint32_t n_bands, uint32_t width,
+                      uint32_t n_frames, const void* local_device, size_t local_frame_stride,
+                      void* frame_device, size_t frame_stride, int root, void* hip_stream );
+
 const char* vrc_last_error( void );
 /* ABI version of this header */
-#define VRC_ABI_VERSION 1
+#define VRC_ABI_VERSION 2
 int vrc_abi_version( void );
 
 #ifdef __cplusplus

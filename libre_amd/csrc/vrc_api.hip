@@ -166,6 +166,14 @@ struct vrc_ctx
     vrc_stats stats = {};
 };
 
+int vrc_internal_fail( int code, const std::string& msg ) { return fail( code, msg ); }
+hipStream_t vrc_internal_ctx_stream( vrc_ctx* c, int* deviceOut )
+{
+    if( deviceOut )
+        *deviceOut = c->device;
+    return c->stream;
+}
+
 extern "C" {
 
 const char* vrc_last_error( void ) { return g_lastError.c_str(); }
@@ -389,7 +397,8 @@ int vrc_pool_create( vrc_ctx* c, size_t bytesPerVoxel, int isSigned, int isFloat
                             std::max( maxBlocks / ( p->slots[0] * p->slots[1] ), 1u ) );
     for( int a = 0; a < 3; ++a )
         p->atlasDim[a] = p->slots[a] * p->slotDim[a];
-    p->atlasBytes = (size_t)p->atlasDim[0] * p->atlasDim[1] * p->atlasDim[2] * p->elemBytes;
+    p->atlasBytes = (size_t)p->slots[0] * p->slots[1] * p->slots[2] *
+                    vrc_slot_elems( p->slotDim[0], p->slotDim[1], p->slotDim[2] ) * p->elemBytes;
     /* more than 2^32 voxels: slot bases become 64-bit (BIG kernel instances; the LDS-staged and the
      * per-ray LOD kernels, whose slot bases are 32-bit, are not offered for such a pool) */
     p->bigAtlas = p->atlasBytes / p->elemBytes >= 0xFFFFFFFFull;

@@ -130,20 +130,110 @@ struct vrc_layout
     uint32_t slotDim[3]; /* padded slot size in voxels, multiples of 8 */
 };
 
+/* ---- slot-local layout: element offset = LX(x) + LY(y) + LZ(z), one part per axis ---------------
+ * VRC_LAYOUT 0 (the product's layout): 8x8x8 micro-blocks as described above.
+ * Other values are developer experiments (tools/dev_layouts.sh): only the table-driven point-sampling
+ * kernel understands them.
+ *   1: micro-blocks 576 B apart and block rows padded to 3 mod 8 blocks: the 64-B lines of x/y
+ *      neighbour blocks fall into different 64-B phases of a 512-B period
+ *   2: row-major (x fastest), pitch slotDim.x + VRC_LAYOUT_PADX
+ *   3: 64-B lines of 32 x 2 voxels      4: 64-B lines of 16 x 4 voxels */
+#ifndef VRC_LAYOUT
+#define VRC_LAYOUT 0
+#endif
+#ifndef VRC_LAYOUT_PADX
+#define VRC_LAYOUT_PADX 0
+#endif
+struct vrc_lay
+{
+    uint32_t a, b, c; /* meaning depends on the layout */
+};
+VRC_HD vrc_lay vrc_make_lay( uint32_t sbx, uint32_t sby )
+{
+    vrc_lay l;
+#if VRC_LAYOUT == 0
+    l.a = 504u; l.b = sbx * VRC_MB_VOXELS - 64u; l.c = sbx * sby * VRC_MB_VOXELS - 512u;
+#elif VRC_LAYOUT == 1
+    const uint32_t sbxp = sbx + ( ( 3u - sbx ) & 7u );
+    l.a = 576u; l.b = 576u * sbxp; l.c = 576u * sbxp * sby;
+#elif VRC_LAYOUT == 2
+    l.a = 1u; l.b = sbx * 8u + VRC_LAYOUT_PADX; l.c = l.b * sby * 8u;
+#elif VRC_LAYOUT == 3
+    l.a = 64u; l.b = 64u * ( ( sbx * 8u + 31u ) / 32u ); l.c = l.b * sby * 4u;
+#else
+    l.a = 64u; l.b = 64u * ( ( sbx * 8u + 15u ) / 16u ); l.c = l.b * sby * 2u;
+#endif
+    return l;
+}
+VRC_HD uint32_t vrc_lay_x( const vrc_lay& l, uint32_t u )
+{
+#if VRC_LAYOUT == 0
+    return u + l.a * ( u >> 3 );
+#elif VRC_LAYOUT == 1
+    return ( u & 7u ) + l.a * ( u >> 3 );
+#elif VRC_LAYOUT == 2
+    return u;
+#elif VRC_LAYOUT == 3
+    return ( u & 31u ) + l.a * ( u >> 5 );
+#else
+    return ( u & 15u ) + l.a * ( u >> 4 );
+#endif
+}
+VRC_HD uint32_t vrc_lay_y( const vrc_lay& l, uint32_t u )
+{
+#if VRC_LAYOUT == 0
+    return 8u * u + l.b * ( u >> 3 );
+#elif VRC_LAYOUT == 1
+    return 8u * ( u & 7u ) + l.b * ( u >> 3 );
+#elif VRC_LAYOUT == 2
+    return l.b * u;
+#elif VRC_LAYOUT == 3
+    return 32u * ( u & 1u ) + l.b * ( u >> 1 );
+#else
+    return 16u * ( u & 3u ) + l.b * ( u >> 2 );
+#endif
+}
+VRC_HD uint32_t vrc_lay_z( const vrc_lay& l, uint32_t u )
+{
+#if VRC_LAYOUT == 0
+    return 64u * u + l.c * ( u >> 3 );
+#elif VRC_LAYOUT == 1
+    return 64u * ( u & 7u ) + l.c * ( u >> 3 );
+#else
+    return l.c * u;
+#endif
+}
+/* physical elements of one slot */
+VRC_HD uint64_t vrc_slot_elems( uint32_t sdx, uint32_t sdy, uint32_t sdz )
+{
+#if VRC_LAYOUT == 0
+    return (uint64_t)sdx * sdy * sdz;
+#elif VRC_LAYOUT == 1
+    return (uint64_t)vrc_make_lay( sdx >> 3, sdy >> 3 ).c * ( sdz >> 3 );
+#else
+    return (uint64_t)vrc_make_lay( sdx >> 3, sdy >> 3 ).c * sdz;
+#endif
+}
+
 /* element offset of voxel (x,y,z), local to a slot of sbx x sby x * micro-blocks */
 VRC_HD uint32_t vrc_slot_local_index( uint32_t x, uint32_t y, uint32_t z, uint32_t sbx, uint32_t sby )
 {
+#if VRC_LAYOUT == 0
     const uint32_t blk = ( ( z >> VRC_MB_SHIFT ) * sby + ( y >> VRC_MB_SHIFT ) ) * sbx +
                          ( x >> VRC_MB_SHIFT );
     const uint32_t inner = ( ( z & 7u ) << 6 ) | ( ( y & 7u ) << 3 ) | ( x & 7u );
     return blk * VRC_MB_VOXELS + inner;
+#else
+    const vrc_lay l = vrc_make_lay( sbx, sby );
+    return vrc_lay_x( l, x ) + vrc_lay_y( l, y ) + vrc_lay_z( l, z );
+#endif
 }
 
 /* element offset of slot (i,j,k): 64 bits, an atlas may hold more than 2^32 voxels (it is sized
  * for the GPU's memory, not for a 32-bit index; the reference truncates, quirk Q12) */
 VRC_HD uint64_t vrc_slot_base( const vrc_layout& l, uint32_t i, uint32_t j, uint32_t k )
 {
-    const uint64_t slotVoxels = (uint64_t)l.slotDim[0] * l.slotDim[1] * l.slotDim[2];
+    const uint64_t slotVoxels = vrc_slot_elems( l.slotDim[0], l.slotDim[1], l.slotDim[2] );
     return ( ( (uint64_t)k * l.slots[1] + j ) * l.slots[0] + i ) * slotVoxels;
 }
 
@@ -1054,49 +1144,83 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
             tMax[a] = ( boundary - o[a] ) * id[a];
             tDelta[a] = f.cellSize[a] * fabsf( id[a] );
         }
-        int32_t lastNode = -1;
+        /* nodes already handed to the slab test (a brick is convex: once left it is never entered
+         * again, but a tie probe below, or a coarse brick that spans several cells, meets it twice) */
+        int32_t recent[4] = { -1, -1, -1, -1 };
         const int maxSteps = f.gridDim[0] + f.gridDim[1] + f.gridDim[2] + 3;
-        for( int it = 0; it < maxSteps; ++it )
-        {
-            const int32_t node =
-                gridTable[( cell[2] * f.gridDim[1] + cell[1] ) * f.gridDim[0] + cell[0]];
-            if( node >= 0 && node != lastNode )
+        bool finished = false;
+        /* slab test + march of the brick of one cell (at most once per brick) */
+        auto visit = [&]( int cx, int cy, int cz ) {
+            if( cx < 0 || cx >= f.gridDim[0] || cy < 0 || cy >= f.gridDim[1] || cz < 0 || cz >= f.gridDim[2] )
+                return;
+            const int32_t node = gridTable[( cz * f.gridDim[1] + cy ) * f.gridDim[0] + cx];
+            if( node < 0 || node == recent[0] || node == recent[1] || node == recent[2] || node == recent[3] )
+                return;
+            recent[3] = recent[2];
+            recent[2] = recent[1];
+            recent[1] = recent[0];
+            recent[0] = node;
+            const vrc_dev_node n = nodes[node];
+            vrc_segment s;
+            bool stop;
+            if( vrc_brick_segment( f, r, n, f.stepSize, &s, &stop ) )
             {
-                lastNode = node;
-                const vrc_dev_node n = nodes[node];
-                vrc_segment s;
-                bool stop;
-                if( vrc_brick_segment( f, r, n, f.stepSize, &s, &stop ) )
-                {
-                    if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >( f, n, s, atlas, lut,
-                                                                                 cls, color, nSamples ) )
-                        break;
-                }
-                else if( stop )
-                    break;
+                if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >( f, n, s, atlas, lut, cls,
+                                                                             color, nSamples ) )
+                    finished = true;
             }
-            /* advance to the next cell along the ray */
+            else if( stop )
+                finished = true;
+        };
+        for( int it = 0; it < maxSteps && !finished; ++it )
+        {
+            visit( cell[0], cell[1], cell[2] );
+            /* Where the ray leaves the cell through an edge or a corner of the grid (two or three of the
+             * exit parameters equal to within rounding) it also touches the cells around that edge or
+             * corner.  In exact arithmetic it has no extent in those; the reference tests every brick
+             * with its float slab test (Renderer.cu:56-80, :179-181), and one that comes out with tfar a
+             * last bit above tnear gets its one sample (:208).  Testing the same cells with the same
+             * arithmetic reproduces that, instead of depending on which of the tied faces this walk
+             * happens to take first: the walk then composites the reference's samples, one for one. */
             const float tNext = fminf( fminf( tMax[0], tMax[1] ), tMax[2] );
-            if( tNext > t1 )
+            const float tol = fabsf( tNext ) * 2e-6f;
+            const bool tie0 = tMax[0] <= tNext + tol, tie1 = tMax[1] <= tNext + tol, tie2 = tMax[2] <= tNext + tol;
+            const bool leaves = tNext > t1; /* the ray ends inside this cell */
+            if( !finished && !leaves && ( (int)tie0 + (int)tie1 + (int)tie2 ) > 1 )
+            {
+                const int sx = tie0 ? stepDir[0] : 0, sy = tie1 ? stepDir[1] : 0, sz = tie2 ? stepDir[2] : 0;
+                /* proper subsets of the tied axes: single faces first, then (three-way tie) the pairs */
+                if( tie0 && !finished ) visit( cell[0] + sx, cell[1], cell[2] );
+                if( tie1 && !finished ) visit( cell[0], cell[1] + sy, cell[2] );
+                if( tie2 && !finished ) visit( cell[0], cell[1], cell[2] + sz );
+                if( tie0 && tie1 && tie2 )
+                {
+                    if( !finished ) visit( cell[0] + sx, cell[1] + sy, cell[2] );
+                    if( !finished ) visit( cell[0] + sx, cell[1], cell[2] + sz );
+                    if( !finished ) visit( cell[0], cell[1] + sy, cell[2] + sz );
+                }
+            }
+            if( finished || leaves )
                 break;
-            if( tMax[0] <= tMax[1] && tMax[0] <= tMax[2] )
+            /* advance through every tied face at once */
+            if( tie0 )
             {
                 cell[0] += stepDir[0];
                 tMax[0] += tDelta[0];
-                if( cell[0] < 0 || cell[0] >= f.gridDim[0] ) break;
             }
-            else if( tMax[1] <= tMax[2] )
+            if( tie1 )
             {
                 cell[1] += stepDir[1];
                 tMax[1] += tDelta[1];
-                if( cell[1] < 0 || cell[1] >= f.gridDim[1] ) break;
             }
-            else
+            if( tie2 )
             {
                 cell[2] += stepDir[2];
                 tMax[2] += tDelta[2];
-                if( cell[2] < 0 || cell[2] >= f.gridDim[2] ) break;
             }
+            if( cell[0] < 0 || cell[0] >= f.gridDim[0] || cell[1] < 0 || cell[1] >= f.gridDim[1] ||
+                cell[2] < 0 || cell[2] >= f.gridDim[2] )
+                break;
         }
     }
     pixelBuffer[pixelPos] = color;

@@ -75,4 +75,10 @@ hipError_t vrc_launch_raycast_lds( const vrc_raycast_args& a, hipStream_t stream
  * padded transfer function */
 hipError_t vrc_launch_raycast_raylod( const vrc_raycast_args& a, hipStream_t stream );
 
+/* shared by the translation units of libvrc_hip.so (vrc_api.hip owns the state) */
+#include <string>
+struct vrc_ctx;
+int vrc_internal_fail( int code, const std::string& msg );          /* sets vrc_last_error, returns code */
+hipStream_t vrc_internal_ctx_stream( vrc_ctx* ctx, int* deviceOut ); /* the context's render stream + device */
+
 #endif

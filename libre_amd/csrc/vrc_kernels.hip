@@ -421,16 +421,16 @@ __global__ __launch_bounds__( VRC_WG_THREADS, GROUP > 8 ? 2 : VRC_MIN_WAVES ) vo
 #if defined( VRC_ADDR_TABLES )
     if( FIXED )
     {
-        const uint32_t cyy = f.sbx * VRC_MB_VOXELS - 64u, czz = f.sbx * f.sby * VRC_MB_VOXELS - 512u;
+        const vrc_lay lay = vrc_make_lay( f.sbx, f.sby );
 #pragma unroll
         for( uint32_t i = 0; i < ( 256u + VRC_WG_THREADS - 1u ) / VRC_WG_THREADS; ++i )
         {
-            const uint32_t u = tid + i * VRC_WG_THREADS, q = u >> VRC_MB_SHIFT;
+            const uint32_t u = tid + i * VRC_WG_THREADS;
             if( u < 256u )
             {
-                vrc_addr_tab[u] = u + 504u * q;
-                vrc_addr_tab[256u + u] = 8u * u + cyy * q;
-                vrc_addr_tab[512u + u] = 64u * u + czz * q;
+                vrc_addr_tab[u] = vrc_lay_x( lay, u );
+                vrc_addr_tab[256u + u] = vrc_lay_y( lay, u );
+                vrc_addr_tab[512u + u] = vrc_lay_z( lay, u );
             }
         }
     }

@@ -239,14 +239,18 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
 
     /* ---- per-lane segment state ---------------------------------------------------------- */
     bool hasSeg = false;
-    int32_t curNode = -1, lastNode = -1;
+    int32_t curNode = -1;
+    /* bricks already handed to the slab test; probe: what the walk does next at its cell (0: the cell
+     * itself, 1..6: the cells around an edge / corner the ray leaves through, see vrc_pixel_grid_dda) */
+    int32_t recent0 = -1, recent1 = -1, recent2 = -1, recent3 = -1;
+    int probe = 0;
     uint32_t fx = 0, fy = 0, fz = 0, fdx = 0, fdy = 0, fdz = 0; /* 8.24 slot-local voxel */
     float travel = 0.0f;
     uint32_t laneSlotBase = 0;
     uint32_t nSamples = 0;
     const float stepSize = f.stepSize;
     const float invStep = 1.0f / stepSize;
-    int budget = 4 * ( f.gridDim[0] + f.gridDim[1] + f.gridDim[2] + 3 ); /* exit guarantee */
+    int budget = 8 * ( f.gridDim[0] + f.gridDim[1] + f.gridDim[2] + 3 ); /* exit guarantee */
 
     /* staging role of the lane: 4 row-pairs across (x), 16 down (y) per z-slice */
     const uint32_t sxr = lane & 3u, syp = lane >> 2;
@@ -280,11 +284,32 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
                     done = true;
                 else
                 {
-                    const int32_t node =
-                        gridTable[( cell[2] * f.gridDim[1] + cell[1] ) * f.gridDim[0] + cell[0]];
-                    if( node >= 0 && node != lastNode )
+                    /* the same walk as vrc_pixel_grid_dda (vrc_core.h), one cell per iteration: the cell,
+                     * then -- where the ray leaves it through an edge or corner of the grid -- the cells
+                     * around that edge or corner, then the step through every tied face */
+                    const float tNext = fminf( fminf( tMax[0], tMax[1] ), tMax[2] );
+                    const float tol = fabsf( tNext ) * 2e-6f;
+                    const bool tie0 = tMax[0] <= tNext + tol, tie1 = tMax[1] <= tNext + tol,
+                               tie2 = tMax[2] <= tNext + tol;
+                    const int tied = ( tie0 ? 1 : 0 ) | ( tie1 ? 2 : 0 ) | ( tie2 ? 4 : 0 );
+                    const bool leaves = tNext > t1;
+                    const bool multi = !leaves && ( tied & ( tied - 1 ) ) != 0;
+                    const int sub = probe == 0 ? 0
+                                               : ( probe < 4 ? ( 1 << ( probe - 1 ) )
+                                                             : ( probe == 4 ? 3 : ( probe == 5 ? 5 : 6 ) ) );
+                    const int cx = cell[0] + ( ( sub & 1 ) ? stepDir[0] : 0 );
+                    const int cy = cell[1] + ( ( sub & 2 ) ? stepDir[1] : 0 );
+                    const int cz = cell[2] + ( ( sub & 4 ) ? stepDir[2] : 0 );
+                    const bool look = ( probe == 0 || ( multi && ( sub & ~tied ) == 0 && sub != tied ) ) && cx >= 0 &&
+                                      cx < f.gridDim[0] && cy >= 0 && cy < f.gridDim[1] && cz >= 0 &&
+                                      cz < f.gridDim[2];
+                    const int32_t node = look ? gridTable[( cz * f.gridDim[1] + cy ) * f.gridDim[0] + cx] : -1;
+                    if( node >= 0 && node != recent0 && node != recent1 && node != recent2 && node != recent3 )
                     {
-                        lastNode = node;
+                        recent3 = recent2;
+                        recent2 = recent1;
+                        recent1 = recent0;
+                        recent0 = node;
                         const vrc_dev_node n = nodes[node];
                         vrc_segment s;
                         bool stop;
@@ -312,28 +337,31 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
                         else if( stop )
                             done = true;
                     }
-                    if( !done )
+                    ++probe;
+                    if( !done && ( probe > 6 || !multi ) )
                     {
-                        const float tNext = fminf( fminf( tMax[0], tMax[1] ), tMax[2] );
-                        if( tNext > t1 )
+                        probe = 0;
+                        if( leaves )
                             ddaEnd = true;
-                        else if( tMax[0] <= tMax[1] && tMax[0] <= tMax[2] )
-                        {
-                            cell[0] += stepDir[0];
-                            tMax[0] += tDelta[0];
-                            ddaEnd = cell[0] < 0 || cell[0] >= f.gridDim[0];
-                        }
-                        else if( tMax[1] <= tMax[2] )
-                        {
-                            cell[1] += stepDir[1];
-                            tMax[1] += tDelta[1];
-                            ddaEnd = cell[1] < 0 || cell[1] >= f.gridDim[1];
-                        }
                         else
                         {
-                            cell[2] += stepDir[2];
-                            tMax[2] += tDelta[2];
-                            ddaEnd = cell[2] < 0 || cell[2] >= f.gridDim[2];
+                            if( tie0 )
+                            {
+                                cell[0] += stepDir[0];
+                                tMax[0] += tDelta[0];
+                            }
+                            if( tie1 )
+                            {
+                                cell[1] += stepDir[1];
+                                tMax[1] += tDelta[1];
+                            }
+                            if( tie2 )
+                            {
+                                cell[2] += stepDir[2];
+                                tMax[2] += tDelta[2];
+                            }
+                            ddaEnd = cell[0] < 0 || cell[0] >= f.gridDim[0] || cell[1] < 0 ||
+                                     cell[1] >= f.gridDim[1] || cell[2] < 0 || cell[2] >= f.gridDim[2];
                         }
                     }
                 }

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvrc_hip.so")
 
-VRC_OK, VRC_EINVAL, VRC_EHIP, VRC_EFULL, VRC_ENOMEM, VRC_EUNSUPPORTED, VRC_EHIERARCHY = range(7)
+VRC_OK, VRC_EINVAL, VRC_EHIP, VRC_EFULL, VRC_ENOMEM, VRC_EUNSUPPORTED, VRC_EHIERARCHY, VRC_ECOMM = range(8)
 OPT_KERNEL, OPT_FILTER, OPT_TF_FRAC_BITS, OPT_COUNT_SAMPLES, OPT_TILE_ORDER, OPT_STEPPING, OPT_VARIANT, OPT_KERNEL_USED = range(1, 9)
 VARIANT_CUDARAYCASTER, VARIANT_GLRAYCASTER = 0, 1
 FILTER_NEAREST, FILTER_TRILINEAR = 0, 1
@@ -57,7 +57,14 @@ EXPORTS = [
     "vrc_pool_histogram",
     "vrc_update", "vrc_pre_render", "vrc_set_row_map", "vrc_set_framebuffer", "vrc_get_framebuffer", "vrc_render",
     "vrc_post_render", "vrc_synchronize", "vrc_get_stats", "vrc_last_error", "vrc_abi_version",
+    "vrc_comm_unique_id", "vrc_comm_create", "vrc_comm_destroy", "vrc_comm_info", "vrc_gather_tiles",
 ]
+COMM_ID_BYTES = 128
+
+
+class Band(C.Structure):  # vrc_band
+    _fields_ = [("rank", C.c_uint32), ("frame_row", C.c_uint32), ("rows", C.c_uint32)]
+
 
 _lib = None
 
@@ -105,6 +112,13 @@ def load_library(path=None):
     L.vrc_post_render.argtypes = [vp, vp]
     L.vrc_synchronize.argtypes = [vp]
     L.vrc_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.vrc_comm_unique_id.argtypes = [C.c_char_p]
+    L.vrc_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]
+    L.vrc_comm_destroy.argtypes = [vp]
+    L.vrc_comm_destroy.restype = None
+    L.vrc_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.vrc_gather_tiles.argtypes = [vp, vp, C.POINTER(Band), C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t,
+                                   vp, C.c_size_t, C.c_int, vp]
     if path is None:
         _lib = L
     return L

@@ -644,6 +644,55 @@ typedef struct
     const struct lod_grid* lod; /* rayLod only */
 } job_t;
 
+/* TEST INSTRUMENT (orc_options.tieBudget), not part of the restated algorithm: the largest change of a
+ * pixel channel if this point sample read the voxel across a face it lies within tieDelta voxels of.
+ * transmittance = 1 - accumulated alpha before the sample. */
+static float tie_budget( const job_t* j, f3 texPos, float density, float multiplyer, float addedValue,
+                         float alphaCorrection, float transmittance )
+{
+    const float c[3] = { texPos.x * (float)j->atlasDim[0], texPos.y * (float)j->atlasDim[1],
+                         texPos.z * (float)j->atlasDim[2] };
+    int idx[3], off[3] = { 0, 0, 0 }, any = 0;
+    for( int a = 0; a < 3; ++a )
+    {
+        const float fl = floorf( c[a] );
+        const float fr = c[a] - fl;
+        idx[a] = tex_index( a == 0 ? texPos.x : a == 1 ? texPos.y : texPos.z, j->atlasDim[a] );
+        if( fr < j->opt.tieDelta && idx[a] > 0 )
+            off[a] = -1;
+        else if( fr > 1.0f - j->opt.tieDelta && idx[a] < (int)j->atlasDim[a] - 1 )
+            off[a] = 1;
+        any |= off[a] != 0;
+    }
+    if( !any )
+        return 0.0f;
+    float tfn[4], here[4] = { 0, 0, 0, 0 }, worst = 0.0f;
+    orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, tfn );
+    orc_composite( tfn, here, alphaCorrection ); /* (rgb*alpha', alpha') of this sample */
+    /* every combination of the near faces (a sample near an edge or a corner) */
+    for( int m = 1; m < 8; ++m )
+    {
+        int q[3], ok = 1;
+        for( int a = 0; a < 3; ++a )
+        {
+            const int use = ( m >> a ) & 1;
+            if( use && off[a] == 0 )
+                ok = 0;
+            q[a] = idx[a] + ( use ? off[a] : 0 );
+        }
+        if( !ok )
+            continue;
+        const float d2 = texel( j->atlas, j->opt.voxelBytes,
+                                ( (size_t)q[2] * j->atlasDim[1] + (size_t)q[1] ) * j->atlasDim[0] + (size_t)q[0] );
+        float there[4] = { 0, 0, 0, 0 };
+        orc_tf_fetch( j->tf, d2 * multiplyer + addedValue, j->opt.tfFracBits, tfn );
+        orc_composite( tfn, there, alphaCorrection );
+        for( int k = 0; k < 4; ++k )
+            worst = fmaxf( worst, fabsf( there[k] - here[k] ) );
+    }
+    return worst * transmittance;
+}
+
 /* one pixel: Renderer.cu:106-229 */
 static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
 {
@@ -749,6 +798,9 @@ static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
                                       ? fetch_trilinear( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos )
                                       : fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
             float transferFn[4];
+            if( j->opt.tieBudget && !j->opt.filter ) /* test instrument, see orc_options */
+                j->opt.tieBudget[pixelPos] += tie_budget( j, texPos, density, multiplyer, addedValue,
+                                                          alphaCorrection, 1.0f - color[3] );
             orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, transferFn );
             orc_composite( transferFn, color, alphaCorrection );
             ++nSamples;
@@ -880,6 +932,9 @@ static uint64_t raycast_pixel_gl( const job_t* j, uint32_t x, uint32_t y )
                                       ? fetch_trilinear( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos )
                                       : fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
             float transferFn[4];
+            if( j->opt.tieBudget && !j->opt.filter ) /* test instrument, see orc_options */
+                j->opt.tieBudget[pixelPos] += tie_budget( j, texPos, density, multiplyer, addedValue,
+                                                          alphaCorrection, 1.0f - color[3] );
             orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, transferFn );
             orc_composite( transferFn, color, alphaCorrection );
             ++nSamples;
@@ -1055,7 +1110,7 @@ static lod_grid* lod_grid_build( const orc_node_data* nodes, uint32_t n, const u
 
 /* integrate one run [tA, tB] of the ray through one brick; returns 1 on early exit */
 static int integrate_run( const job_t* j, const orc_node_data* nodeData, int level, f3 origin, f3 dir,
-                          float tA, float tB, float color[4], uint64_t* nSamples )
+                          float tA, float tB, float color[4], uint64_t* nSamples, size_t pixelPos )
 {
     const orc_render_data* renderData = j->render;
     const float r0 = renderData->dataSourceRange[0], r1 = renderData->dataSourceRange[1];
@@ -1090,6 +1145,9 @@ static int integrate_run( const job_t* j, const orc_node_data* nodeData, int lev
                                   ? fetch_trilinear( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos )
                                   : fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
         float transferFn[4];
+        if( j->opt.tieBudget && !j->opt.filter ) /* test instrument, see orc_options */
+            j->opt.tieBudget[pixelPos] += tie_budget( j, texPos, density, multiplyer, addedValue,
+                                                      alphaCorrection, 1.0f - color[3] );
         orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, transferFn );
         orc_composite( transferFn, color, alphaCorrection );
         ++*nSamples;
@@ -1206,7 +1264,8 @@ static uint64_t raycast_pixel_ray_lod( const job_t* j, uint32_t x, uint32_t y )
             tX = fminf( tX, ( ( d[2] > 0.0f ? bmax[2] : bmin[2] ) - o[2] ) * invD[2] );
             const float tB = fminf( fmaxf( tX, tp ), t1 ); /* always forward */
             if( node >= 0 &&
-                integrate_run( j, &j->nodes[node], g->level[node], origin, dir, tp, tB, color, &nSamples ) )
+                integrate_run( j, &j->nodes[node], g->level[node], origin, dir, tp, tB, color, &nSamples,
+                               (size_t)y * j->width + x ) )
                 break;
             te = tB;
         }
@@ -1278,6 +1337,8 @@ uint64_t orc_raycast( const uint8_t* atlas, const uint32_t atlasDim[3], float* p
         job.opt.variant = 0;
         job.opt.rayLod = 0;
         job.opt.lodScreenSpaceError = job.opt.lodWorldSpacePerPixel = 0.f;
+        job.opt.tieBudget = NULL;
+        job.opt.tieDelta = 0.f;
     }
     job.lod = NULL;
     lod_grid* lodGrid = NULL;

@@ -100,6 +100,16 @@ typedef struct
                       * list is a hierarchy of bricks; the criterion of SelectVisibles.cpp:52-68 is
                       * applied along the ray instead of per brick (raycast_pixel_ray_lod) */
     float lodScreenSpaceError, lodWorldSpacePerPixel; /* SelectVisibles.cpp:57-67 */
+    /* TEST INSTRUMENT, not part of the restated algorithm (NULL = off): width*height floats that receive,
+     * per pixel, how much the pixel can change if samples that lie within tieDelta voxels of a voxel face
+     * read the voxel on the other side of that face:
+     *     sum over such samples of max_channel |classified(neighbour) - classified(voxel)| * transmittance.
+     * The reference puts the first sample of every brick exactly ON a brick face (= a voxel face,
+     * Renderer.cu:195-196), so which voxel it reads hangs on the last bit of the coordinate arithmetic;
+     * an implementation that evaluates the coordinate by another (equally valid) float expression
+     * differs from this oracle by at most E0 + 2 * tieBudget per pixel (tests/scenes.py). */
+    float* tieBudget;
+    float tieDelta;
 } orc_options;
 
 /* ---- NodeId: livre/core/data/NodeId.h:38-49, livre/core/types.h:191-195, mathTypes.h:82 */

@@ -9,8 +9,8 @@ from libre_amd import vrc
 class GpuScene:
     """Uploads a Scene's bricks through vrc_pool_copy_to_slot and renders it."""
 
-    def __init__(self, s, device=0):
-        self.L = L = vrc.load_library()
+    def __init__(self, s, device=0, lib=None):
+        self.L = L = lib if lib is not None else vrc.load_library()  # lib: a developer A/B build
         self.s = s
         self.ctx = C.c_void_p()
         vrc.check(L, L.vrc_ctx_create(device, C.byref(self.ctx)))

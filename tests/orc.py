@@ -7,6 +7,7 @@ sorting, view data), so the parity tests feed the HIP path and the oracle the sa
 import ctypes as C
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -54,7 +55,8 @@ class Options(C.Structure):
     _fields_ = [("tfFracBits", C.c_int), ("filter", C.c_int), ("nThreads", C.c_int),
                 ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32), ("rowStride", C.c_uint32),
                 ("voxelBytes", C.c_int), ("variant", C.c_int), ("rayLod", C.c_int),
-                ("lodScreenSpaceError", C.c_float), ("lodWorldSpacePerPixel", C.c_float)]
+                ("lodScreenSpaceError", C.c_float), ("lodWorldSpacePerPixel", C.c_float),
+                ("tieBudget", C.c_void_p), ("tieDelta", C.c_float)]
 
 
 def build_oracle():
@@ -232,21 +234,33 @@ def default_mv(spin=(0.0, 0.0), eye=(0.0, 0.0, 1.5)):
     return m
 
 
-def hash_volume(vx, vy, vz, seed=0x5EED):
-    """'Volume N' of SURVEY 8d: v = hash32(x + vx*(y + vy*z) + seed) >> 24, then a 3-tap box
-    filter per axis.  Deterministic, build-defined (not a reference input)."""
-    idx = np.arange(vx * vy * vz, dtype=np.uint64).reshape(vz, vy, vx)
-    h = (idx + np.uint64(seed)) & np.uint64(0xFFFFFFFF)
-    h = h.astype(np.uint32)
+def _hash_raw(vx, vy, zs, seed):
+    """lowbias32(x + vx*(y + vy*z) + seed) >> 24 as float32 for the z slices zs."""
+    plane = np.arange(vx * vy, dtype=np.uint64).reshape(1, vy, vx)
+    idx = plane + (np.asarray(zs, dtype=np.uint64) * np.uint64(vx * vy)).reshape(-1, 1, 1)
+    h = ((idx + np.uint64(seed)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     h ^= h >> np.uint32(16)
     h *= np.uint32(0x7FEB352D)
     h ^= h >> np.uint32(15)
     h *= np.uint32(0x846CA68B)
     h ^= h >> np.uint32(16)
-    v = (h >> np.uint32(24)).astype(np.float32)
-    for ax in range(3):
-        v = (np.roll(v, 1, axis=ax) + v + np.roll(v, -1, axis=ax)) / 3.0
-    return np.clip(np.floor(v), 0, 255).astype(np.uint8)
+    return (h >> np.uint32(24)).astype(np.float32)
+
+
+def hash_volume(vx, vy, vz, seed=0x5EED, slab=16):
+    """'Volume N' of SURVEY 8d: v = hash32(x + vx*(y + vy*z) + seed) >> 24, then a 3-tap box
+    filter per axis (z, then y, then x; periodic; ((prev + cur) + next) / 3 in float32).
+    Deterministic, build-defined (not a reference input).  Computed slab by slab in z so that the
+    1024^3 volume of BASELINE C2 needs no more than its own gigabyte."""
+    out = np.empty((vz, vy, vx), dtype=np.uint8)
+    for z0 in range(0, vz, slab):
+        z1 = min(vz, z0 + slab)
+        raw = _hash_raw(vx, vy, [(z % vz) for z in range(z0 - 1, z1 + 1)], seed)
+        v = (raw[:-2] + raw[1:-1] + raw[2:]) / np.float32(3.0)
+        for ax in (1, 2):
+            v = (np.roll(v, 1, axis=ax) + v + np.roll(v, -1, axis=ax)) / np.float32(3.0)
+        out[z0:z1] = np.clip(np.floor(v), 0, 255).astype(np.uint8)
+    return out
 
 
 def brick_from_volume(vol, vi, node):
@@ -374,19 +388,41 @@ def build_scene(voxels=(64, 64, 64), block=16, viewport=(64, 64), spr=0, alpha=0
     return s
 
 
+def with_viewport(s, W, H):
+    """The same scene (volume, atlas, bricks, camera) seen through another viewport."""
+    import copy
+    t = copy.copy(s)
+    t.W, t.H = W, H
+    t.view = ViewData()
+    lib().orc_make_view_data(s.mv, s.proj, (C.c_uint32 * 4)(0, 0, W, H), C.byref(s.vi), C.byref(t.view))
+    return t
+
+
 def world_space_per_pixel(s, top=0.05, bottom=-0.05):
     """SelectVisibles.cpp:55-57: (frustum.top - frustum.bottom) / window height, for default_proj."""
     return (top - bottom) / float(s.H)
 
 
-def oracle_render(s, frac_bits=8, threads=8, rows=None, fb=None, filter_mode=0, variant=0, ray_lod=None):
-    """Run the oracle integrator on a scene. Returns (rgba[H,W,4], samples).
+#: samples within this many voxels of a voxel face count towards a pixel's tie budget (orc_options.tieBudget)
+TIE_DELTA = 2.0 ** -10
+
+
+def oracle_render(s, frac_bits=8, threads=8, rows=None, fb=None, filter_mode=0, variant=0, ray_lod=None,
+                  budget=False):
+    """Run the oracle integrator on a scene. Returns (rgba[H,W,4], samples), with budget=True
+    (rgba, samples, tie_budget[H,W]) (orc_options.tieBudget, the per-pixel part of the parity tolerance).
     ray_lod = (screenSpaceError, worldSpacePerPixel): per-ray adaptive LOD over a node hierarchy."""
+    global _LAST_SCENE
+    _LAST_SCENE = s
     L = lib()
     if fb is None:
         fb = np.zeros((s.H, s.W, 4), dtype=np.float32)
+    first_pass = not fb.any()  # a frame that accumulates over passes keeps adding to its budget
+    prev = budget_of(fb)
+    tb = prev if (prev is not None and not first_pass) else np.zeros((s.H, s.W), dtype=np.float32)
     opt = Options(frac_bits, filter_mode, threads, 0, s.H, 1, s.atlas.dtype.itemsize, variant,
-                  1 if ray_lod else 0, ray_lod[0] if ray_lod else 0.0, ray_lod[1] if ray_lod else 0.0)
+                  1 if ray_lod else 0, ray_lod[0] if ray_lod else 0.0, ray_lod[1] if ray_lod else 0.0,
+                  tb.ctypes.data, TIE_DELTA)
     if rows is not None:
         opt.rowBegin, opt.rowEnd, opt.rowStride = rows
     n = L.orc_raycast(s.atlas.ctypes.data, u32x3(*s.atlas_dim), fb.ctypes.data, s.W, s.H,
@@ -395,7 +431,11 @@ def oracle_render(s, frac_bits=8, threads=8, rows=None, fb=None, filter_mode=0, 
                       C.byref(opt))
     if int(n) == 2 ** 64 - 1:
         raise RuntimeError("orc_raycast: the node list is not a brick hierarchy")
-    return fb, int(n)
+    if len(_BUDGETS) > 64:  # frames that are gone
+        for k in [k for k, v in _BUDGETS.items() if v[0]() is None]:
+            del _BUDGETS[k]
+    _BUDGETS[fb.__array_interface__["data"][0]] = (weakref.ref(fb), tb)
+    return (fb, int(n), tb) if budget else (fb, int(n))
 
 
 def harness_render(s, kernel=2, frac_bits=8, fb=None, sanitize=False, pixel_off=(0, 0), variant=0):
@@ -449,10 +489,71 @@ def all_level_ids(vi, levels=None):
     return ids
 
 
+#: the scene of the last oracle_render call: compare() takes the frame's largest single-sample weight from it
+_LAST_SCENE = None
+#: with VRC_PARITY_STATS=<file> every comparison is appended to <file> as one JSON line (profiles/*_parity_errors.json)
+_STATS_FILE = os.environ.get("VRC_PARITY_STATS")
+#: tie budgets of the frames oracle_render returned, by the address of the frame's memory
+_BUDGETS = {}
+
+
+def flip_weight(s, level_scale=1.0):
+    """Largest change one sample can make to a channel of a pixel: the largest classified alpha,
+    1 - (1 - min(a, 255/256))^(maxSamplesPerRay / samplesPerRay) (cuda/Renderer.cu:88-89, 167-168); colours
+    are <= 1."""
+    a = np.minimum(np.asarray(s.tf, dtype=np.float64).reshape(-1, 4)[:, 3], 255.0 / 256.0)
+    k = float(s.render.maxSamplesPerRay) / float(s.render.samplesPerRay) * level_scale
+    return float((1.0 - (1.0 - a) ** k).max())
+
+
+def budget_of(frame):
+    """The tie budget (orc_options.tieBudget) of an oracle frame or of a row/column slice of one
+    (frame[::64], frame[a:b]); None if `frame` did not come from oracle_render."""
+    base = frame
+    while isinstance(base, np.ndarray) and base.base is not None:
+        base = base.base
+    ent = _BUDGETS.get(base.__array_interface__["data"][0]) if isinstance(base, np.ndarray) else None
+    if ent is None or ent[0]() is not base:
+        return None
+    tb = ent[1]
+    if frame is base:
+        return tb
+    # the same rows / columns of the budget as the view takes of the frame
+    off = frame.__array_interface__["data"][0] - base.__array_interface__["data"][0]
+    r0, rem = divmod(off, base.strides[0])
+    c0 = rem // base.strides[1]
+    rs, cs = frame.strides[0] // base.strides[0], frame.strides[1] // base.strides[1]
+    out = tb[r0::rs, c0::cs][:frame.shape[0], :frame.shape[1]]
+    assert out.shape == frame.shape[:2], (out.shape, frame.shape)
+    return out
+
+
 def compare(a, b):
     """(max-abs, mean-abs, fraction of pixels with any channel over 2e-3)."""
     d = np.abs(a.astype(np.float64) - b.astype(np.float64))
     over = (d.max(axis=-1) > 2e-3).mean()
+    if _STATS_FILE:
+        import inspect
+        import json
+        pix = d.max(axis=-1)
+        small = pix <= 1e-4
+        fr = inspect.stack()
+        who = next((f.function for f in fr[1:] if f.function.startswith("test_")), fr[1].function)
+        tb = budget_of(b)
+        if tb is None:
+            tb = budget_of(a)
+        rec = dict(test=who, case=os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0],
+                   shape=list(a.shape[:2]), max=float(d.max()), mean=float(d.mean()),
+                   frac_over_1e4=float(1.0 - small.mean()), frac_over_2e3=float(over),
+                   flip_weight=flip_weight(_LAST_SCENE) if _LAST_SCENE is not None else None)
+        if tb is not None:
+            ex = pix - 2.0 * tb
+            rec.update(budget_mean=float(tb.mean()), budget_max=float(tb.max()),
+                       excess_max=float(ex.max()), n_excess_over_1e5=int((ex > 1e-5).sum()),
+                       n_excess_over_2e5=int((ex > 2e-5).sum()), n_excess_over_1e4=int((ex > 1e-4).sum()),
+                       n_excess_over_2e4=int((ex > 2e-4).sum()), n_pixels=int(pix.size))
+        with open(_STATS_FILE, "a") as f:
+            f.write(json.dumps(rec) + "\n")
     return float(d.max()), float(d.mean()), float(over)
 
 

@@ -7,22 +7,40 @@ import numpy as np
 
 import orc
 
-# tolerance of the parity contract: per-channel max-abs <= 2e-3, mean-abs
-# <= 5e-5 on RGBA in [0,1], at most 0.1 % of pixels over 2e-3.  The residual comes from
-# (a) brick slivers the DDA steps over (<= 1 sample per brick crossing), (b) nearest-voxel
-# flips for samples within ~1e-4 voxel of a voxel face, (c) FMA contraction on the GPU.
-# VRC_FUZZ_SCALE=n multiplies the number of seeds of every randomized test (soak runs)
+# ---- THE tolerance of the parity contract: one rule for every comparison with the oracle ----------------
+# RGBA float32 in [0,1].  For every pixel and channel
+#
+#       |frame - oracle|  <=  E0 + TIE_FACTOR * B(pixel)
+#
+# E0 = 5e-5 covers float evaluation order: the device contracts the multiply-adds of the blend and of the
+# sample-position chain, evaluates voxel coordinates brick-locally (a finer float grid than the reference's
+# normalized atlas coordinate) and, in the per-sample classification modes, uses v_log_f32 / v_exp_f32.
+# Measured on MI355X: <= 2.6e-5 on frames without ties (profiles/r2_parity_errors.json).
+#
+# B(pixel) is the pixel's TIE BUDGET, computed by the oracle itself (orc_options.tieBudget): the reference
+# puts the first sample of every brick segment exactly ON a brick face, which is a voxel face
+# (cuda/Renderer.cu:195-196, :208-214), so which of two voxels that sample reads hangs on the last bit of
+# the coordinate arithmetic -- in the reference as much as here.  B sums, over the samples of the ray that lie
+# within 2^-10 voxel of a voxel face, the largest channel difference between the classified sample and
+# the classified neighbour across that face, times the transmittance at the sample.  An outlier pixel is
+# thus only accepted where the oracle's own arithmetic says a one-voxel flip is possible, and by no more
+# than that flip can make (x 2: the flipped sample's alpha also rescales everything behind it).  Pixels
+# without such samples get the bare E0.  There is no allowance for "a few pixels over the line" any more,
+# no separate mean bound (it follows from the per-pixel bound) and no widening for randomized tests.
+#
+# VRC_FUZZ_SCALE=n multiplies the number of seeds of every randomized test (soak runs).
 FUZZ_SCALE = max(1, int(os.environ.get("VRC_FUZZ_SCALE", "1")))
 
-# A soak run meets the rare seeds whose first sample of a brick -- which the reference puts exactly on the
-# brick's face -- sits on a voxel boundary to the last bit in several pixels at once: the oracle's and the
-# kernel's rounding pick different voxels there (one sample's weight, up to ~2e-2 with an opaque transfer
-# function on noise).  The randomized checks widen by this factor when VRC_FUZZ_SCALE > 1.
-SOAK_SLACK = 1.0 if FUZZ_SCALE == 1 else 4.0
+E0 = 5e-5
+TIE_FACTOR = 2.0
 
+# legacy figures, used only by PROPERTY tests that compare two renders of slightly different ray sets
+# (a sub-frustum tile against the crop of the full frame; per-ray LOD runs that start 1 % of a voxel inside a
+# brick against per-brick segments): there every sample near any voxel face may differ, not only the ties
 MAX_ABS = 2e-3
 MEAN_ABS = 5e-5
 MAX_OVER = 1e-3
+SOAK_SLACK = 1.0
 
 SCENES = {
     # name: kwargs of orc.build_scene
@@ -102,8 +120,34 @@ def nucleon_scene(viewport=(48, 48), spin=(0.4, 0.3), alpha=0.3):
     return s
 
 
-def assert_parity(got, want, what=""):
+def assert_parity(got, want, what="", budget=None, e0=E0):
+    """THE parity check (see the head of this file): every pixel within E0 + TIE_FACTOR x its tie budget.
+    `want` is an oracle frame (or a row / column slice of one): its budget is looked up; pass `budget`
+    when comparing with a stored copy of an oracle frame (golden fixtures)."""
+    tb = budget if budget is not None else orc.budget_of(want)
+    assert tb is not None, "%s: assert_parity needs an oracle frame (or its budget) to compare with" % what
     mx, mean, over = orc.compare(got, want)
-    assert mx <= MAX_ABS and mean <= MEAN_ABS and over <= MAX_OVER, \
-        "%s: max|d|=%.3g mean|d|=%.3g over=%.4f" % (what, mx, mean, over)
+    d = np.abs(got.astype(np.float64) - want.astype(np.float64)).max(axis=-1)
+    ex = d - (e0 + TIE_FACTOR * tb.astype(np.float64))
+    bad = int((ex > 0).sum())
+    if bad:
+        y, x = np.unravel_index(int(np.argmax(ex)), ex.shape)
+        raise AssertionError(
+            "%s: %d of %d pixels differ from the oracle by more than E0 + %g x their tie budget; worst at "
+            "(x=%d, y=%d): |d|=%.3g, budget %.3g; frame max|d|=%.3g mean|d|=%.3g"
+            % (what, bad, d.size, TIE_FACTOR, x, y, d[y, x], tb[y, x], mx, mean))
     return mx, mean, over
+
+
+def assert_close_frames(a, b, what="", max_abs=5e-3, mean_abs=1e-4):
+    """PROPERTY check, not oracle parity: two renders whose rays differ slightly."""
+    mx, mean, _ = orc.compare(a, b)
+    assert mx < max_abs and mean < mean_abs, "%s: max|d|=%.3g mean|d|=%.3g" % (what, mx, mean)
+    return mx, mean
+
+
+def assert_same_frame(a, b, what="", tol=1e-6):
+    """Two kernel forms (or two schedules of one) that composite the same samples: equal up to the last bits."""
+    mx, mean, _ = orc.compare(a, b)
+    assert mx <= tol, "%s: max|d|=%.3g mean|d|=%.3g" % (what, mx, mean)
+    return mx

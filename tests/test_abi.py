@@ -24,7 +24,21 @@ def test_library_exports_every_declared_symbol(built):
     for name in declared:
         assert hasattr(L, name), "libvrc_hip.so does not export %s" % name
     assert sorted(vrc.EXPORTS) == declared
-    assert L.vrc_abi_version() == 1
+    assert L.vrc_abi_version() == 2
+
+
+def test_comm_of_one_rank_needs_no_rccl_and_no_gpu_for_argument_checks(built):
+    # vrc_comm_* / vrc_gather_tiles (sort-first exchange, livre/eq/Channel.cpp:519-523): argument errors come
+    # back as codes before any device or RCCL call
+    from libre_amd import vrc
+    L = vrc.load_library()
+    comm = C.c_void_p()
+    assert L.vrc_comm_create(None, 0, 1, None, C.byref(comm)) == vrc.VRC_EINVAL
+    assert b"bad ctx" in L.vrc_last_error()
+    assert L.vrc_comm_info(None, None, None) == vrc.VRC_EINVAL
+    assert L.vrc_gather_tiles(None, None, None, 0, 16, 1, None, 0, None, 0, 0, None) == vrc.VRC_EINVAL
+    assert C.sizeof(vrc.Band) == 12
+    L.vrc_comm_destroy(None)
 
 
 def test_library_is_gfx950_code_object(built):

@@ -106,7 +106,10 @@ def test_mixed_lod_node_set():
     scenes.assert_parity(ref, want, "mixed ref-order")
     got, _, grid_ok = orc.harness_render(s, kernel=2)
     assert grid_ok
-    scenes.assert_parity(got, want, "mixed dda")
+    # bricks of different sizes: the reference composites them in the host's centre-distance order, which is
+    # not a visibility order for every ray; the grid walk takes them along the ray.
+    # Where the two orders differ, two samples swap places: a second-order effect (weight^2)
+    scenes.assert_parity(got, want, "mixed dda", e0=2e-4)
 
 
 def test_sort_first_tile_equals_crop():
@@ -136,8 +139,7 @@ def test_sort_first_tile_with_subfrustum_matches_oracle():
     got, _, _ = orc.harness_render(t, kernel=2)
     scenes.assert_parity(got, want, "tile")
     # and the sub-frustum tile is the crop of the full frame up to float rounding of the matrices
-    mx, mean, _ = orc.compare(want, want_full[24:36, 12:36])
-    assert mx < 5e-3 and mean < 1e-4
+    scenes.assert_close_frames(want, want_full[24:36, 12:36], "tile vs crop")
 
 
 def test_sanitized_build_runs_clean():
@@ -304,18 +306,8 @@ def _fuzz_scene(rng):
 
 
 def _fuzz_parity(got, want, what):
-    # isolated nearest-voxel flips weigh up to a few 1e-3 with an opaque transfer function
-    # on a noise volume: a handful of pixels may pass the 2e-3 line, the frame as a whole may not.
-    # Random geometry also hits the degenerate case the fixed scenes avoid: a step that is a
-    # rational fraction of a voxel along an axis-parallel ray puts every n-th sample exactly on a
-    # voxel face, where float rounding (the oracle's as much as the kernel's) picks the voxel:
-    # small differences in many pixels, mean up to ~1.2e-4 seen, hence 4 x MEAN_ABS here.
-    mx, mean, over = orc.compare(got, want)
-    npix = got.shape[0] * got.shape[1]
-    k = scenes.SOAK_SLACK
-    allowed = max(3.0, 5e-3 * npix) if k == 1.0 else max(12.0, 0.08 * npix)
-    assert mx <= 3 * k * scenes.MAX_ABS and mean <= 4 * k * scenes.MEAN_ABS and over * npix <= allowed, \
-        "%s: max|d|=%.3g mean|d|=%.3g over=%.4f" % (what, mx, mean, over)
+    # the same rule as everywhere (tests/scenes.py): no widening for random geometry
+    scenes.assert_parity(got, want, what)
 
 
 @pytest.mark.parametrize("seed", range(64 * scenes.FUZZ_SCALE))

@@ -105,7 +105,7 @@ def test_multipass_when_atlas_is_smaller_than_the_frame(drv):
         big.set_colormap(orc.linear_ramp_tf(0.05))
         fb_big, st2 = big.render_frame()
         assert st2.n_passes == 1
-    scenes.assert_parity(fb_small, fb_big, "multipass vs single pass")
+    scenes.assert_same_frame(fb_small, fb_big, "multipass vs single pass")
 
 
 def test_async_mode_converges_to_sync_frame(drv):
@@ -143,8 +143,7 @@ def test_sort_first_tile_apps_assemble_the_full_frame(drv):
             fb, st = t.render_frame()
             assert fb.shape == (h, W, 4)
             out[y0:y0 + h] = fb
-    mx, mean, _ = orc.compare(out, full)
-    assert mx < 5e-3 and mean < 1e-4  # sub-frustum matrices differ in rounding from the full one
+    scenes.assert_close_frames(out, full, "tile apps vs full frame")  # sub-frustum matrices differ in rounding
 
 
 def test_unknown_renderer_and_volume_are_reported(drv):
@@ -333,10 +332,7 @@ def test_uvf_volume_through_the_plugin_matches_oracle(drv):
             assert s.render.samplesPerRay == st.samples_per_ray
             want, n_want = orc.oracle_render(s, threads=8)
             assert want[..., 3].max() > 0.3
-            # real data with steep gradients: the isolated nearest-voxel flips at brick faces
-            #  weigh more than on the synthetic scenes; their number stays tiny
-            mx, mean, over = orc.compare(fb, want)
-            assert mx <= 2 * scenes.MAX_ABS and mean <= scenes.MEAN_ABS and over <= 2e-3, (mx, mean, over)
+            scenes.assert_parity(fb, want, "uvf lod %d" % lod)
             assert abs(int(app.stats().samples) - n_want) <= 2e-4 * n_want + 8
             app.set_option(vrc.OPT_FILTER, vrc.FILTER_TRILINEAR)
             lin, _ = app.render_frame()
@@ -373,15 +369,8 @@ def test_random_lod_cuts_through_the_plugin_match_the_oracle(drv, seed):
                             volume=volume, alpha=0.3)
         want, n_want = orc.oracle_render(s, threads=8)
         assert st.samples_per_ray == s.render.samplesPerRay
-        # a noise volume seen through coarse bricks is oversampled (the step follows the finest level
-        # present), so more samples sit within a rounding error of a voxel face: the flips of
-        # DESIGN.md section 2 add up to a mean of ~1e-4 (the reference-order kernel and the host
-        # build of the same code show the same figure), still isolated pixels
-        mx, mean, over = orc.compare(fb, want)
-        k = scenes.SOAK_SLACK
-        assert mx <= 3 * k * scenes.MAX_ABS and mean <= 4 * k * scenes.MEAN_ABS and over <= k * 1e-2, (
-            "seed %d %s eye %r spin %r sse %g levels %r: max %.3g mean %.3g over %.4f" % (
-                seed, uri, eye, spin, sse, sorted({i & 0xF for i in ids}), mx, mean, over))
+        scenes.assert_parity(fb, want, "seed %d %s eye %r spin %r sse %g levels %r" % (
+            seed, uri, eye, spin, sse, sorted({i & 0xF for i in ids})))
         assert abs(int(app.stats().samples) - n_want) <= 5e-4 * n_want + 16
 
 
@@ -482,10 +471,8 @@ def test_per_ray_lod_through_the_plugin_matches_the_oracle(drv, seed):
                             volume=volume, alpha=0.3)
         assert st.samples_per_ray == s.render.samplesPerRay
         want, n_want = orc.oracle_render(s, threads=8, ray_lod=(sse, orc.world_space_per_pixel(s)))
-        mx, mean, over = orc.compare(fb, want)
-        assert mx <= 5 * scenes.MAX_ABS and mean <= 4 * scenes.MEAN_ABS and over <= 1e-2, (
-            "seed %d %s eye %r spin %r sse %g levels %r: max %.3g mean %.3g over %.4f" % (
-                seed, uri, eye, spin, sse, sorted({i & 0xF for i in hierarchy}), mx, mean, over))
+        scenes.assert_parity(fb, want, "seed %d %s eye %r spin %r sse %g levels %r" % (
+            seed, uri, eye, spin, sse, sorted({i & 0xF for i in hierarchy})))
         assert abs(int(app.stats().samples) - n_want) <= 5e-4 * n_want + 16
         # fewer samples than the per-brick cut of the same frame costs
         app.set_ray_lod(False)
@@ -526,8 +513,7 @@ def test_per_ray_lod_on_the_uvf_fixture(drv):
             assert s.render.samplesPerRay == st.samples_per_ray
             want, n_want = orc.oracle_render(s, threads=8, ray_lod=(sse, orc.world_space_per_pixel(s)))
             assert want[..., 3].max() > 0.3
-            mx, mean, over = orc.compare(fb, want)
-            assert mx <= 5 * scenes.MAX_ABS and mean <= 4 * scenes.MEAN_ABS and over <= 1e-2, (sse, mx, mean, over)
+            scenes.assert_parity(fb, want, "uvf per-ray lod sse %g" % sse)
             assert abs(int(app.stats().samples) - n_want) <= 5e-4 * n_want + 16
 
 

@@ -65,7 +65,7 @@ def test_scene_parity_both_kernels(vrc, golden, name):
         ref, n_ref, st = g.render(kernel=vrc.KERNEL_REFERENCE_ORDER)
         assert st.kernel_variant == vrc.KERNEL_REFERENCE_ORDER
         scenes.assert_parity(ref, want, name + " ref-order vs oracle")
-        scenes.assert_parity(ref, golden[name], name + " ref-order vs golden")
+        scenes.assert_parity(ref, golden[name], name + " ref-order vs golden", budget=orc.budget_of(want))
         assert abs(n_ref - n_want) <= 1e-4 * n_want + 8
         dda, n_dda, st = g.render(kernel=vrc.KERNEL_GRID_DDA)
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
@@ -286,10 +286,7 @@ def test_large_launch_uses_groups_of_eight_and_matches_small_launch_rules(vrc):
     with _gpu(s) as g:
         got, n_got, st = g.render()
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
-    # half a million rays through a noise volume: the isolated nearest-voxel flips reach
-    # a little further out than on the 48x48 scenes, their number stays negligible
-    mx, mean, over = orc.compare(got, want)
-    assert mx <= 2 * scenes.MAX_ABS and mean <= scenes.MEAN_ABS and over <= 1e-4, (mx, mean, over)
+    scenes.assert_parity(got, want, "half a million rays through the noise volume")
     assert abs(n_got - n_want) <= 2e-4 * n_want + 8
 
 
@@ -308,8 +305,8 @@ def test_c2_full_size_rows_and_properties(vrc):
         assert (again == got).all() and n_again == n_got
         ref, n_ref, _ = g.render(kernel=vrc.KERNEL_REFERENCE_ORDER)
     scenes.assert_parity(got[::64], want[::64], "C2 rows")
-    scenes.assert_parity(ref, got, "C2 reference order vs DDA")
-    assert abs(n_ref - n_got) <= 2e-4 * n_got
+    scenes.assert_same_frame(ref, got, "C2 reference order vs DDA")
+    assert n_ref == n_got  # the grid walk composites the reference's samples, one for one
     assert 5.5e8 < n_got < 5.8e8  # SURVEY 8d estimate: ~5.6e8 samples per frame
     # the oracle's count over 16 of 1024 rows, scaled, agrees with the full-frame counter to 3 %
     assert abs(n_want * 64 - n_got) <= 0.03 * n_got
@@ -331,8 +328,92 @@ def test_c2_full_size_rows_of_the_other_modes(vrc):
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
     scenes.assert_parity(gl[::128], want_gl[::128], "C2 rows, glRaycaster variant")
     scenes.assert_parity(lin[::128], want_lin[::128], "C2 rows, trilinear (LDS kernel)")
-    scenes.assert_parity(lin_gather, lin, "C2 trilinear: gather form vs LDS form")
+    scenes.assert_same_frame(lin_gather, lin, "C2 trilinear: gather form vs LDS form", tol=2e-5)
     assert abs(n_lin - n_gather) <= 2e-4 * n_lin
+
+
+# ---- the judged shape on data that can tell voxels apart -----------------------------------------------
+# BASELINE C2/C4 use block 128 -> slots of 136^3 voxels (17^3 micro-blocks, address tables indexed up to
+# 135).  mem:// bricks are constant including their overlap, so the tests above cannot see a wrong voxel
+# inside such a slot; these render the seeded-noise volume ("Volume N") in the same slots.
+# Reference: cuda/Renderer.cu:208-216 (sample fetch), cuda/TexturePool.cu:187-201 (copyToSlot).
+
+@pytest.mark.parametrize("spin", [(0.0, 0.0), (0.5236, 0.349)])
+def test_noise_in_136_cubed_slots_every_kernel_form(vrc, spin):
+    # 256^3 noise, block 128: 8 bricks of 136^3, full 256^2 frame against the oracle
+    s = orc.build_scene(voxels=(256, 256, 256), block=128, viewport=(256, 256), volume="hash", spin=spin)
+    assert s.slot_dim == [136, 136, 136] and s.n_nodes == 8
+    want, n_want = orc.oracle_render(s, threads=16)
+    want_lin, n_lin = orc.oracle_render(s, threads=16, filter_mode=1)
+    want_gl, _ = orc.oracle_render(s, threads=16, variant=1)
+    with _gpu(s) as g:
+        # one whole 136^3 brick read back through the layout transform, bit-exact
+        nid = s.ids[5]
+        o = [int(round(s.slot_of[nid][a] * s.atlas_dim[a])) for a in range(3)]
+        back = np.zeros((136, 136, 136), dtype=np.uint8)
+        vrc.check(g.L, g.L.vrc_pool_read_region(g.pool, vrc.u32x3(*o), vrc.u32x3(136, 136, 136), back.ctypes.data))
+        assert (back == s.bricks[nid]).all()
+        ref, n_ref, st = g.render(kernel=vrc.KERNEL_REFERENCE_ORDER)
+        assert st.kernel_variant == vrc.KERNEL_REFERENCE_ORDER
+        scenes.assert_parity(ref, want, "136^3 noise, reference order")
+        assert abs(n_ref - n_want) <= 1e-4 * n_want + 8
+        dda, n_dda, st = g.render(kernel=vrc.KERNEL_GRID_DDA)
+        assert st.kernel_variant == vrc.KERNEL_GRID_DDA
+        scenes.assert_parity(dda, want, "136^3 noise, grid DDA, fixed-point stepping")
+        assert abs(n_dda - n_want) <= 2e-4 * n_want + 8
+        flt, n_flt, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, stepping=0)
+        scenes.assert_parity(flt, want, "136^3 noise, grid DDA, float stepping")
+        assert n_flt == n_dda
+        lds, n_lds, st = g.render(kernel=vrc.KERNEL_LDS)
+        assert st.kernel_variant == vrc.KERNEL_LDS
+        scenes.assert_parity(lds, want, "136^3 noise, LDS-staged")
+        assert n_lds == n_dda
+        gl, _, _ = g.render(variant=vrc.VARIANT_GLRAYCASTER)
+        scenes.assert_parity(gl, want_gl, "136^3 noise, glRaycaster variant")
+        lin, n_got_lin, st = g.render(filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_LDS
+        scenes.assert_parity(lin, want_lin, "136^3 noise, trilinear (LDS kernel)")
+        assert abs(n_got_lin - n_lin) <= 2e-4 * n_lin + 8
+        ling, _, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, filter_mode=vrc.FILTER_TRILINEAR)
+        scenes.assert_parity(ling, want_lin, "136^3 noise, trilinear (gather form)")
+
+
+@pytest.fixture(scope="module")
+def c2_noise_scene():
+    # "Volume N" at BASELINE C2's size: hash 1024^3, block 128 (512 bricks of 136^3), default camera
+    return orc.build_scene(voxels=(1024, 1024, 1024), block=128, viewport=(1024, 1024), volume="hash")
+
+
+def test_c2_noise_volume_rows_at_1024_and_2048(vrc, c2_noise_scene):
+    # the kernel instance bench.py times (grid DDA, fixed-point stepping, groups of 8) on the judged shape
+    # with noise data: every 64th row of the 1024^2 frame (C2) and every 128th of the 2048^2 frame (C4's)
+    # against the oracle; plus the reference-order kernel and the float stepping on the same frame
+    s = c2_noise_scene
+    assert s.n_nodes == 512 and s.render.samplesPerRay == 1024 and s.slot_dim == [136, 136, 136]
+    rows = (0, 1024, 64)
+    want, n_want = orc.oracle_render(s, threads=16, rows=rows)
+    s2 = orc.with_viewport(s, 2048, 2048)
+    rows2 = (0, 2048, 128)
+    want2, n_want2 = orc.oracle_render(s2, threads=16, rows=rows2)
+    with _gpu(s) as g:
+        nid = s.ids[137]
+        o = [int(round(s.slot_of[nid][a] * s.atlas_dim[a])) for a in range(3)]
+        back = np.zeros((136, 136, 136), dtype=np.uint8)
+        vrc.check(g.L, g.L.vrc_pool_read_region(g.pool, vrc.u32x3(*o), vrc.u32x3(136, 136, 136), back.ctypes.data))
+        assert (back == s.bricks[nid]).all()
+        got, n_got, st = g.render()
+        assert st.kernel_variant == vrc.KERNEL_GRID_DDA and list(st.grid_dims) == [8, 8, 8]
+        ref, n_ref, _ = g.render(kernel=vrc.KERNEL_REFERENCE_ORDER)
+        flt, n_flt, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, stepping=0)
+        g.s = s2
+        got2, n_got2, st2 = g.render()
+        assert st2.kernel_variant == vrc.KERNEL_GRID_DDA
+    scenes.assert_parity(got[::64], want[::64], "C2 noise rows")
+    scenes.assert_parity(ref[::64], want[::64], "C2 noise rows, reference order")
+    scenes.assert_parity(flt[::64], want[::64], "C2 noise rows, float stepping")
+    assert abs(n_want * 64 - n_got) <= 0.03 * n_got and n_flt == n_got and abs(n_ref - n_got) <= 2e-4 * n_got
+    scenes.assert_parity(got2[::128], want2[::128], "C4 frame (2048^2) noise rows")
+    assert abs(n_want2 * 128 - n_got2) <= 0.03 * n_got2
 
 
 @pytest.mark.parametrize("seed", range(32 * scenes.FUZZ_SCALE))
@@ -407,7 +488,7 @@ def test_nucleon_raw_single_brick(vrc, golden):
         for k in (vrc.KERNEL_REFERENCE_ORDER, vrc.KERNEL_GRID_DDA):
             got, n_got, _ = g.render(kernel=k)
             scenes.assert_parity(got, want, "nucleon")
-            scenes.assert_parity(got, golden["nucleon"], "nucleon golden")
+            scenes.assert_parity(got, golden["nucleon"], "nucleon golden", budget=orc.budget_of(want))
             assert n_got == n_want
 
 
@@ -419,7 +500,7 @@ def test_multipass_equals_single_pass(vrc):
         many, n3, _ = g.render(passes=[(0, h), (h, 2 * h), (2 * h, s.n_nodes)])
     want, _ = orc.oracle_render(s, threads=8)
     scenes.assert_parity(many, want, "multipass")
-    scenes.assert_parity(many, one, "multipass vs single")
+    scenes.assert_same_frame(many, one, "multipass vs single")
 
 
 def test_early_ray_termination(vrc):
@@ -446,8 +527,7 @@ def test_sort_first_tile_is_crop_of_full_frame(vrc):
         tile, _, _ = g.render()
     want, _ = orc.oracle_render(t, threads=8)
     scenes.assert_parity(tile, want, "tile vs oracle")
-    mx, mean, _ = orc.compare(tile, full[24:36, 12:36])
-    assert mx < 5e-3 and mean < 1e-4
+    scenes.assert_close_frames(tile, full[24:36, 12:36], "tile vs crop of the full frame")
 
 
 def test_pool_exhaustion_and_slot_reuse(vrc):
@@ -551,10 +631,7 @@ def _hierarchy(voxels=(64, 64, 64), block=16, levels=None, **kw):
 
 
 def _lod_parity(got, want, what):
-    mx, mean, over = orc.compare(got, want)
-    npix = got.shape[0] * got.shape[1]
-    assert mx <= 5 * scenes.MAX_ABS and mean <= 4 * scenes.MEAN_ABS and over * npix <= max(3.0, 5e-3 * npix), \
-        "%s: max|d|=%.3g mean|d|=%.3g over=%.4f" % (what, mx, mean, over)
+    scenes.assert_parity(got, want, what)
 
 
 @pytest.mark.parametrize("sse", [0.5, 1.3, 1.7, 2.5, 6.0])
@@ -752,7 +829,9 @@ def test_ray_lod_matches_the_committed_frames(vrc):
         with _gpu(s) as g:
             got, n_got, st = g.render(ray_lod=(sse, orc.world_space_per_pixel(s)))
         assert st.kernel_variant == vrc.KERNEL_RAY_LOD
-        _lod_parity(got, golden_lod[name], name + " gpu vs golden")
+        want, _ = orc.oracle_render(s, threads=8, ray_lod=(sse, orc.world_space_per_pixel(s)))
+        assert np.allclose(want, golden_lod[name], atol=1e-6), name
+        scenes.assert_parity(got, golden_lod[name], name + " gpu vs golden", budget=orc.budget_of(want))
         n_want = int(golden_lod[name + "__samples"][0])
         assert abs(n_got - n_want) <= 3e-4 * n_want + 16
 
@@ -771,8 +850,8 @@ def test_more_bricks_than_the_reference_node_table_holds(vrc):
             # 8-voxel bricks: a brick entry (the reference's sample on the face) every few samples
             _fuzz_parity(got, want, "32768 bricks k%d" % k)
             assert abs(n_got - n_want) <= 3e-4 * n_want + 16
-        # the two enumerations agree except where a ray grazes a brick edge: the slab test of the list walk
-        # and the cell walk of the DDA may or may not give such a brick its one sample
+        # the two enumerations composite the same samples: where a ray leaves a cell through an edge or a
+        # corner of the brick grid, the cell walk hands the bricks around it to the reference's slab test too
         dda, n_dda, _ = g.render(kernel=vrc.KERNEL_GRID_DDA)
         ref, n_ref, _ = g.render(kernel=vrc.KERNEL_REFERENCE_ORDER)
-        assert np.abs(dda - ref).max() <= scenes.MAX_ABS and abs(n_dda - n_ref) <= 1e-4 * n_ref + 8
+        assert n_dda == n_ref and np.abs(dda - ref).max() <= 1e-6

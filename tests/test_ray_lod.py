@@ -10,12 +10,7 @@ import scenes
 
 
 def _parity(got, want, what):
-    # run borders are cell faces: a ray through a cell edge may take the neighbouring brick in one
-    # implementation and not the other, the same isolated-pixel effect as nearest-voxel flips
-    mx, mean, over = orc.compare(got, want)
-    npix = got.shape[0] * got.shape[1]
-    assert mx <= 5 * scenes.MAX_ABS and mean <= 4 * scenes.MEAN_ABS and over * npix <= max(3.0, 5e-3 * npix), \
-        "%s: max|d|=%.3g mean|d|=%.3g over=%.4f" % (what, mx, mean, over)
+    scenes.assert_parity(got, want, what)
 
 
 def _close_to_per_brick(got, want, what):
@@ -248,6 +243,6 @@ def test_oracle_still_matches_the_committed_ray_lod_frames():
         assert n == int(golden[name + "__samples"][0]), name
         assert np.allclose(fb, golden[name], atol=1e-6), name
         got, n_got, ok = orc.harness_render_ray_lod(s, lod, kernel=3)
-        _parity(got, golden[name], name + " host build vs golden")
+        scenes.assert_parity(got, golden[name], name + " host build vs golden", budget=orc.budget_of(fb))
         n_cases += 1
     assert n_cases == 3

@@ -60,9 +60,8 @@ def test_sort_first_assembly_equals_full_frame(tmp_path, world, height, bands):
     kw["viewport"] = (width, height)
     full, _ = orc.oracle_render(orc.build_scene(**kw), threads=4)
     assert got.shape == full.shape
-    mx, mean, _ = orc.compare(got, full)
     # the tile frusta are separate float matrices: equal up to rounding of the ray directions
-    assert mx < 5e-3 and mean < 1e-4
+    scenes.assert_close_frames(got, full, "assembled tiles vs full frame")
 
 
 def test_band_layout_properties():
