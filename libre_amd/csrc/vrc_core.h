@@ -1149,59 +1149,82 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
         int32_t recent[4] = { -1, -1, -1, -1 };
         const int maxSteps = f.gridDim[0] + f.gridDim[1] + f.gridDim[2] + 3;
         bool finished = false;
-        /* slab test + march of the brick of one cell (at most once per brick) */
-        auto visit = [&]( int cx, int cy, int cz ) {
-            if( cx < 0 || cx >= f.gridDim[0] || cy < 0 || cy >= f.gridDim[1] || cz < 0 || cz >= f.gridDim[2] )
-                return;
-            const int32_t node = gridTable[( cz * f.gridDim[1] + cy ) * f.gridDim[0] + cx];
-            if( node < 0 || node == recent[0] || node == recent[1] || node == recent[2] || node == recent[3] )
-                return;
-            recent[3] = recent[2];
-            recent[2] = recent[1];
-            recent[1] = recent[0];
-            recent[0] = node;
-            const vrc_dev_node n = nodes[node];
-            vrc_segment s;
-            bool stop;
-            if( vrc_brick_segment( f, r, n, f.stepSize, &s, &stop ) )
-            {
-                if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >( f, n, s, atlas, lut, cls,
-                                                                             color, nSamples ) )
-                    finished = true;
-            }
-            else if( stop )
-                finished = true;
-        };
+        /* cells entered at the ray's first parameter t0 (the first cell, and any cell reached from it
+         * without the parameter moving on) */
+        bool atStart = true;
+        const float tolE = fabsf( t0 ) * 2e-6f;
         for( int it = 0; it < maxSteps && !finished; ++it )
         {
-            visit( cell[0], cell[1], cell[2] );
-            /* Where the ray leaves the cell through an edge or a corner of the grid (two or three of the
-             * exit parameters equal to within rounding) it also touches the cells around that edge or
-             * corner.  In exact arithmetic it has no extent in those; the reference tests every brick
-             * with its float slab test (Renderer.cu:56-80, :179-181), and one that comes out with tfar a
-             * last bit above tnear gets its one sample (:208).  Testing the same cells with the same
-             * arithmetic reproduces that, instead of depending on which of the tied faces this walk
-             * happens to take first: the walk then composites the reference's samples, one for one. */
+            /* Which bricks does the ray meet at this cell?  The cell's own -- and, where the ray enters or
+             * leaves the cell through an edge or a corner of the grid (two or three of the entry / exit
+             * parameters equal to within rounding), the cells around that edge or corner.  In exact
+             * arithmetic the ray has no extent in those; the reference tests every brick with its float slab
+             * test (Renderer.cu:56-80, :179-181), and one that comes out with tfar a last bit above tnear
+             * gets its one sample (:208).  Handing the same cells to the same arithmetic
+             * (vrc_brick_segment) reproduces that instead of depending on which of the tied faces this
+             * walk happens to cross first: the walk composites the reference's samples, one for one.
+             * Entry side: only for cells entered at t0 -- later cells are entered where the previous
+             * one was left, and that edge was handled there. */
             const float tNext = fminf( fminf( tMax[0], tMax[1] ), tMax[2] );
             const float tol = fabsf( tNext ) * 2e-6f;
             const bool tie0 = tMax[0] <= tNext + tol, tie1 = tMax[1] <= tNext + tol, tie2 = tMax[2] <= tNext + tol;
             const bool leaves = tNext > t1; /* the ray ends inside this cell */
-            if( !finished && !leaves && ( (int)tie0 + (int)tie1 + (int)tie2 ) > 1 )
+            const uint32_t tied = ( tie0 ? 1u : 0u ) | ( tie1 ? 2u : 0u ) | ( tie2 ? 4u : 0u );
+            uint32_t back = 0u;
+            if( atStart )
+                back = ( fabsf( ( tMax[0] - tDelta[0] ) - t0 ) <= tolE ? 1u : 0u ) |
+                       ( fabsf( ( tMax[1] - tDelta[1] ) - t0 ) <= tolE ? 2u : 0u ) |
+                       ( fabsf( ( tMax[2] - tDelta[2] ) - t0 ) <= tolE ? 4u : 0u );
+            /* work list, one bit per candidate cell, in the order they are met:
+             *   bits 0-6   cell - (subset of the entry-tied axes): subsets 7, 3, 5, 6, 1, 2, 4
+             *   bit  7     the cell
+             *   bits 8-13  cell + (proper subset of the exit-tied axes): subsets 1, 2, 4, 3, 5, 6
+             * the tables below hold, per 3-bit axis set, the bits whose subset lies inside it */
+            uint32_t pending = 0x80u | (uint32_t)( ( 0x7F68544032201000ull >> ( back * 8u ) ) & 0x7Fu );
+            if( !leaves && ( tied & ( tied - 1u ) ) != 0u )
+                pending |= (uint32_t)( ( 0x3F06050003000000ull >> ( tied * 8u ) ) & 0x3Fu ) << 8;
+            while( pending != 0u && !finished )
             {
-                const int sx = tie0 ? stepDir[0] : 0, sy = tie1 ? stepDir[1] : 0, sz = tie2 ? stepDir[2] : 0;
-                /* proper subsets of the tied axes: single faces first, then (three-way tie) the pairs */
-                if( tie0 && !finished ) visit( cell[0] + sx, cell[1], cell[2] );
-                if( tie1 && !finished ) visit( cell[0], cell[1] + sy, cell[2] );
-                if( tie2 && !finished ) visit( cell[0], cell[1], cell[2] + sz );
-                if( tie0 && tie1 && tie2 )
+#if defined( __HIP_DEVICE_COMPILE__ )
+                const uint32_t slot = (uint32_t)__builtin_ctz( pending );
+#else
+                uint32_t slot = 0;
+                while( !( ( pending >> slot ) & 1u ) )
+                    ++slot;
+#endif
+                pending &= pending - 1u;
+                const uint32_t sub = slot < 7u ? ( 0x4216537u >> ( slot * 4u ) ) & 7u
+                                               : ( slot == 7u ? 0u : ( 0x653421u >> ( ( slot - 8u ) * 4u ) ) & 7u );
+                const int sgn = slot < 7u ? -1 : 1;
+                const int cx = cell[0] + ( ( sub & 1u ) ? sgn * stepDir[0] : 0 );
+                const int cy = cell[1] + ( ( sub & 2u ) ? sgn * stepDir[1] : 0 );
+                const int cz = cell[2] + ( ( sub & 4u ) ? sgn * stepDir[2] : 0 );
+                if( cx < 0 || cx >= f.gridDim[0] || cy < 0 || cy >= f.gridDim[1] || cz < 0 || cz >= f.gridDim[2] )
+                    continue;
+                const int32_t node = gridTable[( cz * f.gridDim[1] + cy ) * f.gridDim[0] + cx];
+                /* a brick is convex: once left it is never entered again, but the work list (or a coarse
+                 * brick that spans several cells) meets it more than once */
+                if( node < 0 || node == recent[0] || node == recent[1] || node == recent[2] || node == recent[3] )
+                    continue;
+                recent[3] = recent[2];
+                recent[2] = recent[1];
+                recent[1] = recent[0];
+                recent[0] = node;
+                const vrc_dev_node n = nodes[node];
+                vrc_segment s;
+                bool stop;
+                if( vrc_brick_segment( f, r, n, f.stepSize, &s, &stop ) )
                 {
-                    if( !finished ) visit( cell[0] + sx, cell[1] + sy, cell[2] );
-                    if( !finished ) visit( cell[0] + sx, cell[1], cell[2] + sz );
-                    if( !finished ) visit( cell[0], cell[1] + sy, cell[2] + sz );
+                    if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >( f, n, s, atlas, lut, cls,
+                                                                                 color, nSamples ) )
+                        finished = true;
                 }
+                else if( stop )
+                    finished = true;
             }
             if( finished || leaves )
                 break;
+            atStart = atStart && tNext <= t0 + tolE;
             /* advance through every tied face at once */
             if( tie0 )
             {

@@ -195,7 +195,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
 
     int cell[3] = { 0, 0, 0 }, stepDir[3] = { 1, 1, 1 };
     float tMax[3] = { 0.f, 0.f, 0.f }, tDelta[3] = { 0.f, 0.f, 0.f };
-    float t1 = 0.0f;
+    float t0 = 0.0f, t1 = 0.0f;
     bool ddaEnd = false;
     if( !done )
     {
@@ -203,7 +203,6 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
         const vrc_f3 gmax = { f.gridMin[0] + f.cellSize[0] * (float)f.gridDim[0],
                               f.gridMin[1] + f.cellSize[1] * (float)f.gridDim[1],
                               f.gridMin[2] + f.cellSize[2] * (float)f.gridDim[2] };
-        float t0;
         const bool any = vrc_intersect_box( r.origin, r.invDir, gmin, gmax, &t0, &t1 );
         /* the GLSL twin does not clamp a brick's interval to the global box (fragRaycast.glsl:149-150):
          * bricks of the tree that reach past the volume (ragged trees) are sampled there too */
@@ -243,7 +242,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
     /* bricks already handed to the slab test; probe: what the walk does next at its cell (0: the cell
      * itself, 1..6: the cells around an edge / corner the ray leaves through, see vrc_pixel_grid_dda) */
     int32_t recent0 = -1, recent1 = -1, recent2 = -1, recent3 = -1;
-    int probe = 0;
+    uint32_t pending = 0u; /* work list of the cell the walk stands in (0: not drawn up yet) */
+    bool listed = false, atStart = true;
     uint32_t fx = 0, fy = 0, fz = 0, fdx = 0, fdy = 0, fdz = 0; /* 8.24 slot-local voxel */
     float travel = 0.0f;
     uint32_t laneSlotBase = 0;
@@ -284,26 +284,40 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
                     done = true;
                 else
                 {
-                    /* the same walk as vrc_pixel_grid_dda (vrc_core.h), one cell per iteration: the cell,
-                     * then -- where the ray leaves it through an edge or corner of the grid -- the cells
-                     * around that edge or corner, then the step through every tied face */
+                    /* the walk of vrc_pixel_grid_dda (vrc_core.h), one candidate cell per iteration: the
+                     * cells around an edge / corner the ray enters through (cells entered at t0 only), the
+                     * cell, the cells around an edge / corner it leaves through, then the step through
+                     * every tied face.  Same work-list encoding as there. */
                     const float tNext = fminf( fminf( tMax[0], tMax[1] ), tMax[2] );
                     const float tol = fabsf( tNext ) * 2e-6f;
                     const bool tie0 = tMax[0] <= tNext + tol, tie1 = tMax[1] <= tNext + tol,
                                tie2 = tMax[2] <= tNext + tol;
-                    const int tied = ( tie0 ? 1 : 0 ) | ( tie1 ? 2 : 0 ) | ( tie2 ? 4 : 0 );
                     const bool leaves = tNext > t1;
-                    const bool multi = !leaves && ( tied & ( tied - 1 ) ) != 0;
-                    const int sub = probe == 0 ? 0
-                                               : ( probe < 4 ? ( 1 << ( probe - 1 ) )
-                                                             : ( probe == 4 ? 3 : ( probe == 5 ? 5 : 6 ) ) );
-                    const int cx = cell[0] + ( ( sub & 1 ) ? stepDir[0] : 0 );
-                    const int cy = cell[1] + ( ( sub & 2 ) ? stepDir[1] : 0 );
-                    const int cz = cell[2] + ( ( sub & 4 ) ? stepDir[2] : 0 );
-                    const bool look = ( probe == 0 || ( multi && ( sub & ~tied ) == 0 && sub != tied ) ) && cx >= 0 &&
-                                      cx < f.gridDim[0] && cy >= 0 && cy < f.gridDim[1] && cz >= 0 &&
-                                      cz < f.gridDim[2];
-                    const int32_t node = look ? gridTable[( cz * f.gridDim[1] + cy ) * f.gridDim[0] + cx] : -1;
+                    const float tolE = fabsf( t0 ) * 2e-6f;
+                    if( !listed )
+                    {
+                        const uint32_t tied = ( tie0 ? 1u : 0u ) | ( tie1 ? 2u : 0u ) | ( tie2 ? 4u : 0u );
+                        uint32_t back = 0u;
+                        if( atStart )
+                            back = ( fabsf( ( tMax[0] - tDelta[0] ) - t0 ) <= tolE ? 1u : 0u ) |
+                                   ( fabsf( ( tMax[1] - tDelta[1] ) - t0 ) <= tolE ? 2u : 0u ) |
+                                   ( fabsf( ( tMax[2] - tDelta[2] ) - t0 ) <= tolE ? 4u : 0u );
+                        pending = 0x80u | (uint32_t)( ( 0x7F68544032201000ull >> ( back * 8u ) ) & 0x7Fu );
+                        if( !leaves && ( tied & ( tied - 1u ) ) != 0u )
+                            pending |= (uint32_t)( ( 0x3F06050003000000ull >> ( tied * 8u ) ) & 0x3Fu ) << 8;
+                        listed = true;
+                    }
+                    const uint32_t slot = (uint32_t)__builtin_ctz( pending );
+                    pending &= pending - 1u;
+                    const uint32_t sub = slot < 7u ? ( 0x4216537u >> ( slot * 4u ) ) & 7u
+                                                   : ( slot == 7u ? 0u : ( 0x653421u >> ( ( slot - 8u ) * 4u ) ) & 7u );
+                    const int sgn = slot < 7u ? -1 : 1;
+                    const int cx = cell[0] + ( ( sub & 1u ) ? sgn * stepDir[0] : 0 );
+                    const int cy = cell[1] + ( ( sub & 2u ) ? sgn * stepDir[1] : 0 );
+                    const int cz = cell[2] + ( ( sub & 4u ) ? sgn * stepDir[2] : 0 );
+                    const bool inside = cx >= 0 && cx < f.gridDim[0] && cy >= 0 && cy < f.gridDim[1] && cz >= 0 &&
+                                        cz < f.gridDim[2];
+                    const int32_t node = inside ? gridTable[( cz * f.gridDim[1] + cy ) * f.gridDim[0] + cx] : -1;
                     if( node >= 0 && node != recent0 && node != recent1 && node != recent2 && node != recent3 )
                     {
                         recent3 = recent2;
@@ -337,10 +351,10 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
                         else if( stop )
                             done = true;
                     }
-                    ++probe;
-                    if( !done && ( probe > 6 || !multi ) )
+                    if( !done && pending == 0u )
                     {
-                        probe = 0;
+                        listed = false;
+                        atStart = atStart && tNext <= t0 + tolE;
                         if( leaves )
                             ddaEnd = true;
                         else
