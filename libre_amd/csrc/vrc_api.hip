@@ -126,6 +126,7 @@ struct vrc_ctx
     std::vector< vrc_node_data > cachedNodes;
     uint64_t cachedPoolUid = 0;
     bool cachedGridOk = false;
+    bool cachedOneCell = false; /* every brick = one grid cell (vrc_host_tables::oneCellPerBrick) */
     bool cachedRayLod = false; /* tables are per-level (vrc_build_lod_tables) */
     bool cachedLodOk = false;
     uint32_t cachedLodLevels = 0;
@@ -991,6 +992,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         c->cachedNodes.assign( nodes, nodes + nNodes );
         c->cachedPoolUid = pool->uid;
         c->cachedGridOk = t.gridOk && !c->rayLod; /* the grid buffer holds the per-level tables */
+        c->cachedOneCell = t.oneCellPerBrick;
         c->cachedRayLod = c->rayLod;
         c->cachedLodOk = t.lodOk;
         c->cachedLodLevels = t.lodLevels;
@@ -1011,6 +1013,14 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
             return fail( VRC_EHIERARCHY, "vrc_render: per-ray LOD is not available in atlases of more than 2^32 voxels" );
     }
     bool useDda = c->cachedGridOk;
+    /* AUTO keeps the reference's frame: bricks of one size are met by the grid walk in the reference's
+     * order; a list that mixes brick sizes (an LOD cut) is composited in the host's centre-distance order,
+     * which is not a visibility order for every ray (quirk Q6) -- the literal loop reproduces that as long
+     * as testing every brick per ray is affordable.  GRID_DDA can always be asked for (true visibility
+     * order); the trilinear filter (extension, no reference frame to keep) stays on the grid. */
+    if( c->optKernel == VRC_KERNEL_AUTO && useDda && !c->cachedOneCell && !linear &&
+        nNodes <= VRC_REFERENCE_ORDER_MAX_NODES )
+        useDda = false;
     if( c->optKernel == VRC_KERNEL_REFERENCE_ORDER )
         useDda = false;
     else if( c->optKernel == VRC_KERNEL_GRID_DDA && !c->cachedGridOk )

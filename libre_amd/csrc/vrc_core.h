@@ -1180,27 +1180,43 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
              *   bit  7     the cell
              *   bits 8-13  cell + (proper subset of the exit-tied axes): subsets 1, 2, 4, 3, 5, 6
              * the tables below hold, per 3-bit axis set, the bits whose subset lies inside it */
-            uint32_t pending = 0x80u | (uint32_t)( ( 0x7F68544032201000ull >> ( back * 8u ) ) & 0x7Fu );
-            if( !leaves && ( tied & ( tied - 1u ) ) != 0u )
-                pending |= (uint32_t)( ( 0x3F06050003000000ull >> ( tied * 8u ) ) & 0x3Fu ) << 8;
+            const bool multi = !leaves && ( tied & ( tied - 1u ) ) != 0u;
+            uint32_t pending = 0x80u;
+            bool plain = back == 0u && !multi; /* nothing but the cell itself: almost always */
+#if defined( __HIP_DEVICE_COMPILE__ )
+            /* wave-uniform: the short path only when no lane of the wave has a tie at this step */
+            plain = __builtin_amdgcn_ballot_w64( !plain ) == 0ull;
+#endif
+            if( !plain )
+            {
+                pending |= (uint32_t)( ( 0x7F68544032201000ull >> ( back * 8u ) ) & 0x7Fu );
+                if( multi )
+                    pending |= (uint32_t)( ( 0x3F06050003000000ull >> ( tied * 8u ) ) & 0x3Fu ) << 8;
+            }
             while( pending != 0u && !finished )
             {
+                int cx = cell[0], cy = cell[1], cz = cell[2];
+                if( plain )
+                    pending = 0u;
+                else
+                {
 #if defined( __HIP_DEVICE_COMPILE__ )
-                const uint32_t slot = (uint32_t)__builtin_ctz( pending );
+                    const uint32_t slot = (uint32_t)__builtin_ctz( pending );
 #else
-                uint32_t slot = 0;
-                while( !( ( pending >> slot ) & 1u ) )
-                    ++slot;
+                    uint32_t slot = 0;
+                    while( !( ( pending >> slot ) & 1u ) )
+                        ++slot;
 #endif
-                pending &= pending - 1u;
-                const uint32_t sub = slot < 7u ? ( 0x4216537u >> ( slot * 4u ) ) & 7u
-                                               : ( slot == 7u ? 0u : ( 0x653421u >> ( ( slot - 8u ) * 4u ) ) & 7u );
-                const int sgn = slot < 7u ? -1 : 1;
-                const int cx = cell[0] + ( ( sub & 1u ) ? sgn * stepDir[0] : 0 );
-                const int cy = cell[1] + ( ( sub & 2u ) ? sgn * stepDir[1] : 0 );
-                const int cz = cell[2] + ( ( sub & 4u ) ? sgn * stepDir[2] : 0 );
-                if( cx < 0 || cx >= f.gridDim[0] || cy < 0 || cy >= f.gridDim[1] || cz < 0 || cz >= f.gridDim[2] )
-                    continue;
+                    pending &= pending - 1u;
+                    const uint32_t sub = slot < 7u ? ( 0x4216537u >> ( slot * 4u ) ) & 7u
+                                                   : ( slot == 7u ? 0u : ( 0x653421u >> ( ( slot - 8u ) * 4u ) ) & 7u );
+                    const int sgn = slot < 7u ? -1 : 1;
+                    cx += ( sub & 1u ) ? sgn * stepDir[0] : 0;
+                    cy += ( sub & 2u ) ? sgn * stepDir[1] : 0;
+                    cz += ( sub & 4u ) ? sgn * stepDir[2] : 0;
+                    if( cx < 0 || cx >= f.gridDim[0] || cy < 0 || cy >= f.gridDim[1] || cz < 0 || cz >= f.gridDim[2] )
+                        continue;
+                }
                 const int32_t node = gridTable[( cz * f.gridDim[1] + cy ) * f.gridDim[0] + cx];
                 /* a brick is convex: once left it is never entered again, but the work list (or a coarse
                  * brick that spans several cells) meets it more than once */

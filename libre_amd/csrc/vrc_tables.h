@@ -25,6 +25,10 @@ struct vrc_host_tables
     std::vector< vrc_dev_node > nodes;
     std::vector< int32_t > grid;
     bool gridOk = false;
+    /* every brick covers exactly one grid cell (one LOD level, regular tree): the along-ray order of the
+     * grid walk then equals the reference's centre-distance order for every pair of bricks that share a
+     * ray; with bricks of different sizes it need not */
+    bool oneCellPerBrick = false;
     bool clamp = false;
     vrc_frame g = {}; /* grid and lod* fields only */
     /* per-ray LOD (vrc_build_lod_tables): one cell -> node table per level in `grid` */
@@ -128,6 +132,7 @@ inline void vrc_build_tables( const vrc_atlas_geom& p, const vrc_node_data* in, 
     if( (double)dim[0] * dim[1] * dim[2] > 64.0 * 1024 * 1024 )
         return;
     t.grid.assign( (size_t)dim[0] * dim[1] * dim[2], -1 );
+    bool oneCell = true;
     for( uint32_t i = 0; i < n; ++i )
     {
         long i0[3], cnt[3];
@@ -141,6 +146,7 @@ inline void vrc_build_tables( const vrc_atlas_geom& p, const vrc_node_data* in, 
                 return;
             }
         }
+        oneCell = oneCell && cnt[0] == 1 && cnt[1] == 1 && cnt[2] == 1;
         for( long z = i0[2]; z < i0[2] + cnt[2]; ++z )
             for( long y = i0[1]; y < i0[1] + cnt[1]; ++y )
                 for( long x = i0[0]; x < i0[0] + cnt[0]; ++x )
@@ -163,6 +169,7 @@ inline void vrc_build_tables( const vrc_atlas_geom& p, const vrc_node_data* in, 
         t.g.gridDim[a] = (int32_t)dim[a];
     }
     t.gridOk = true;
+    t.oneCellPerBrick = oneCell;
 }
 
 /* Per-ray LOD tables (vrc_pixel_ray_lod): the node list is a hierarchy -- boxes of different

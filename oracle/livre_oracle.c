@@ -648,8 +648,14 @@ typedef struct
  * pixel channel if this point sample read the voxel across a face it lies within tieDelta voxels of.
  * transmittance = 1 - accumulated alpha before the sample. */
 static float tie_budget( const job_t* j, f3 texPos, float density, float multiplyer, float addedValue,
-                         float alphaCorrection, float transmittance )
+                         float alphaCorrection, float transmittance, uint32_t k, f3 voxelsPerWorld )
 {
+    /* how close to a voxel face counts: tieDelta voxels for the coordinate evaluation itself, plus what the
+     * reference's own position chain (pos += step, Renderer.cu:208) may have drifted after k additions:
+     * half an ulp of a coordinate below 1 (2^-25 world units) per addition, in voxels */
+    const float drift = (float)k * 2.98023224e-8f;
+    const float delta[3] = { j->opt.tieDelta + drift * voxelsPerWorld.x, j->opt.tieDelta + drift * voxelsPerWorld.y,
+                             j->opt.tieDelta + drift * voxelsPerWorld.z };
     const float c[3] = { texPos.x * (float)j->atlasDim[0], texPos.y * (float)j->atlasDim[1],
                          texPos.z * (float)j->atlasDim[2] };
     int idx[3], off[3] = { 0, 0, 0 }, any = 0;
@@ -658,9 +664,9 @@ static float tie_budget( const job_t* j, f3 texPos, float density, float multipl
         const float fl = floorf( c[a] );
         const float fr = c[a] - fl;
         idx[a] = tex_index( a == 0 ? texPos.x : a == 1 ? texPos.y : texPos.z, j->atlasDim[a] );
-        if( fr < j->opt.tieDelta && idx[a] > 0 )
+        if( fr < delta[a] && idx[a] > 0 )
             off[a] = -1;
-        else if( fr > 1.0f - j->opt.tieDelta && idx[a] < (int)j->atlasDim[a] - 1 )
+        else if( fr > 1.0f - delta[a] && idx[a] < (int)j->atlasDim[a] - 1 )
             off[a] = 1;
         any |= off[a] != 0;
     }
@@ -788,8 +794,11 @@ static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
         const f3 texSize = { nodeData->textureSize[0], nodeData->textureSize[1], nodeData->textureSize[2] };
 
         int isEarlyExit = 0;
+        uint32_t kStep = 0; /* test instrument only (tie budget) */
+        const f3 vpw = { texSize.x * (float)j->atlasDim[0] / boxSize.x, texSize.y * (float)j->atlasDim[1] / boxSize.y,
+                         texSize.z * (float)j->atlasDim[2] / boxSize.z };
         for( float travel = dist; travel > 0.0f;
-             pos.x += step.x, pos.y += step.y, pos.z += step.z, travel -= stepSize )
+             pos.x += step.x, pos.y += step.y, pos.z += step.z, travel -= stepSize, ++kStep )
         {
             const f3 texPos = { ( ( pos.x - boxMin.x ) / boxSize.x ) * texSize.x + texMin.x,
                                 ( ( pos.y - boxMin.y ) / boxSize.y ) * texSize.y + texMin.y,
@@ -800,7 +809,7 @@ static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
             float transferFn[4];
             if( j->opt.tieBudget && !j->opt.filter ) /* test instrument, see orc_options */
                 j->opt.tieBudget[pixelPos] += tie_budget( j, texPos, density, multiplyer, addedValue,
-                                                          alphaCorrection, 1.0f - color[3] );
+                                                          alphaCorrection, 1.0f - color[3], kStep, vpw );
             orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, transferFn );
             orc_composite( transferFn, color, alphaCorrection );
             ++nSamples;
@@ -922,8 +931,11 @@ static uint64_t raycast_pixel_gl( const job_t* j, uint32_t x, uint32_t y )
         const f3 texMin = { nodeData->textureMin[0], nodeData->textureMin[1], nodeData->textureMin[2] };
         const f3 texSize = { nodeData->textureSize[0], nodeData->textureSize[1], nodeData->textureSize[2] };
 
+        uint32_t kStep = 0; /* test instrument only (tie budget) */
+        const f3 vpw = { texSize.x * (float)j->atlasDim[0] / boxSize.x, texSize.y * (float)j->atlasDim[1] / boxSize.y,
+                         texSize.z * (float)j->atlasDim[2] / boxSize.z };
         for( float travel = dist; travel > 0.0f;
-             pos.x += step.x, pos.y += step.y, pos.z += step.z, travel -= stepSize )
+             pos.x += step.x, pos.y += step.y, pos.z += step.z, travel -= stepSize, ++kStep )
         {
             const f3 texPos = { ( ( pos.x - boxMin.x ) / boxSize.x ) * texSize.x + texMin.x,
                                 ( ( pos.y - boxMin.y ) / boxSize.y ) * texSize.y + texMin.y,
@@ -934,7 +946,7 @@ static uint64_t raycast_pixel_gl( const job_t* j, uint32_t x, uint32_t y )
             float transferFn[4];
             if( j->opt.tieBudget && !j->opt.filter ) /* test instrument, see orc_options */
                 j->opt.tieBudget[pixelPos] += tie_budget( j, texPos, density, multiplyer, addedValue,
-                                                          alphaCorrection, 1.0f - color[3] );
+                                                          alphaCorrection, 1.0f - color[3], kStep, vpw );
             orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, transferFn );
             orc_composite( transferFn, color, alphaCorrection );
             ++nSamples;
@@ -1135,8 +1147,11 @@ static int integrate_run( const job_t* j, const orc_node_data* nodeData, int lev
     const float inv = 1.0f / dist;
     const f3 step = { diff.x * inv * stepSize, diff.y * inv * stepSize, diff.z * inv * stepSize };
     f3 pos = rayStart;
+    uint32_t kStep = 0; /* test instrument only (tie budget) */
+    const f3 vpw = { texSize.x * (float)j->atlasDim[0] / boxSize.x, texSize.y * (float)j->atlasDim[1] / boxSize.y,
+                     texSize.z * (float)j->atlasDim[2] / boxSize.z };
     for( float travel = dist; travel > 0.0f;
-         pos.x += step.x, pos.y += step.y, pos.z += step.z, travel -= stepSize )
+         pos.x += step.x, pos.y += step.y, pos.z += step.z, travel -= stepSize, ++kStep )
     {
         const f3 texPos = { ( ( pos.x - boxMin.x ) / boxSize.x ) * texSize.x + texMin.x,
                             ( ( pos.y - boxMin.y ) / boxSize.y ) * texSize.y + texMin.y,
@@ -1147,7 +1162,7 @@ static int integrate_run( const job_t* j, const orc_node_data* nodeData, int lev
         float transferFn[4];
         if( j->opt.tieBudget && !j->opt.filter ) /* test instrument, see orc_options */
             j->opt.tieBudget[pixelPos] += tie_budget( j, texPos, density, multiplyer, addedValue,
-                                                      alphaCorrection, 1.0f - color[3] );
+                                                      alphaCorrection, 1.0f - color[3], kStep, vpw );
         orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, transferFn );
         orc_composite( transferFn, color, alphaCorrection );
         ++*nSamples;

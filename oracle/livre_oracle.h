@@ -101,8 +101,9 @@ typedef struct
                       * applied along the ray instead of per brick (raycast_pixel_ray_lod) */
     float lodScreenSpaceError, lodWorldSpacePerPixel; /* SelectVisibles.cpp:57-67 */
     /* TEST INSTRUMENT, not part of the restated algorithm (NULL = off): width*height floats that receive,
-     * per pixel, how much the pixel can change if samples that lie within tieDelta voxels of a voxel face
-     * read the voxel on the other side of that face:
+     * per pixel, how much the pixel can change if samples that lie within tieDelta + k * 2^-25 * (voxels per
+     * world unit) voxels of a voxel face (k = the sample's index in its brick segment: the drift of the
+     * reference's own pos += step chain, half an ulp per addition) read the voxel on the other side of it:
      *     sum over such samples of max_channel |classified(neighbour) - classified(voxel)| * transmittance.
      * The reference puts the first sample of every brick exactly ON a brick face (= a voxel face,
      * Renderer.cu:195-196), so which voxel it reads hangs on the last bit of the coordinate arithmetic;

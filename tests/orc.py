@@ -403,8 +403,9 @@ def world_space_per_pixel(s, top=0.05, bottom=-0.05):
     return (top - bottom) / float(s.H)
 
 
-#: samples within this many voxels of a voxel face count towards a pixel's tie budget (orc_options.tieBudget)
-TIE_DELTA = 2.0 ** -10
+#: samples within this many voxels of a voxel face (+ the drift of the reference's own position chain, see
+#: orc_options.tieBudget) count towards a pixel's tie budget
+TIE_DELTA = 2.0 ** -11
 
 
 def oracle_render(s, frac_bits=8, threads=8, rows=None, fb=None, filter_mode=0, variant=0, ray_lod=None,

@@ -21,8 +21,11 @@ import orc
 # puts the first sample of every brick segment exactly ON a brick face, which is a voxel face
 # (cuda/Renderer.cu:195-196, :208-214), so which of two voxels that sample reads hangs on the last bit of
 # the coordinate arithmetic -- in the reference as much as here.  B sums, over the samples of the ray that lie
-# within 2^-10 voxel of a voxel face, the largest channel difference between the classified sample and
-# the classified neighbour across that face, times the transmittance at the sample.  An outlier pixel is
+# within delta_k of a voxel face, the largest channel difference between the classified sample and the
+# classified neighbour across that face, times the transmittance at the sample.  delta_k = 2^-11 voxel (the
+# coordinate evaluation) + k x 2^-25 world units (the reference's pos += step rounds by up to half an ulp per
+# addition; after k steps of a brick segment its sample sits that far from start + k x step, which is what the
+# fixed-point stepping of the kernel evaluates): 3e-5 voxel per step in a 1024-voxel volume.  An outlier pixel is
 # thus only accepted where the oracle's own arithmetic says a one-voxel flip is possible, and by no more
 # than that flip can make (x 2: the flipped sample's alpha also rescales everything behind it).  Pixels
 # without such samples get the bare E0.  There is no allowance for "a few pixels over the line" any more,
@@ -33,6 +36,11 @@ FUZZ_SCALE = max(1, int(os.environ.get("VRC_FUZZ_SCALE", "1")))
 
 E0 = 5e-5
 TIE_FACTOR = 2.0
+# per-ray LOD (extension, defined by this build's oracle, no reference frame exists): a run ends where the ray
+# leaves a brick; a ray through a brick edge may hop into the neighbouring brick in the kernel and not in
+# the oracle (hop parameters are compared in float on both sides) -- one sample of another brick.  At most
+# this fraction of a frame's pixels may miss the rule for that reason.
+RAY_LOD_ALLOW = 5e-4
 
 # legacy figures, used only by PROPERTY tests that compare two renders of slightly different ray sets
 # (a sub-frustum tile against the crop of the full frame; per-ray LOD runs that start 1 % of a voxel inside a
@@ -120,17 +128,18 @@ def nucleon_scene(viewport=(48, 48), spin=(0.4, 0.3), alpha=0.3):
     return s
 
 
-def assert_parity(got, want, what="", budget=None, e0=E0):
+def assert_parity(got, want, what="", budget=None, e0=E0, allow_frac=0.0):
     """THE parity check (see the head of this file): every pixel within E0 + TIE_FACTOR x its tie budget.
     `want` is an oracle frame (or a row / column slice of one): its budget is looked up; pass `budget`
-    when comparing with a stored copy of an oracle frame (golden fixtures)."""
+    when comparing with a stored copy of an oracle frame (golden fixtures).  allow_frac > 0 only for the
+    per-ray LOD EXTENSION (RAY_LOD_ALLOW below): never for a path the reference has."""
     tb = budget if budget is not None else orc.budget_of(want)
     assert tb is not None, "%s: assert_parity needs an oracle frame (or its budget) to compare with" % what
     mx, mean, over = orc.compare(got, want)
     d = np.abs(got.astype(np.float64) - want.astype(np.float64)).max(axis=-1)
     ex = d - (e0 + TIE_FACTOR * tb.astype(np.float64))
     bad = int((ex > 0).sum())
-    if bad:
+    if bad > allow_frac * d.size:
         y, x = np.unravel_index(int(np.argmax(ex)), ex.shape)
         raise AssertionError(
             "%s: %d of %d pixels differ from the oracle by more than E0 + %g x their tie budget; worst at "

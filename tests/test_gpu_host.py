@@ -85,7 +85,19 @@ def test_lod_cut_mixed_levels_matches_oracle(drv):
         # the driver applies spin after look-at like the oracle helper does
         want, _ = orc.oracle_render(s, threads=8)
         assert st.samples_per_ray == s.render.samplesPerRay
+        # AUTO composites a list of mixed brick sizes in the reference's (centre-distance) order
+        from libre_amd import vrc
         scenes.assert_parity(fb, want, "host lod cut")
+        # the grid walk takes the same samples along the ray instead: the same frame up to the pairs of brick
+        # segments the reference's order swaps (quirk Q6; not a parity statement)
+        app.set_option(vrc.OPT_KERNEL, vrc.KERNEL_GRID_DDA)
+        app.set_option(vrc.OPT_COUNT_SAMPLES, 1)
+        dda, _ = app.render_frame()
+        n_dda = int(app.stats().samples)
+        app.set_option(vrc.OPT_KERNEL, vrc.KERNEL_AUTO)
+        ref, _ = app.render_frame()
+        assert int(app.stats().samples) == n_dda
+        scenes.assert_close_frames(dda, ref, "grid walk vs reference order on a mixed cut")
 
 
 def test_multipass_when_atlas_is_smaller_than_the_frame(drv):
@@ -472,7 +484,7 @@ def test_per_ray_lod_through_the_plugin_matches_the_oracle(drv, seed):
         assert st.samples_per_ray == s.render.samplesPerRay
         want, n_want = orc.oracle_render(s, threads=8, ray_lod=(sse, orc.world_space_per_pixel(s)))
         scenes.assert_parity(fb, want, "seed %d %s eye %r spin %r sse %g levels %r" % (
-            seed, uri, eye, spin, sse, sorted({i & 0xF for i in hierarchy})))
+            seed, uri, eye, spin, sse, sorted({i & 0xF for i in hierarchy})), allow_frac=scenes.RAY_LOD_ALLOW)
         assert abs(int(app.stats().samples) - n_want) <= 5e-4 * n_want + 16
         # fewer samples than the per-brick cut of the same frame costs
         app.set_ray_lod(False)
@@ -513,7 +525,7 @@ def test_per_ray_lod_on_the_uvf_fixture(drv):
             assert s.render.samplesPerRay == st.samples_per_ray
             want, n_want = orc.oracle_render(s, threads=8, ray_lod=(sse, orc.world_space_per_pixel(s)))
             assert want[..., 3].max() > 0.3
-            scenes.assert_parity(fb, want, "uvf per-ray lod sse %g" % sse)
+            scenes.assert_parity(fb, want, "uvf per-ray lod sse %g" % sse, allow_frac=scenes.RAY_LOD_ALLOW)
             assert abs(int(app.stats().samples) - n_want) <= 5e-4 * n_want + 16
 
 

@@ -332,6 +332,30 @@ def test_c2_full_size_rows_of_the_other_modes(vrc):
     assert abs(n_lin - n_gather) <= 2e-4 * n_lin
 
 
+def test_auto_keeps_the_reference_order_for_mixed_brick_sizes(vrc):
+    # a coarse brick among fine ones (an LOD cut): the reference composites in the host's centre-distance
+    # order (cuda/Renderer.cu:172-199, CudaRaycastRenderer.cpp:160-163), which is not a visibility order for
+    # every ray once brick sizes differ; AUTO reproduces it with the literal loop, GRID_DDA walks along the ray
+    vi = orc.mem_volume_info(64, 64, 64, 16)
+    coarse = orc.pack(1, 0, 0, 0)
+    ids = [coarse] + [i for i in orc.leaf_ids(vi) if orc.lib().orc_nodeid_parent(i) != coarse]
+    s = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(96, 80), spin=(0.4, 0.3), ids=ids, volume="hash")
+    want, n_want = orc.oracle_render(s, threads=8)
+    with _gpu(s) as g:
+        auto, n_auto, st = g.render()
+        assert st.kernel_variant == vrc.KERNEL_REFERENCE_ORDER
+        scenes.assert_parity(auto, want, "mixed brick sizes, AUTO")
+        assert n_auto == n_want
+        dda, n_dda, st = g.render(kernel=vrc.KERNEL_GRID_DDA)
+        assert st.kernel_variant == vrc.KERNEL_GRID_DDA and n_dda == n_want  # the same samples ...
+        scenes.assert_close_frames(dda, auto, "grid walk vs reference order")  # ... in along-ray order
+    # bricks of one size: AUTO is the grid walk, and it is the reference's frame
+    s1 = scenes.get("hash64_spin")
+    with _gpu(s1) as g:
+        _, _, st = g.render()
+        assert st.kernel_variant == vrc.KERNEL_GRID_DDA
+
+
 # ---- the judged shape on data that can tell voxels apart -----------------------------------------------
 # BASELINE C2/C4 use block 128 -> slots of 136^3 voxels (17^3 micro-blocks, address tables indexed up to
 # 135).  mem:// bricks are constant including their overlap, so the tests above cannot see a wrong voxel
@@ -631,7 +655,7 @@ def _hierarchy(voxels=(64, 64, 64), block=16, levels=None, **kw):
 
 
 def _lod_parity(got, want, what):
-    scenes.assert_parity(got, want, what)
+    scenes.assert_parity(got, want, what, allow_frac=scenes.RAY_LOD_ALLOW)
 
 
 @pytest.mark.parametrize("sse", [0.5, 1.3, 1.7, 2.5, 6.0])

@@ -10,7 +10,7 @@ import scenes
 
 
 def _parity(got, want, what):
-    scenes.assert_parity(got, want, what)
+    scenes.assert_parity(got, want, what, allow_frac=scenes.RAY_LOD_ALLOW)
 
 
 def _close_to_per_brick(got, want, what):
