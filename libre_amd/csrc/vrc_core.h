@@ -1129,76 +1129,88 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
         const float o[3] = { r.origin.x, r.origin.y, r.origin.z };
         const float d[3] = { r.dir.x, r.dir.y, r.dir.z };
         const float id[3] = { r.invDir.x, r.invDir.y, r.invDir.z };
+        /* Which bricks does the ray meet?  Those of the cells it runs through -- and, where it enters or leaves
+         * a cell through an edge or a corner of the grid (two or three of the entry / exit parameters equal
+         * to within rounding), the bricks of the cells around that edge or corner.  In exact arithmetic the
+         * ray has no extent in those; the reference tests every brick with its float slab test
+         * (Renderer.cu:56-80, :179-181), and one that comes out with tfar a last bit above tnear gets its one
+         * sample (:208).  Handing the same cells to the same arithmetic (vrc_brick_segment) reproduces that,
+         * instead of depending on which of the tied faces this walk happens to cross first: the walk
+         * composites the reference's samples, one for one. */
         int cell[3], stepDir[3];
         float tMax[3], tDelta[3];
+        const float tolE = fabsf( t0 ) * 2e-6f;
+        uint32_t back = 0u; /* axes on whose cell faces the ray is at t0: it also touches the cells behind them */
 #pragma unroll
         for( int a = 0; a < 3; ++a )
         {
             const float p = o[a] + d[a] * t0;
-            int c = (int)floorf( ( p - f.gridMin[a] ) * f.invCellSize[a] );
-            c = c < 0 ? 0 : ( c > f.gridDim[a] - 1 ? f.gridDim[a] - 1 : c );
-            cell[a] = c;
+            const float u = ( p - f.gridMin[a] ) * f.invCellSize[a];
             const bool pos = d[a] > 0.0f;
             stepDir[a] = pos ? 1 : -1;
+            /* on a cell face at t0 (the ray enters the grid through an edge, or starts on a face): the walk
+             * starts in the cell the ray goes on into, so that no cell is left at the parameter it was
+             * entered at */
+            const float kf = rintf( u );
+            const float tFace = ( ( f.gridMin[a] + f.cellSize[a] * kf ) - o[a] ) * id[a];
+            int c = (int)floorf( u );
+            const int cOn = (int)kf - ( pos ? 0 : 1 );
+            if( fabsf( tFace - t0 ) <= tolE && cOn >= 0 && cOn <= f.gridDim[a] - 1 )
+            {
+                c = cOn;
+                back |= 1u << a;
+            }
+            c = c < 0 ? 0 : ( c > f.gridDim[a] - 1 ? f.gridDim[a] - 1 : c );
+            cell[a] = c;
             const float boundary = f.gridMin[a] + f.cellSize[a] * (float)( pos ? c + 1 : c );
             tMax[a] = ( boundary - o[a] ) * id[a];
             tDelta[a] = f.cellSize[a] * fabsf( id[a] );
         }
-        /* nodes already handed to the slab test (a brick is convex: once left it is never entered
-         * again, but a tie probe below, or a coarse brick that spans several cells, meets it twice) */
+        /* bricks already handed to the slab test: a brick is convex, once left it is never entered again,
+         * but a coarse brick that spans several cells is met in each of them */
         int32_t recent[4] = { -1, -1, -1, -1 };
         const int maxSteps = f.gridDim[0] + f.gridDim[1] + f.gridDim[2] + 3;
         bool finished = false;
-        /* cells entered at the ray's first parameter t0 (the first cell, and any cell reached from it
-         * without the parameter moving on) */
-        bool atStart = true;
-        const float tolE = fabsf( t0 ) * 2e-6f;
-        for( int it = 0; it < maxSteps && !finished; ++it )
-        {
-            /* Which bricks does the ray meet at this cell?  The cell's own -- and, where the ray enters or
-             * leaves the cell through an edge or a corner of the grid (two or three of the entry / exit
-             * parameters equal to within rounding), the cells around that edge or corner.  In exact
-             * arithmetic the ray has no extent in those; the reference tests every brick with its float slab
-             * test (Renderer.cu:56-80, :179-181), and one that comes out with tfar a last bit above tnear
-             * gets its one sample (:208).  Handing the same cells to the same arithmetic
-             * (vrc_brick_segment) reproduces that instead of depending on which of the tied faces this
-             * walk happens to cross first: the walk composites the reference's samples, one for one.
-             * Entry side: only for cells entered at t0 -- later cells are entered where the previous
-             * one was left, and that edge was handled there. */
-            const float tNext = fminf( fminf( tMax[0], tMax[1] ), tMax[2] );
-            const float tol = fabsf( tNext ) * 2e-6f;
-            const bool tie0 = tMax[0] <= tNext + tol, tie1 = tMax[1] <= tNext + tol, tie2 = tMax[2] <= tNext + tol;
-            const bool leaves = tNext > t1; /* the ray ends inside this cell */
-            const uint32_t tied = ( tie0 ? 1u : 0u ) | ( tie1 ? 2u : 0u ) | ( tie2 ? 4u : 0u );
-            uint32_t back = 0u;
-            if( atStart )
-                back = ( fabsf( ( tMax[0] - tDelta[0] ) - t0 ) <= tolE ? 1u : 0u ) |
-                       ( fabsf( ( tMax[1] - tDelta[1] ) - t0 ) <= tolE ? 2u : 0u ) |
-                       ( fabsf( ( tMax[2] - tDelta[2] ) - t0 ) <= tolE ? 4u : 0u );
-            /* work list, one bit per candidate cell, in the order they are met:
-             *   bits 0-6   cell - (subset of the entry-tied axes): subsets 7, 3, 5, 6, 1, 2, 4
-             *   bit  7     the cell
-             *   bits 8-13  cell + (proper subset of the exit-tied axes): subsets 1, 2, 4, 3, 5, 6
-             * the tables below hold, per 3-bit axis set, the bits whose subset lies inside it */
-            const bool multi = !leaves && ( tied & ( tied - 1u ) ) != 0u;
-            uint32_t pending = 0x80u;
-            bool plain = back == 0u && !multi; /* nothing but the cell itself: almost always */
-#if defined( __HIP_DEVICE_COMPILE__ )
-            /* wave-uniform: the short path only when no lane of the wave has a tie at this step */
-            plain = __builtin_amdgcn_ballot_w64( !plain ) == 0ull;
-#endif
-            if( !plain )
+        auto visit = [&]( int cx, int cy, int cz ) {
+            const int32_t node = gridTable[( cz * f.gridDim[1] + cy ) * f.gridDim[0] + cx];
+            if( node < 0 || node == recent[0] || node == recent[1] || node == recent[2] || node == recent[3] )
+                return;
+            recent[3] = recent[2];
+            recent[2] = recent[1];
+            recent[1] = recent[0];
+            recent[0] = node;
+            const vrc_dev_node n = nodes[node];
+            vrc_segment s;
+            bool stop;
+            if( vrc_brick_segment( f, r, n, f.stepSize, &s, &stop ) )
             {
-                pending |= (uint32_t)( ( 0x7F68544032201000ull >> ( back * 8u ) ) & 0x7Fu );
+                if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >( f, n, s, atlas, lut, cls, color,
+                                                                             nSamples ) )
+                    finished = true;
+            }
+            else if( stop )
+                finished = true;
+        };
+        /* work list of the cells around an edge / corner, one bit per cell, in the order they are met:
+         *   bits 0-6   cell - (subset of the entry-tied axes): subsets 7, 3, 5, 6, 1, 2, 4
+         *   bits 8-13  cell + (proper subset of the exit-tied axes): subsets 1, 2, 4, 3, 5, 6
+         * the 64-bit constants hold, per 3-bit axis set, the bits whose subset lies inside it */
+        uint32_t pending = (uint32_t)( ( 0x7F68544032201000ull >> ( back * 8u ) ) & 0x7Fu );
+        uint32_t tied = 0u; /* axes whose faces the ray leaves the current cell through */
+        bool multi = false; /* more than one of them */
+        for( int it = 0; it < maxSteps; ++it )
+        {
+            /* rare, and taken by the whole wave or not at all: the cells around the edge / corner the ray
+             * entered the first cell through (first iteration) or left the last cell through */
+            bool rare = pending != 0u || multi;
+#if defined( __HIP_DEVICE_COMPILE__ )
+            rare = __builtin_amdgcn_ballot_w64( rare ) != 0ull;
+#endif
+            if( rare )
+            {
                 if( multi )
                     pending |= (uint32_t)( ( 0x3F06050003000000ull >> ( tied * 8u ) ) & 0x3Fu ) << 8;
-            }
-            while( pending != 0u && !finished )
-            {
-                int cx = cell[0], cy = cell[1], cz = cell[2];
-                if( plain )
-                    pending = 0u;
-                else
+                while( pending != 0u && !finished )
                 {
 #if defined( __HIP_DEVICE_COMPILE__ )
                     const uint32_t slot = (uint32_t)__builtin_ctz( pending );
@@ -1209,50 +1221,30 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
 #endif
                     pending &= pending - 1u;
                     const uint32_t sub = slot < 7u ? ( 0x4216537u >> ( slot * 4u ) ) & 7u
-                                                   : ( slot == 7u ? 0u : ( 0x653421u >> ( ( slot - 8u ) * 4u ) ) & 7u );
+                                                   : ( 0x653421u >> ( ( slot - 8u ) * 4u ) ) & 7u;
                     const int sgn = slot < 7u ? -1 : 1;
-                    cx += ( sub & 1u ) ? sgn * stepDir[0] : 0;
-                    cy += ( sub & 2u ) ? sgn * stepDir[1] : 0;
-                    cz += ( sub & 4u ) ? sgn * stepDir[2] : 0;
-                    if( cx < 0 || cx >= f.gridDim[0] || cy < 0 || cy >= f.gridDim[1] || cz < 0 || cz >= f.gridDim[2] )
-                        continue;
+                    const int cx = cell[0] + ( ( sub & 1u ) ? sgn * stepDir[0] : 0 );
+                    const int cy = cell[1] + ( ( sub & 2u ) ? sgn * stepDir[1] : 0 );
+                    const int cz = cell[2] + ( ( sub & 4u ) ? sgn * stepDir[2] : 0 );
+                    if( cx >= 0 && cx < f.gridDim[0] && cy >= 0 && cy < f.gridDim[1] && cz >= 0 && cz < f.gridDim[2] )
+                        visit( cx, cy, cz );
                 }
-                const int32_t node = gridTable[( cz * f.gridDim[1] + cy ) * f.gridDim[0] + cx];
-                /* a brick is convex: once left it is never entered again, but the work list (or a coarse
-                 * brick that spans several cells) meets it more than once */
-                if( node < 0 || node == recent[0] || node == recent[1] || node == recent[2] || node == recent[3] )
-                    continue;
-                recent[3] = recent[2];
-                recent[2] = recent[1];
-                recent[1] = recent[0];
-                recent[0] = node;
-                const vrc_dev_node n = nodes[node];
-                vrc_segment s;
-                bool stop;
-                if( vrc_brick_segment( f, r, n, f.stepSize, &s, &stop ) )
-                {
-                    if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >( f, n, s, atlas, lut, cls,
-                                                                                 color, nSamples ) )
-                        finished = true;
-                }
-                else if( stop )
-                    finished = true;
+                pending = 0u;
             }
-            if( finished || leaves )
+            if( finished )
                 break;
-            atStart = atStart && tNext <= t0 + tolE;
-            /* advance through every tied face at once */
-            if( tie0 )
+            /* through every tied face at once */
+            if( tied & 1u )
             {
                 cell[0] += stepDir[0];
                 tMax[0] += tDelta[0];
             }
-            if( tie1 )
+            if( tied & 2u )
             {
                 cell[1] += stepDir[1];
                 tMax[1] += tDelta[1];
             }
-            if( tie2 )
+            if( tied & 4u )
             {
                 cell[2] += stepDir[2];
                 tMax[2] += tDelta[2];
@@ -1260,6 +1252,15 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
             if( cell[0] < 0 || cell[0] >= f.gridDim[0] || cell[1] < 0 || cell[1] >= f.gridDim[1] ||
                 cell[2] < 0 || cell[2] >= f.gridDim[2] )
                 break;
+            visit( cell[0], cell[1], cell[2] );
+            if( finished )
+                break;
+            const float tNext = fminf( fminf( tMax[0], tMax[1] ), tMax[2] );
+            if( tNext > t1 ) /* the ray ends inside this cell */
+                break;
+            const float thr = tNext + fabsf( tNext ) * 2e-6f;
+            tied = ( tMax[0] <= thr ? 1u : 0u ) | ( tMax[1] <= thr ? 2u : 0u ) | ( tMax[2] <= thr ? 4u : 0u );
+            multi = ( tied & ( tied - 1u ) ) != 0u;
         }
     }
     pixelBuffer[pixelPos] = color;

@@ -196,6 +196,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
     int cell[3] = { 0, 0, 0 }, stepDir[3] = { 1, 1, 1 };
     float tMax[3] = { 0.f, 0.f, 0.f }, tDelta[3] = { 0.f, 0.f, 0.f };
     float t0 = 0.0f, t1 = 0.0f;
+    uint32_t back = 0u;
     bool ddaEnd = false;
     if( !done )
     {
@@ -220,15 +221,27 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
             const float o[3] = { r.origin.x, r.origin.y, r.origin.z };
             const float d[3] = { r.dir.x, r.dir.y, r.dir.z };
             const float id[3] = { r.invDir.x, r.invDir.y, r.invDir.z };
+            /* as vrc_pixel_grid_dda (vrc_core.h): on a cell face at t0 the walk starts in the cell the ray
+             * goes on into; `back` = the axes of those faces (the cells behind them are touched too) */
+            const float tolE = fabsf( t0 ) * 2e-6f;
 #pragma unroll
             for( int a = 0; a < 3; ++a )
             {
                 const float p = o[a] + d[a] * t0;
-                int c = (int)floorf( ( p - f.gridMin[a] ) * f.invCellSize[a] );
-                c = c < 0 ? 0 : ( c > f.gridDim[a] - 1 ? f.gridDim[a] - 1 : c );
-                cell[a] = c;
+                const float u = ( p - f.gridMin[a] ) * f.invCellSize[a];
                 const bool pos = d[a] > 0.0f;
                 stepDir[a] = pos ? 1 : -1;
+                const float kf = rintf( u );
+                const float tFace = ( ( f.gridMin[a] + f.cellSize[a] * kf ) - o[a] ) * id[a];
+                int c = (int)floorf( u );
+                const int cOn = (int)kf - ( pos ? 0 : 1 );
+                if( fabsf( tFace - t0 ) <= tolE && cOn >= 0 && cOn <= f.gridDim[a] - 1 )
+                {
+                    c = cOn;
+                    back |= 1u << a;
+                }
+                c = c < 0 ? 0 : ( c > f.gridDim[a] - 1 ? f.gridDim[a] - 1 : c );
+                cell[a] = c;
                 const float boundary = f.gridMin[a] + f.cellSize[a] * (float)( pos ? c + 1 : c );
                 tMax[a] = ( boundary - o[a] ) * id[a];
                 tDelta[a] = f.cellSize[a] * fabsf( id[a] );
@@ -242,8 +255,11 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
     /* bricks already handed to the slab test; probe: what the walk does next at its cell (0: the cell
      * itself, 1..6: the cells around an edge / corner the ray leaves through, see vrc_pixel_grid_dda) */
     int32_t recent0 = -1, recent1 = -1, recent2 = -1, recent3 = -1;
-    uint32_t pending = 0u; /* work list of the cell the walk stands in (0: not drawn up yet) */
-    bool listed = false, atStart = true;
+    /* work list of cells around an edge / corner (encoding: vrc_pixel_grid_dda), the faces the ray leaves
+     * the current cell through, and whether the step through them is still to be taken */
+    uint32_t pending = (uint32_t)( ( 0x7F68544032201000ull >> ( back * 8u ) ) & 0x7Fu );
+    uint32_t tied = 0u;
+    bool needAdvance = false;
     uint32_t fx = 0, fy = 0, fz = 0, fdx = 0, fdy = 0, fdz = 0; /* 8.24 slot-local voxel */
     float travel = 0.0f;
     uint32_t laneSlotBase = 0;
@@ -284,40 +300,68 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
                     done = true;
                 else
                 {
-                    /* the walk of vrc_pixel_grid_dda (vrc_core.h), one candidate cell per iteration: the
-                     * cells around an edge / corner the ray enters through (cells entered at t0 only), the
-                     * cell, the cells around an edge / corner it leaves through, then the step through
-                     * every tied face.  Same work-list encoding as there. */
-                    const float tNext = fminf( fminf( tMax[0], tMax[1] ), tMax[2] );
-                    const float tol = fabsf( tNext ) * 2e-6f;
-                    const bool tie0 = tMax[0] <= tNext + tol, tie1 = tMax[1] <= tNext + tol,
-                               tie2 = tMax[2] <= tNext + tol;
-                    const bool leaves = tNext > t1;
-                    const float tolE = fabsf( t0 ) * 2e-6f;
-                    if( !listed )
+                    /* the walk of vrc_pixel_grid_dda (vrc_core.h), one candidate cell per iteration: the cells
+                     * around the edge / corner the ray entered the first cell through or left the last cell
+                     * through, then the step through every tied face and the cell behind it */
+                    int cx = cell[0], cy = cell[1], cz = cell[2];
+                    bool look = false, endAfter = false;
+                    if( pending != 0u )
                     {
-                        const uint32_t tied = ( tie0 ? 1u : 0u ) | ( tie1 ? 2u : 0u ) | ( tie2 ? 4u : 0u );
-                        uint32_t back = 0u;
-                        if( atStart )
-                            back = ( fabsf( ( tMax[0] - tDelta[0] ) - t0 ) <= tolE ? 1u : 0u ) |
-                                   ( fabsf( ( tMax[1] - tDelta[1] ) - t0 ) <= tolE ? 2u : 0u ) |
-                                   ( fabsf( ( tMax[2] - tDelta[2] ) - t0 ) <= tolE ? 4u : 0u );
-                        pending = 0x80u | (uint32_t)( ( 0x7F68544032201000ull >> ( back * 8u ) ) & 0x7Fu );
-                        if( !leaves && ( tied & ( tied - 1u ) ) != 0u )
-                            pending |= (uint32_t)( ( 0x3F06050003000000ull >> ( tied * 8u ) ) & 0x3Fu ) << 8;
-                        listed = true;
+                        const uint32_t slot = (uint32_t)__builtin_ctz( pending );
+                        pending &= pending - 1u;
+                        const uint32_t sub = slot < 7u ? ( 0x4216537u >> ( slot * 4u ) ) & 7u
+                                                       : ( 0x653421u >> ( ( slot - 8u ) * 4u ) ) & 7u;
+                        const int sgn = slot < 7u ? -1 : 1;
+                        cx += ( sub & 1u ) ? sgn * stepDir[0] : 0;
+                        cy += ( sub & 2u ) ? sgn * stepDir[1] : 0;
+                        cz += ( sub & 4u ) ? sgn * stepDir[2] : 0;
+                        look = cx >= 0 && cx < f.gridDim[0] && cy >= 0 && cy < f.gridDim[1] && cz >= 0 &&
+                               cz < f.gridDim[2];
                     }
-                    const uint32_t slot = (uint32_t)__builtin_ctz( pending );
-                    pending &= pending - 1u;
-                    const uint32_t sub = slot < 7u ? ( 0x4216537u >> ( slot * 4u ) ) & 7u
-                                                   : ( slot == 7u ? 0u : ( 0x653421u >> ( ( slot - 8u ) * 4u ) ) & 7u );
-                    const int sgn = slot < 7u ? -1 : 1;
-                    const int cx = cell[0] + ( ( sub & 1u ) ? sgn * stepDir[0] : 0 );
-                    const int cy = cell[1] + ( ( sub & 2u ) ? sgn * stepDir[1] : 0 );
-                    const int cz = cell[2] + ( ( sub & 4u ) ? sgn * stepDir[2] : 0 );
-                    const bool inside = cx >= 0 && cx < f.gridDim[0] && cy >= 0 && cy < f.gridDim[1] && cz >= 0 &&
-                                        cz < f.gridDim[2];
-                    const int32_t node = inside ? gridTable[( cz * f.gridDim[1] + cy ) * f.gridDim[0] + cx] : -1;
+                    else
+                    {
+                        if( needAdvance )
+                        {
+                            if( tied & 1u )
+                            {
+                                cell[0] += stepDir[0];
+                                tMax[0] += tDelta[0];
+                            }
+                            if( tied & 2u )
+                            {
+                                cell[1] += stepDir[1];
+                                tMax[1] += tDelta[1];
+                            }
+                            if( tied & 4u )
+                            {
+                                cell[2] += stepDir[2];
+                                tMax[2] += tDelta[2];
+                            }
+                            needAdvance = false;
+                            ddaEnd = cell[0] < 0 || cell[0] >= f.gridDim[0] || cell[1] < 0 ||
+                                     cell[1] >= f.gridDim[1] || cell[2] < 0 || cell[2] >= f.gridDim[2];
+                        }
+                        if( !ddaEnd )
+                        {
+                            cx = cell[0];
+                            cy = cell[1];
+                            cz = cell[2];
+                            look = true;
+                            const float tNext = fminf( fminf( tMax[0], tMax[1] ), tMax[2] );
+                            if( tNext > t1 )
+                                endAfter = true; /* the ray ends inside this cell */
+                            else
+                            {
+                                const float thr = tNext + fabsf( tNext ) * 2e-6f;
+                                tied = ( tMax[0] <= thr ? 1u : 0u ) | ( tMax[1] <= thr ? 2u : 0u ) |
+                                       ( tMax[2] <= thr ? 4u : 0u );
+                                if( ( tied & ( tied - 1u ) ) != 0u )
+                                    pending = (uint32_t)( ( 0x3F06050003000000ull >> ( tied * 8u ) ) & 0x3Fu ) << 8;
+                                needAdvance = true;
+                            }
+                        }
+                    }
+                    const int32_t node = look ? gridTable[( cz * f.gridDim[1] + cy ) * f.gridDim[0] + cx] : -1;
                     if( node >= 0 && node != recent0 && node != recent1 && node != recent2 && node != recent3 )
                     {
                         recent3 = recent2;
@@ -351,33 +395,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
                         else if( stop )
                             done = true;
                     }
-                    if( !done && pending == 0u )
-                    {
-                        listed = false;
-                        atStart = atStart && tNext <= t0 + tolE;
-                        if( leaves )
-                            ddaEnd = true;
-                        else
-                        {
-                            if( tie0 )
-                            {
-                                cell[0] += stepDir[0];
-                                tMax[0] += tDelta[0];
-                            }
-                            if( tie1 )
-                            {
-                                cell[1] += stepDir[1];
-                                tMax[1] += tDelta[1];
-                            }
-                            if( tie2 )
-                            {
-                                cell[2] += stepDir[2];
-                                tMax[2] += tDelta[2];
-                            }
-                            ddaEnd = cell[0] < 0 || cell[0] >= f.gridDim[0] || cell[1] < 0 ||
-                                     cell[1] >= f.gridDim[1] || cell[2] < 0 || cell[2] >= f.gridDim[2];
-                        }
-                    }
+                    if( endAfter )
+                        ddaEnd = true;
                 }
             }
         }

@@ -427,6 +427,7 @@ typedef struct
 {
     float d;
     uint64_t id;
+    uint32_t index; /* position in the caller's list */
 } sort_item;
 
 static int cmp_sort_item( const void* a, const void* b )
@@ -435,10 +436,11 @@ static int cmp_sort_item( const void* a, const void* b )
     const sort_item* y = (const sort_item*)b;
     if( x->d < y->d ) return -1;
     if( x->d > y->d ) return 1;
-    /* std::sort is not stable; ties (equal centre distance) are ordered by id here so the
-     * oracle is deterministic.  Bricks at equal distance never share a ray prefix order
-     * dependency in a regular grid. */
-    return x->id < y->id ? -1 : ( x->id > y->id ? 1 : 0 );
+    /* std::sort (CudaRaycastRenderer.cpp:160-163) leaves the order of bricks at equal centre distance
+     * to the library; here they keep the order of the caller's list, which makes the oracle
+     * deterministic and lets a test hand over the list exactly as a host produced it.  In a regular
+     * grid bricks at equal distance share a ray only where it runs along their common face. */
+    return x->index < y->index ? -1 : ( x->index > y->index ? 1 : 0 );
 }
 
 void orc_sort_nodes_front_to_back( const orc_volume_info* info, const float mv[16],
@@ -451,6 +453,7 @@ void orc_sort_nodes_front_to_back( const orc_volume_info* info, const float mv[1
         orc_lod_node_from_id( info, ids[i], &node );
         items[i].d = orc_node_distance( mv, &node );
         items[i].id = ids[i];
+        items[i].index = i;
     }
     qsort( items, n, sizeof( sort_item ), cmp_sort_item );
     for( uint32_t i = 0; i < n; ++i )

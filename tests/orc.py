@@ -70,20 +70,24 @@ def build_harness(sanitize=False):
         # contraction "fast" but honouring the pragmas in vrc_core.h (hipcc's default mode)
         out = os.path.join(HARNESS_DIR, "libharness_fma.so")
         src = os.path.join(HARNESS_DIR, "harness.cpp")
+        tmp = "%s.%d.tmp" % (out, os.getpid())  # several test workers may build at once: rename is atomic
         subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-O2", "-std=c++17", "-fPIC",
                                "-shared", "-mfma", "-ffp-contract=fast-honor-pragmas",
-                               "-Wno-unknown-pragmas", "-o", out, src])
+                               "-Wno-unknown-pragmas", "-o", tmp, src])
+        os.replace(tmp, out)
         return out
     out = HARNESS_SO if not sanitize else os.path.join(HARNESS_DIR, "libharness_asan.so")
     src = os.path.join(HARNESS_DIR, "harness.cpp")
     deps = [src] + [os.path.join(ROOT, "libre_amd", "csrc", f) for f in ("vrc_core.h", "vrc_tables.h")]
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
+    tmp = "%s.%d.tmp" % (out, os.getpid())  # several test workers may build at once: rename is atomic
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wno-unknown-pragmas", "-o", out, src]
+           "-Wno-unknown-pragmas", "-o", tmp, src]
     if sanitize:
         cmd[1:1] = ["-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
     subprocess.check_call(cmd)
+    os.replace(tmp, out)
     return out
 
 
