@@ -90,6 +90,11 @@ int lvh_app_volume_info( lvh_app* app, uint32_t voxels[3], uint32_t max_block[3]
                          uint32_t overlap[3], float world_size[3], uint32_t* depth,
                          uint32_t root_blocks[3] );
 int lvh_app_visible_set( lvh_app* app, uint64_t* ids, size_t capacity, size_t* n );
+/* ids of the bricks of the last (pass of the last) frame in the order the renderer handed them to the device
+ * layer: front to back by box-centre distance (CudaRaycastRenderer.cpp:160-163).  Bricks at (nearly) equal
+ * distance come in an order the reference leaves to std::sort and to the rounding of vmmlib's transform;
+ * tests hand this list to the oracle instead of re-deriving it. */
+int lvh_app_node_order( lvh_app* app, uint64_t* ids, size_t cap, size_t* n );
 int lvh_app_view_matrices( lvh_app* app, float mv[16], float proj[16] );
 int lvh_app_cache_stats( lvh_app* app, uint64_t tex[4], uint64_t data[4] ); /* used, max, count, misses */
 /* standalone LOD cut with explicit matrices (tests/lib/lodSelection.cpp harness) */

@@ -29,7 +29,7 @@ EXPORTS = [
     "lvh_app_set_modelview", "lvh_app_set_colormap", "lvh_app_set_clip_planes",
     "lvh_app_set_bands", "lvh_app_set_frames_in_flight", "lvh_app_select_slot", "lvh_app_set_option", "lvh_app_set_data_range", "lvh_app_set_ray_lod", "lvh_app_set_stream", "lvh_app_set_framebuffer", "lvh_app_render_frame",
     "lvh_app_get_stats", "lvh_app_wait_uploads", "lvh_app_synchronize", "lvh_app_volume_info",
-    "lvh_app_visible_set", "lvh_app_view_matrices", "lvh_app_cache_stats", "lvh_select_visibles",
+    "lvh_app_visible_set", "lvh_app_node_order", "lvh_app_view_matrices", "lvh_app_cache_stats", "lvh_select_visibles",
     "lvh_selftest_cache", "lvh_selftest_plugin_factory", "lvh_selftest_camera",
     "lvh_selftest_clip_planes", "lvh_selftest_renderer_parameters",
     "lvh_datasource_brick", "lvh_datasource_info", "lvh_datasource_node",
@@ -69,6 +69,7 @@ def load_library():
     L.lvh_app_volume_info.argtypes = [vp, C.c_uint32 * 3, C.c_uint32 * 3, C.c_uint32 * 3,
                                       C.c_float * 3, C.POINTER(C.c_uint32), C.c_uint32 * 3]
     L.lvh_app_visible_set.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
+    L.lvh_app_node_order.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
     L.lvh_app_view_matrices.argtypes = [vp, C.c_float * 16, C.c_float * 16]
     L.lvh_app_cache_stats.argtypes = [vp, C.c_uint64 * 4, C.c_uint64 * 4]
     L.lvh_select_visibles.argtypes = [C.c_char_p, C.c_float * 16, C.c_float * 16, C.c_uint32,
@@ -183,6 +184,14 @@ class App:
         check(self.L, self.L.lvh_app_visible_set(self.h, None, 0, C.byref(n)))
         ids = (C.c_uint64 * max(1, n.value))()
         check(self.L, self.L.lvh_app_visible_set(self.h, ids, n.value, C.byref(n)))
+        return list(ids)[:n.value]
+
+    def node_order(self):
+        """ids of the bricks of the last frame in the renderer's front-to-back order."""
+        n = C.c_size_t()
+        check(self.L, self.L.lvh_app_node_order(self.h, None, 0, C.byref(n)))
+        ids = (C.c_uint64 * max(1, n.value))()
+        check(self.L, self.L.lvh_app_node_order(self.h, ids, n.value, C.byref(n)))
         return list(ids)[:n.value]
 
     def view_matrices(self):

@@ -90,6 +90,9 @@ public:
     uint32_t getComputedSamplesPerRay() const { return _computedSamplesPerRay; }
     /** the last render() went through the per-ray LOD kernel (false: per-brick cut) */
     bool lastRenderUsedRayLOD() const { return _lastRayLod; }
+    /** ids of the bricks of the last render() in the order the node table was handed to the device layer
+     *  (front to back by box-centre distance, CudaRaycastRenderer.cpp:160-163) */
+    const std::vector< Identifier >& lastNodeOrder() const { return _sortedIds; }
 
 private:
     vrc_ctx* _ctx;

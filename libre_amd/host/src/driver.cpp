@@ -357,6 +357,17 @@ int lvh_app_visible_set( lvh_app* app, uint64_t* ids, size_t cap, size_t* n )
     }
 }
 
+int lvh_app_node_order( lvh_app* app, uint64_t* ids, size_t cap, size_t* n )
+{
+    if( !app ) return fail( "NULL argument" );
+    const std::vector< Identifier >& order = app->renderer().lastNodeOrder();
+    if( n ) *n = order.size();
+    if( ids )
+        for( size_t i = 0; i < order.size() && i < cap; ++i )
+            ids[i] = order[i];
+    return 0;
+}
+
 int lvh_app_view_matrices( lvh_app* app, float mv[16], float proj[16] )
 {
     if( !app ) return fail( "NULL argument" );

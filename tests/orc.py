@@ -286,7 +286,7 @@ class Scene:
 def build_scene(voxels=(64, 64, 64), block=16, viewport=(64, 64), spr=0, alpha=0.05,
                 spin=(0.0, 0.0), volume="mem", max_slots=None, planes=None, ids=None,
                 tile=None, eye=(0.0, 0.0, 1.5), max_tex3d=4096, pad8=True, dtype="u8",
-                data_range=None):
+                data_range=None, order=None):
     """Everything the integrator needs, derived through the oracle's restatement of the
     reference host code.  `pad8`: slot = maxBlock rounded up to 8 (the HIP atlas layout)."""
     L = lib()
@@ -367,6 +367,14 @@ def build_scene(voxels=(64, 64, 64), block=16, viewport=(64, 64), spr=0, alpha=0
     ids_arr = (C.c_uint64 * n)(*s.ids)
     L.orc_sort_nodes_front_to_back(C.byref(vi), s.mv, ids_arr, n)
     s.sorted_ids = list(ids_arr)
+    if order is not None:
+        # a host's own front-to-back list (bricks at nearly equal centre distance come in an order the
+        # reference leaves to std::sort and to the rounding of vmmlib's transform): take it as it is, after
+        # checking that it IS a front-to-back order of the oracle's distances up to that rounding
+        assert sorted(order) == sorted(s.ids)
+        dist = [float(L.orc_node_distance(s.mv, C.byref(s.lod[i]))) for i in order]
+        assert all(b >= a - 1e-5 * max(1.0, a) for a, b in zip(dist, dist[1:])), "not a front-to-back order"
+        s.sorted_ids = list(order)
     s.nodes = (NodeData * n)()
     for k, nid in enumerate(s.sorted_ids):
         node = s.lod[nid]

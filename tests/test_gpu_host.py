@@ -81,7 +81,7 @@ def test_lod_cut_mixed_levels_matches_oracle(drv):
         fb, st = app.render_frame()
         assert st.n_available == len(ids)
         s = orc.build_scene(voxels=(128, 128, 128), block=16, viewport=(64, 64), ids=ids,
-                            spin=(0.3, 0.2), eye=(0.2, 0.1, 0.9))
+                            spin=(0.3, 0.2), eye=(0.2, 0.1, 0.9), order=app.node_order())
         # the driver applies spin after look-at like the oracle helper does
         want, _ = orc.oracle_render(s, threads=8)
         assert st.samples_per_ray == s.render.samplesPerRay
@@ -377,13 +377,16 @@ def test_random_lod_cuts_through_the_plugin_match_the_oracle(drv, seed):
         if not ids:
             assert (fb == 0).all()
             return
+        # the oracle renders the plugin's own front-to-back list (checked to be one): with bricks of mixed
+        # sizes the order is part of the result (quirk Q6), and the order of bricks at nearly equal centre
+        # distance hangs on the last bit of the host's transform
         s = orc.build_scene(voxels=(vox, vox, vox), block=block, viewport=(W, H), ids=ids, spin=spin, eye=eye,
-                            volume=volume, alpha=0.3)
+                            volume=volume, alpha=0.3, order=app.node_order())
         want, n_want = orc.oracle_render(s, threads=8)
         assert st.samples_per_ray == s.render.samplesPerRay
         scenes.assert_parity(fb, want, "seed %d %s eye %r spin %r sse %g levels %r" % (
             seed, uri, eye, spin, sse, sorted({i & 0xF for i in ids})))
-        assert abs(int(app.stats().samples) - n_want) <= 5e-4 * n_want + 16
+        assert int(app.stats().samples) == n_want
 
 
 @pytest.mark.parametrize("seed", range(8 * scenes.FUZZ_SCALE))
