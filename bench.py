@@ -6,9 +6,11 @@ One "step" = one frame: RenderPipeline("hip")::render with every brick resident 
 atlas (steady state; the first, uploading frame is reported separately and never timed), i.e.
 pre-render (clear) -> node-table/LUT reuse -> raycast kernel -> post-render.  The product path
 is C++ host (libre_amd/host) -> C ABI (include/vrc_hip.h) -> gfx950 kernels; Python only
-parses flags, barriers and prints.  N > 1: sort-first screen tiles, one process per GPU
-(torch.distributed over RCCL), every rank holds the whole volume, tiles are gathered to rank 0
-each frame inside the timed region.
+parses flags, barriers and prints.  N > 1: sort-first screen tiles, one process per GPU, every rank
+holds the whole volume, tiles go to rank 0 over RCCL/xGMI inside the timed region through the C ABI's
+vrc_gather_tiles (torch.distributed is the control plane only: barrier, timing, the communicator id).
+Started by a launcher (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) the process is one
+rank; started plainly with --gpus N > 1 it starts the N ranks itself, before it touches a GPU.
 
 Prints ONE JSON line (rank 0).  `roofline` is the HBM roofline of the raycast kernel with the
 algorithmic bytes of SURVEY.md 8(d); `cpu_baseline` times the CPU oracle (oracle/, "port") on a
@@ -51,8 +53,11 @@ def parse():
                     help="N>1: frames per RCCL gather (sortfirst.BatchedTileGather); 0 = auto: 3 when every rank "
                          "has the same number of rows, else 1 (one gather per frame, sortfirst.TileGather)")
     ap.add_argument("--check-frames", action="store_true",
-                    help="N>1: after the timing, compare the last assembled frame on rank 0 with the full frame "
-                         "rendered by one application (must be bit-identical)")
+                    help="(always on for N>1) after the timing, compare the last assembled frame on rank 0 with the "
+                         "full frame rendered by one application (must be bit-identical)")
+    ap.add_argument("--gather", choices=["abi", "torch"], default="abi",
+                    help="N>1: who moves the tiles: abi = vrc_gather_tiles (RCCL behind the C ABI, the product path); "
+                         "torch = torch.distributed.gather (the round-1 path, kept as a cross-check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the trilinear-extension measurement")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
@@ -90,12 +95,51 @@ def cpu_baseline(a, samples_gpu_frame):
                                                         samples_gpu_frame, dt)}
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here.  This process never
+    initialises a GPU (torch.cuda.device_count() does not, on this image); the ranks are fresh processes."""
+    import socket
+    import subprocess
+    import torch
+    n_dev = torch.cuda.device_count()
+    if "BENCH_FORCE_DEVICE" not in os.environ and n_dev < a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (a.gpus, n_dev))
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for pr in list(alive):
+            code = pr.poll()
+            if code is None:
+                continue
+            alive.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in alive:  # one rank failed: the others would wait for it forever
+                    other.terminate()
+    return rc
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
+        if world > 1 or a.gpus > 1:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: using the launcher's world\n" % (a.gpus, world))
         a.gpus = world
 
     import numpy as np
@@ -111,12 +155,35 @@ def main():
         local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
+    data_group = None  # torch.distributed group that moves tiles (--gather torch, or the fallback)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # control plane: barrier, max-over-ranks of the timing, the communicator id.  CPU tensors over gloo.
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == a.gpus == world, (dist.get_world_size(), a.gpus, world)
+
+    def make_data_group():
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+            return dist.new_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        return dist.group.WORLD  # rehearsal on one card: gloo moves the tiles too
+
+    def all_max(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_sum(x):
+        t = torch.tensor([x], dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(t)
+        return int(t.item())
+
+    def all_ok(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
 
     W = H = a.viewport
     uri = "mem://#%d,%d,%d,%d" % (a.voxels, a.voxels, a.voxels, a.block)
@@ -124,29 +191,13 @@ def main():
     bands = layout[rank]
     rows = sum(h for _, h in bands)
     K = a.frames_in_flight if a.frames_in_flight > 0 else (1 if world == 1 else 3)
-    # N>1: B frames share one gather (a collective costs its host issue time whatever it carries, and at
+    # N>1: B frames share one exchange (a collective costs its host issue time whatever it carries, and at
     # 8 ranks a rank's share of a frame is ~60 us of kernel); 2B renderer slots: batch n+1 is
     # rendered while batch n is on the wire
     equal_rows = len({sum(h for _, h in b) for b in layout}) == 1
-    B = a.gather_batch if a.gather_batch > 0 else (3 if (world > 1 and equal_rows) else 1)
-    if world == 1 or not equal_rows:
+    B = a.gather_batch if a.gather_batch > 0 else (3 if world > 1 else 1)
+    if world == 1:
         B = 1
-    batched = world > 1 and B > 1
-    if batched:
-        K = 2 * B
-    a.warmup = max(a.warmup, K)
-    # per in-flight frame: a pixel buffer of this rank's stacked bands (device memory owned by
-    # torch), a stream and a tile-gather buffer set
-    bgather = sortfirst.BatchedTileGather(layout, W, rank, "cuda", B) if batched else None
-    if batched:
-        fbs = [bgather.send[k // B, k % B] for k in range(K)]
-    else:
-        fbs = [torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(K)]
-    streams = [torch.cuda.Stream() for _ in range(K)]
-    gstream = torch.cuda.Stream() if batched else None
-    rendered = [torch.cuda.Event() for _ in range(K)] if batched else None
-    consumed = [None, None]  # per half: event after the gather that last read it
-
     # leaves only: --min-lod = --max-lod = depth-1 (BASELINE.md "single LOD")
     probe = driver.App(uri, W, H, device=local_rank)
     depth = probe.volume_info()["depth"]
@@ -164,12 +215,64 @@ def main():
         app.set_bands(bands)
     app.set_camera(spin=tuple(a.spin))
     app.set_colormap(linear_ramp(a.alpha))
+
+    # ---- who moves the tiles -------------------------------------------------------------------------
+    # abi: vrc_gather_tiles behind the C ABI (RCCL sends/receives straight into the frame); checked once on a
+    # known pattern before it is trusted.  torch: torch.distributed.gather + a placement copy (round 1).
+    gather_kind, gather_note = ("none", None) if world == 1 else (a.gather, None)
+    bgather = None
+    if world > 1 and gather_kind == "abi":
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(driver.comm_unique_id()), dtype=torch.uint8).clone()
+            dist.broadcast(uid, src=0)
+            app.comm_create(rank, world, bytes(uid.numpy().tobytes()))
+            bgather = sortfirst.AbiTileGather(app, layout, W, rank, "cuda", B)
+            bgather.send[0, 0].fill_(float(rank + 1))
+            torch.cuda.synchronize()
+            bgather.gather(0, 1, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            ok = True
+            if rank == 0:
+                got = bgather.frames[0, :, 0, 0].cpu().numpy()
+                want = np.zeros(H, dtype=np.float32)
+                for r_, y0_, h_ in sortfirst.flat_layout(layout):
+                    want[y0_:y0_ + h_] = r_ + 1
+                ok = bool((got == want).all()) and bool((bgather.frames[0] == bgather.frames[0, :, :1, :1]).all())
+            err = None if ok else "pattern check failed"
+        except Exception as e:  # noqa: BLE001
+            ok, err = False, repr(e)
+        if not all_ok(ok):
+            # loud, reported, and only for the plumbing around the kernels: the round-1 gather takes over
+            sys.stderr.write("bench.py rank %d: C-ABI tile gather unavailable (%s); using torch.distributed\n" % (rank, err))
+            gather_kind, gather_note, bgather = "torch", "C-ABI gather unavailable on at least one rank (%s)" % err, None
+    if world > 1 and gather_kind == "torch":
+        data_group = make_data_group()
+        if not equal_rows:
+            B = 1
+        if B > 1:
+            bgather = sortfirst.BatchedTileGather(layout, W, rank, "cuda", B, group=data_group)
+    batched = bgather is not None
+    if batched:
+        K = 2 * B
+    a.warmup = max(a.warmup, K)
+    # per in-flight frame: a pixel buffer of this rank's stacked bands (device memory owned by
+    # torch), a stream and a tile-gather buffer set
+    if batched:
+        fbs = [bgather.send[k // B, k % B] for k in range(K)]
+    else:
+        fbs = [torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(K)]
+    streams = [torch.cuda.Stream() for _ in range(K)]
+    gstream = torch.cuda.Stream() if batched else None
+    rendered = [torch.cuda.Event() for _ in range(K)] if batched else None
+    consumed = [None, None]  # per half: event after the gather that last read it
     app.set_frames_in_flight(K)
     for k in range(K):
         app.select_slot(k)
         app.set_stream(streams[k].cuda_stream)
         app.set_framebuffer(fbs[k].data_ptr())
-    gathers = ([sortfirst.TileGather(layout, W, rank, "cuda") for _ in range(K)]
+    gathers = ([sortfirst.TileGather(layout, W, rank, "cuda", group=data_group) for _ in range(K)]
                if (world > 1 and not batched) else None)
     counter = [0]
     last_frame = [None]  # rank 0: the most recently assembled frame (--check-frames)
@@ -179,7 +282,10 @@ def main():
         with torch.cuda.stream(gstream):
             for i in range(n):
                 gstream.wait_event(rendered[half * B + i])
-            bgather.gather(half, n)
+            if gather_kind == "abi":
+                bgather.gather(half, n, gstream.cuda_stream)
+            else:
+                bgather.gather(half, n)
             if rank == 0:
                 last_frame[0] = bgather.assemble(n)[n - 1]
             ev = torch.cuda.Event()
@@ -240,10 +346,7 @@ def main():
         app.render_frame(readback=False)
     samples = app.stats().samples
     app.set_option(vrc.OPT_COUNT_SAMPLES, 0)
-    st = torch.tensor([samples], dtype=torch.int64, device="cuda")
-    if world > 1:
-        dist.all_reduce(st)
-    samples_frame = int(st.item())
+    samples_frame = all_sum(int(samples))
 
     # the GPU clocks up over the first ~20 ms of load: a short untimed run-in before the W warm-up steps,
     # so that a small --warmup / --steps pair measures the same machine state as the default one
@@ -264,25 +367,20 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    dt = all_max(time.perf_counter() - t0)
 
-    # HIP-event kernel time of the timed region (events recorded on the render stream)
+    # HIP-event kernel time of the timed region (events recorded by the library around every raycast launch on
+    # the render stream): mean over the launches, which must be the timed frames, one launch each
     ksum, klaunch = 0.0, 0
     for s_ in all_slots(app.stats):
         ksum += s_.kernel_ms_sum
         klaunch += s_.kernel_launches
-    kt = torch.tensor([ksum], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
-    kernel_ms_per_frame = float(kt.item()) / a.steps  # slowest rank's kernels per frame
+    assert klaunch == a.steps, "kernel launches in the timed region: %d, frames: %d" % (klaunch, a.steps)
+    kernel_ms_per_frame = all_max(ksum / klaunch)  # slowest rank's kernel per frame
 
-    # --check-frames: the frame assembled from the ranks' bands is the frame one application renders
+    # the frame assembled from the ranks' bands is the frame one application renders (outside the timing)
     frame_check = None
-    if a.check_frames and world > 1 and rank == 0 and last_frame[0] is not None:
+    if world > 1 and rank == 0 and last_frame[0] is not None:
         with driver.App(uri, W, H, device=local_rank, synchronous=True, gpu_cache_mb=3072,
                         **(dict(sse=a.ray_lod_sse) if ray_lod_on else dict(min_lod=depth - 1, max_lod=depth - 1))) as whole:
             whole.set_ray_lod(ray_lod_on)
@@ -437,6 +535,33 @@ def main():
                             "Msamples_per_s": n / ms / 1e3}
         return res
 
+    def extra_volume_n():
+        # SURVEY 8(d) "Volume N" (bandwidth realism): mem:// bricks are constant, so every lane of a wave reads
+        # the same classified-table entry; the seeded-noise volume of the same size, camera and transfer
+        # function does not have that luck.  Same kernel, kernel time from the library's HIP events.
+        n_uri = "hash://#%d,%d,%d,%d" % (a.voxels, a.voxels, a.voxels, a.block)
+        with driver.App(n_uri, W, H, device=local_rank, synchronous=True, min_lod=depth - 1, max_lod=depth - 1,
+                        gpu_cache_mb=3072) as napp:
+            napp.set_camera(spin=tuple(a.spin))
+            napp.set_colormap(linear_ramp(a.alpha))
+            napp.set_option(vrc.OPT_COUNT_SAMPLES, 1)
+            napp.render_frame(readback=False)
+            n_samples = int(napp.stats().samples)
+            napp.set_option(vrc.OPT_COUNT_SAMPLES, 0)
+            for _ in range(10):
+                napp.render_frame(readback=False)
+            napp.stats()
+            for _ in range(40):
+                napp.render_frame(readback=False)
+            torch.cuda.synchronize()
+            st_ = napp.stats()
+            ms = st_.kernel_ms_sum / max(1, st_.kernel_launches)
+        alg = a.voxels ** 3 + W * H * 16 + (a.voxels // a.block) ** 3 * 48 + 4096
+        return {"volume": n_uri + " (v = lowbias32(x + X*(y + Y*z) + 0x5EED) >> 24, 3-tap box filter per axis)",
+                "kernel_ms_per_frame": ms, "samples_per_frame": n_samples, "Msamples_per_s": n_samples / ms / 1e3,
+                "frames_per_s_kernel": 1e3 / ms, "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "vs_mem_volume_kernel_ms": ms / kernel_ms_per_frame}
+
     # the extras can never cost the judged line: a failure is reported in their place
     def guarded(fn, default):
         if world != 1 or a.no_extras or ray_lod_on:
@@ -451,6 +576,7 @@ def main():
     moving = guarded(extra_moving_camera, None)
     pipelined, readback = guarded(extra_pipelined_and_readback, (None, None))
     ray_lod = guarded(extra_per_ray_lod, None)
+    volume_n = guarded(extra_volume_n, None)
 
     if rank == 0:
         # measured HBM traffic per launch, from the committed rocprofv3 PMC passes (bench.py cannot
@@ -461,10 +587,12 @@ def main():
                 and tuple(a.spin) == (0.0, 0.0) and not ray_lod_on and os.path.exists(tpath)):
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         n_nodes = (a.voxels // a.block) ** 3
-        # interior voxels of marched bricks + one RGBA32F write + node table + TF.
-        # With N ranks every rank marches (nearly) every brick for its rows: bricks count N times.
-        alg_bytes = world * (a.voxels ** 3 + n_nodes * 48 + 4096) + W * H * 16
-        per_rank_alg = a.voxels ** 3 + n_nodes * 48 + 4096 + rows * W * 16
+        # interior voxels of marched bricks + one RGBA32F write + node table + TF, each input
+        # voxel once per frame.  With N ranks a rank's row bands sweep rows/H of the volume (the bands are
+        # interleaved, every brick is crossed by rays of every rank, each voxel belongs to the rays of ONE
+        # row): its launch reads voxels^3 * rows/H + its own part of the frame, the table and the TF.
+        alg_bytes = a.voxels ** 3 + world * (n_nodes * 48 + 4096) + W * H * 16
+        per_rank_alg = a.voxels ** 3 * rows // H + n_nodes * 48 + 4096 + rows * W * 16
         achieved = per_rank_alg / (kernel_ms_per_frame * 1e-3) / 1e9
         out = {
             "metric": "Msamples/s + frames/s, 1024^3 volume @ 1024^2 viewport",
@@ -486,8 +614,13 @@ def main():
                                     "tree, per-ray adaptive LOD at screen-space error %g, linear-ramp TF alpha=%.3g"
                                     % (uri, W, H, a.ray_lod_sse, a.alpha)),
                        "parallelism": "sort-first, %d rank(s) x %d interleaved row band(s) in one "
-                                      "launch, RGBA32F gather to rank 0 (%d frame(s) per gather), %d frames in flight"
-                                      % (world, len(bands), B, K),
+                                      "launch, RGBA32F tiles to rank 0 by %s (%d frame(s) per exchange), %d frames in flight"
+                                      % (world, len(bands),
+                                         {"abi": "vrc_gather_tiles (RCCL behind the C ABI, straight into the frame)",
+                                          "torch": "torch.distributed.gather + placement copy",
+                                          "none": "nothing (one rank)"}[gather_kind], B, K),
+                       "tile_gather": gather_kind, "tile_gather_note": gather_note,
+                       "world_size_checked": world,
                        "sort_first_frame_check": frame_check,
                        "samples_per_frame": samples_frame,
                        "per_frame_work": "every timed frame is a full render_frame call and a full march (frame "
@@ -499,7 +632,8 @@ def main():
                        "extension_trilinear": trilinear, "moving_camera": moving,
                        "with_readback_to_pinned_host": readback,
                        "three_frames_in_flight": pipelined,
-                       "extension_per_ray_lod": ray_lod},
+                       "extension_per_ray_lod": ray_lod,
+                       "volume_n": volume_n},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": ("vrc_k_raycast_raylod<false,false,true,0,unsigned char>" if ray_lod_on else

@@ -90,6 +90,17 @@ int lvh_app_volume_info( lvh_app* app, uint32_t voxels[3], uint32_t max_block[3]
                          uint32_t overlap[3], float world_size[3], uint32_t* depth,
                          uint32_t root_blocks[3] );
 int lvh_app_visible_set( lvh_app* app, uint64_t* ids, size_t capacity, size_t* n );
+/* ---- sort-first tile exchange (include/vrc_hip.h: vrc_comm_*, vrc_gather_tiles) driven from the host:
+ * what eq::Compositor::assembleFrame does for the reference (livre/eq/Channel.cpp:519-523).  One rank calls
+ * lvh_comm_unique_id and hands the 128 bytes to all; every rank then creates its communicator (collective),
+ * declares the frame's band layout (the same list on all ranks; a rank's own bands are those of
+ * lvh_app_set_bands, in list order) and, per frame or batch of frames, calls lvh_app_gather_tiles with its
+ * stacked bands; on `root` the bands land at their rows of `frame_device`. */
+int lvh_comm_unique_id( uint8_t id[128] );
+int lvh_app_comm_create( lvh_app* app, int rank, int world, const uint8_t* id );
+int lvh_app_set_layout( lvh_app* app, const uint32_t* rank, const uint32_t* y0, const uint32_t* h, uint32_t n );
+int lvh_app_gather_tiles( lvh_app* app, uint32_t n_frames, const void* local_device, size_t local_frame_stride,
+                          void* frame_device, size_t frame_stride, int root, void* hip_stream );
 /* ids of the bricks of the last (pass of the last) frame in the order the renderer handed them to the device
  * layer: front to back by box-centre distance (CudaRaycastRenderer.cpp:160-163).  Bricks at (nearly) equal
  * distance come in an order the reference leaves to std::sort and to the rounding of vmmlib's transform;

@@ -29,6 +29,7 @@ EXPORTS = [
     "lvh_app_set_modelview", "lvh_app_set_colormap", "lvh_app_set_clip_planes",
     "lvh_app_set_bands", "lvh_app_set_frames_in_flight", "lvh_app_select_slot", "lvh_app_set_option", "lvh_app_set_data_range", "lvh_app_set_ray_lod", "lvh_app_set_stream", "lvh_app_set_framebuffer", "lvh_app_render_frame",
     "lvh_app_get_stats", "lvh_app_wait_uploads", "lvh_app_synchronize", "lvh_app_volume_info",
+    "lvh_comm_unique_id", "lvh_app_comm_create", "lvh_app_set_layout", "lvh_app_gather_tiles",
     "lvh_app_visible_set", "lvh_app_node_order", "lvh_app_view_matrices", "lvh_app_cache_stats", "lvh_select_visibles",
     "lvh_selftest_cache", "lvh_selftest_plugin_factory", "lvh_selftest_camera",
     "lvh_selftest_clip_planes", "lvh_selftest_renderer_parameters",
@@ -70,6 +71,10 @@ def load_library():
                                       C.c_float * 3, C.POINTER(C.c_uint32), C.c_uint32 * 3]
     L.lvh_app_visible_set.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
     L.lvh_app_node_order.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
+    L.lvh_comm_unique_id.argtypes = [C.c_char_p]
+    L.lvh_app_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
+    L.lvh_app_set_layout.argtypes = [vp, vp, vp, vp, C.c_uint32]
+    L.lvh_app_gather_tiles.argtypes = [vp, C.c_uint32, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp]
     L.lvh_app_view_matrices.argtypes = [vp, C.c_float * 16, C.c_float * 16]
     L.lvh_app_cache_stats.argtypes = [vp, C.c_uint64 * 4, C.c_uint64 * 4]
     L.lvh_select_visibles.argtypes = [C.c_char_p, C.c_float * 16, C.c_float * 16, C.c_uint32,
@@ -186,6 +191,24 @@ class App:
         check(self.L, self.L.lvh_app_visible_set(self.h, ids, n.value, C.byref(n)))
         return list(ids)[:n.value]
 
+    def comm_create(self, rank, world, unique_id):
+        """Collective: the RCCL communicator of the sort-first tile exchange (unique_id: 128 bytes from
+        comm_unique_id() of one rank; None for a world of one)."""
+        check(self.L, self.L.lvh_app_comm_create(self.h, rank, world, unique_id))
+
+    def set_layout(self, layout):
+        """layout: per rank a list of (y0, h) bands (sortfirst.band_layout); bands in frame order."""
+        flat = sorted((y0, h, r) for r, bands in enumerate(layout) for (y0, h) in bands)
+        n = len(flat)
+        rk = (C.c_uint32 * max(1, n))(*[b[2] for b in flat])
+        y0 = (C.c_uint32 * max(1, n))(*[b[0] for b in flat])
+        hh = (C.c_uint32 * max(1, n))(*[b[1] for b in flat])
+        check(self.L, self.L.lvh_app_set_layout(self.h, rk, y0, hh, n))
+
+    def gather_tiles(self, n_frames, local_ptr, local_stride, frame_ptr, frame_stride, root=0, stream=None):
+        check(self.L, self.L.lvh_app_gather_tiles(self.h, n_frames, local_ptr, local_stride, frame_ptr,
+                                                   frame_stride, root, stream))
+
     def node_order(self):
         """ids of the bricks of the last frame in the renderer's front-to-back order."""
         n = C.c_size_t()
@@ -215,6 +238,14 @@ class App:
 
     def __exit__(self, *a):
         self.close()
+
+
+def comm_unique_id():
+    """128 bytes that identify a new RCCL communicator (one rank calls this, all ranks get the bytes)."""
+    L = load_library()
+    buf = C.create_string_buffer(128)
+    check(L, L.lvh_comm_unique_id(buf))
+    return buf.raw
 
 
 def select_visibles(volume_uri, mv, proj, window_height, sse, min_lod, max_lod):

@@ -93,6 +93,10 @@ public:
     /** ids of the bricks of the last render() in the order the node table was handed to the device layer
      *  (front to back by box-centre distance, CudaRaycastRenderer.cpp:160-163) */
     const std::vector< Identifier >& lastNodeOrder() const { return _sortedIds; }
+    /** the device-layer context (C ABI handle): for calls that take it, e.g. the sort-first tile exchange
+     *  vrc_comm_create / vrc_gather_tiles, the step eq::Compositor::assembleFrame performs for the
+     *  reference (livre/eq/Channel.cpp:519-523) */
+    vrc_ctx* deviceContext() const { return _ctx; }
 
 private:
     vrc_ctx* _ctx;

@@ -35,6 +35,8 @@ struct lvh_app
     uint32_t slot = 0;
     std::string rendererName;
     float dataRange[2] = { 0.0f, 0.0f }; /* lvh_app_set_data_range; empty = the voxel type's range */
+    vrc_comm* comm = nullptr;              /* lvh_app_comm_create: sort-first tile exchange */
+    std::vector< vrc_band > layout;        /* lvh_app_set_layout: every band of the frame, all ranks */
 
     Renderer& currentRenderer()
     {
@@ -141,7 +143,12 @@ int lvh_app_create( const char* uri, const char* rendererName, const lvh_params*
     }
 }
 
-void lvh_app_destroy( lvh_app* app ) { delete app; }
+void lvh_app_destroy( lvh_app* app )
+{
+    if( app && app->comm )
+        vrc_comm_destroy( app->comm );
+    delete app;
+}
 
 int lvh_app_set_camera( lvh_app* app, const float pos[3], const float lookat[3], float sx, float sy )
 {
@@ -355,6 +362,52 @@ int lvh_app_visible_set( lvh_app* app, uint64_t* ids, size_t cap, size_t* n )
     {
         return fail( e.what() );
     }
+}
+
+/* ---- sort-first tile exchange: the C ABI's RCCL gather driven from the host side ------------------- */
+int lvh_comm_unique_id( uint8_t id[128] )
+{
+    if( vrc_comm_unique_id( id ) != VRC_OK ) return fail( vrc_last_error() );
+    return 0;
+}
+
+int lvh_app_comm_create( lvh_app* app, int rank, int world, const uint8_t* id )
+{
+    if( !app ) return fail( "NULL argument" );
+    if( app->comm )
+    {
+        vrc_comm_destroy( app->comm );
+        app->comm = nullptr;
+    }
+    if( vrc_comm_create( app->renderer().deviceContext(), rank, world, id, &app->comm ) != VRC_OK )
+        return fail( vrc_last_error() );
+    return 0;
+}
+
+int lvh_app_set_layout( lvh_app* app, const uint32_t* rank, const uint32_t* y0, const uint32_t* h, uint32_t n )
+{
+    if( !app || ( n && ( !rank || !y0 || !h ) ) ) return fail( "NULL argument" );
+    std::vector< vrc_band > l( n );
+    for( uint32_t i = 0; i < n; ++i )
+    {
+        if( y0[i] + h[i] > app->params.height ) return fail( "lvh_app_set_layout: band outside the frame" );
+        l[i].rank = rank[i];
+        l[i].frame_row = y0[i];
+        l[i].rows = h[i];
+    }
+    app->layout.swap( l );
+    return 0;
+}
+
+int lvh_app_gather_tiles( lvh_app* app, uint32_t nFrames, const void* localDevice, size_t localFrameStride,
+                          void* frameDevice, size_t frameStride, int root, void* hipStream )
+{
+    if( !app || !app->comm ) return fail( "lvh_app_gather_tiles: no communicator (lvh_app_comm_create)" );
+    if( vrc_gather_tiles( app->renderer().deviceContext(), app->comm, app->layout.data(),
+                          uint32_t( app->layout.size() ), app->params.width, nFrames, localDevice,
+                          localFrameStride, frameDevice, frameStride, root, hipStream ) != VRC_OK )
+        return fail( vrc_last_error() );
+    return 0;
 }
 
 int lvh_app_node_order( lvh_app* app, uint64_t* ids, size_t cap, size_t* n )

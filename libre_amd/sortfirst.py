@@ -14,6 +14,11 @@ import torch
 import torch.distributed as dist
 
 
+def flat_layout(layout):
+    """-> [(rank, y0, h)] in frame order: the band list vrc_gather_tiles takes (include/vrc_hip.h)."""
+    return [(r, y0, h) for (y0, h, r) in sorted((y0, h, r) for r, bands in enumerate(layout) for (y0, h) in bands)]
+
+
 def band_layout(height, world, bands_per_rank):
     """-> per rank: list of (y0, h).  Bands tile [0, height) exactly."""
     nb = world * bands_per_rank if world > 1 else 1
@@ -30,8 +35,8 @@ class TileGather:
     """Per-frame gather of every rank's stacked bands to rank `dst` and their placement into
     the full frame.  Buffers are allocated once."""
 
-    def __init__(self, layout, width, rank, device, dst=0):
-        self.layout, self.width, self.rank, self.dst = layout, width, rank, dst
+    def __init__(self, layout, width, rank, device, dst=0, group=None):
+        self.layout, self.width, self.rank, self.dst, self.group = layout, width, rank, dst, group
         self.world = len(layout)
         self.counts = [sum(h for _, h in b) for b in layout]
         self.equal = len(set(self.counts)) == 1
@@ -61,14 +66,14 @@ class TileGather:
             return
         if self.equal:
             # equal tiles: one RCCL gather; each peer uses its own point-to-point xGMI link
-            dist.gather(local, self.recv if self.rank == self.dst else None, dst=self.dst)
+            dist.gather(local, self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group)
         elif self.rank == self.dst:
             self.recv[self.dst].copy_(local)
-            reqs = [dist.irecv(self.recv[r], src=r) for r in range(self.world) if r != self.dst]
+            reqs = [dist.irecv(self.recv[r], src=r, group=self.group) for r in range(self.world) if r != self.dst]
             for q in reqs:
                 q.wait()
         else:
-            dist.send(local, dst=self.dst)
+            dist.send(local, dst=self.dst, group=self.group)
 
     def assemble(self):
         """Display rank only: place the received bands at their rows (the frame assembly)."""
@@ -97,8 +102,8 @@ class BatchedTileGather:
     while batch n is on the wire.  Equal row counts per rank (band_layout gives them whenever the
     frame height divides evenly) are required; otherwise use TileGather per frame."""
 
-    def __init__(self, layout, width, rank, device, batch, dst=0):
-        self.layout, self.width, self.rank, self.dst, self.batch = layout, width, rank, dst, batch
+    def __init__(self, layout, width, rank, device, batch, dst=0, group=None):
+        self.layout, self.width, self.rank, self.dst, self.batch, self.group = layout, width, rank, dst, batch, group
         self.world = len(layout)
         counts = [sum(h for _, h in b) for b in layout]
         if len(set(counts)) != 1:
@@ -124,7 +129,7 @@ class BatchedTileGather:
                 self.recv_all[0, :n].copy_(local)
             return
         recv = [self.recv_all[r, :n] for r in range(self.world)] if self.rank == self.dst else None
-        dist.gather(local, recv, dst=self.dst)
+        dist.gather(local, recv, dst=self.dst, group=self.group)
 
     def assemble(self, n):
         """Display rank only: the n gathered frames, each band at its rows.  -> frames[:n]"""
@@ -142,3 +147,35 @@ class BatchedTileGather:
                 off += h
         return self.frames[:n]
 
+
+
+class AbiTileGather:
+    """The sort-first assembly through the C ABI: vrc_gather_tiles (include/vrc_hip.h) -- RCCL sends and
+    receives, one per band, that land every band directly at its rows of the frame on the display rank; no
+    staging buffer and no placement copy.  PyTorch only owns the memory.  `batch` consecutive frames share
+    one group of sends / receives (two halves: batch n+1 is rendered while batch n is on the wire); ranks
+    may have different numbers of rows.  `app` is a libre_amd.driver.App whose communicator exists
+    (app.comm_create)."""
+
+    def __init__(self, app, layout, width, rank, device, batch, dst=0):
+        self.app, self.layout, self.width, self.rank, self.dst, self.batch = app, layout, width, rank, dst, batch
+        self.world = len(layout)
+        self.rows = sum(h for _, h in layout[rank])
+        self.height = sum(h for b in layout for _, h in b)
+        self.send = torch.zeros((2, batch, max(1, self.rows), width, 4), dtype=torch.float32, device=device)
+        self.frames = None
+        if rank == dst:
+            self.frames = torch.zeros((batch, self.height, width, 4), dtype=torch.float32, device=device)
+        app.set_layout(layout)
+
+    def gather(self, half, n, stream=None):
+        """Collective, asynchronous on `stream` (a raw hipStream_t handle; None: the renderer's stream): the first
+        n frames of send[half] of every rank -> frames[:n] on the display rank."""
+        self.app.gather_tiles(n, self.send[half].data_ptr(), self.send[half, 0].numel() * 4,
+                              self.frames.data_ptr() if self.frames is not None else None,
+                              self.height * self.width * 16, self.dst, stream)
+
+    def assemble(self, n):
+        """Display rank only: the n gathered frames (already in place)."""
+        assert self.rank == self.dst
+        return self.frames[:n]

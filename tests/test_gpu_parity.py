@@ -879,3 +879,46 @@ def test_more_bricks_than_the_reference_node_table_holds(vrc):
         dda, n_dda, _ = g.render(kernel=vrc.KERNEL_GRID_DDA)
         ref, n_ref, _ = g.render(kernel=vrc.KERNEL_REFERENCE_ORDER)
         assert n_dda == n_ref and np.abs(dda - ref).max() <= 1e-6
+
+
+def test_gather_tiles_places_bands_at_their_rows(vrc):
+    # vrc_gather_tiles (the sort-first exchange of livre/eq/Channel.cpp:519-523 behind the C ABI) for a world
+    # of one rank: every band of the rank's stacked buffer lands at its rows of the frame, for a batch of frames;
+    # argument errors are reported before anything is queued.  N > 1 needs N GPUs (the driver's scaling run).
+    import torch
+    L = vrc.load_library()
+    ctx, comm = C.c_void_p(), C.c_void_p()
+    vrc.check(L, L.vrc_ctx_create(0, C.byref(ctx)))
+    vrc.check(L, L.vrc_comm_create(ctx, 0, 1, None, C.byref(comm)))
+    r, w = C.c_int(-1), C.c_int(-1)
+    vrc.check(L, L.vrc_comm_info(comm, C.byref(r), C.byref(w)))
+    assert (r.value, w.value) == (0, 1)
+    W, H, F = 24, 20, 3
+    bands = [(0, 3), (7, 5), (12, 1), (15, 4)]  # (frame_row, rows): 13 of 20 rows, the rest stay untouched
+    arr = (vrc.Band * len(bands))(*[vrc.Band(0, y0, h) for y0, h in bands])
+    rows = sum(h for _, h in bands)
+    local = torch.arange(F * rows * W * 4, dtype=torch.float32, device="cuda").reshape(F, rows, W, 4)
+    frame = torch.full((F, H, W, 4), -1.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    vrc.check(L, L.vrc_gather_tiles(ctx, comm, arr, len(bands), W, F, local.data_ptr(), rows * W * 16,
+                                    frame.data_ptr(), H * W * 16, 0, None))
+    vrc.check(L, L.vrc_synchronize(ctx))
+    want = torch.full((F, H, W, 4), -1.0)
+    off = 0
+    for y0, h in bands:
+        want[:, y0:y0 + h] = local[:, off:off + h].cpu()
+        off += h
+    assert (frame.cpu() == want).all()
+    # errors: band of a rank outside the communicator, missing frame on the display rank, bad root
+    bad = (vrc.Band * 1)(vrc.Band(1, 0, 1))
+    assert L.vrc_gather_tiles(ctx, comm, bad, 1, W, 1, local.data_ptr(), 0, frame.data_ptr(), 0, 0, None) == vrc.VRC_EINVAL
+    assert L.vrc_gather_tiles(ctx, comm, arr, len(bands), W, 1, local.data_ptr(), 0, None, 0, 0, None) == vrc.VRC_EINVAL
+    assert L.vrc_gather_tiles(ctx, comm, arr, len(bands), W, 1, local.data_ptr(), 0, frame.data_ptr(), 0, 1, None) == vrc.VRC_EINVAL
+    # a communicator of more ranks needs an id (and RCCL)
+    c2 = C.c_void_p()
+    assert L.vrc_comm_create(ctx, 0, 2, None, C.byref(c2)) == vrc.VRC_ECOMM
+    uid = C.create_string_buffer(vrc.COMM_ID_BYTES)
+    vrc.check(L, L.vrc_comm_unique_id(uid))  # RCCL is on the box: the id comes from ncclGetUniqueId
+    assert any(uid.raw)
+    L.vrc_comm_destroy(comm)
+    L.vrc_ctx_destroy(ctx)
