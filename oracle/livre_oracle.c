@@ -702,6 +702,31 @@ static float tie_budget( const job_t* j, f3 texPos, float density, float multipl
     return worst * transmittance;
 }
 
+/* TEST INSTRUMENT (orc_options.tieBudget), second part: a brick the ray grazes.  Where a ray passes a brick
+ * edge or corner, the slab test of a brick it merely touches comes out with tfar within rounding of tnear:
+ * a last bit decides whether that brick gets its one sample (Renderer.cu:79, :208) -- and an implementation
+ * whose ray differs in the last bit (another, equally valid evaluation of the matrices or of the ray set-up)
+ * decides differently.  Returns the weight such a sample would have (classified alpha of the voxel at the
+ * touching point, times the transmittance), 0 when the interval is not degenerate. */
+static float sliver_budget( const job_t* j, const orc_node_data* nodeData, f3 origin, f3 dir, float tNear,
+                            float tFar, float multiplyer, float addedValue, float alphaCorrection,
+                            float transmittance )
+{
+    const float scale = fmaxf( 1.0f, fabsf( tNear ) );
+    if( !( fabsf( tFar - tNear ) <= 4e-6f * scale ) )
+        return 0.0f;
+    const f3 pos = { origin.x + dir.x * tNear, origin.y + dir.y * tNear, origin.z + dir.z * tNear };
+    const f3 texPos = {
+        ( ( pos.x - nodeData->aabbMin[0] ) / nodeData->aabbSize[0] ) * nodeData->textureSize[0] + nodeData->textureMin[0],
+        ( ( pos.y - nodeData->aabbMin[1] ) / nodeData->aabbSize[1] ) * nodeData->textureSize[1] + nodeData->textureMin[1],
+        ( ( pos.z - nodeData->aabbMin[2] ) / nodeData->aabbSize[2] ) * nodeData->textureSize[2] + nodeData->textureMin[2] };
+    const float density = fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
+    float tfn[4], here[4] = { 0, 0, 0, 0 };
+    orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, tfn );
+    orc_composite( tfn, here, alphaCorrection );
+    return fmaxf( fmaxf( here[0], here[1] ), fmaxf( here[2], here[3] ) ) * transmittance;
+}
+
 /* one pixel: Renderer.cu:106-229 */
 static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
 {
@@ -772,7 +797,12 @@ static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
         const f3 boxMax = { boxMin.x + boxSize.x, boxMin.y + boxSize.y, boxMin.z + boxSize.z };
 
         float tNear = 0.0f, tFar = 0.0f;
-        if( !intersect_box( origin, dir, boxMin, boxMax, &tNear, &tFar ) )
+        const int hitBox = intersect_box( origin, dir, boxMin, boxMax, &tNear, &tFar );
+        if( j->opt.tieBudget && !j->opt.filter && tFar >= tNearGlobal && tNear <= tFarGlobal &&
+            tFar >= tNearPlane ) /* test instrument, see orc_options */
+            j->opt.tieBudget[pixelPos] += sliver_budget( j, nodeData, origin, dir, tNear, tFar, multiplyer,
+                                                         addedValue, alphaCorrection, 1.0f - color[3] );
+        if( !hitBox )
             continue;
         if( tNear > tFarGlobal )
             break;

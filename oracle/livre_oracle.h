@@ -108,7 +108,9 @@ typedef struct
      * The reference puts the first sample of every brick exactly ON a brick face (= a voxel face,
      * Renderer.cu:195-196), so which voxel it reads hangs on the last bit of the coordinate arithmetic;
      * an implementation that evaluates the coordinate by another (equally valid) float expression
-     * differs from this oracle by at most E0 + 2 * tieBudget per pixel (tests/scenes.py). */
+     * differs from this oracle by at most E0 + 2 * tieBudget per pixel (tests/scenes.py).  Also added: the
+     * weight of the one sample of a brick the ray merely grazes (slab interval degenerate to within
+     * rounding): whether it is taken hangs on the last bit of the ray (sliver_budget in the .c file). */
     float* tieBudget;
     float tieDelta;
 } orc_options;

@@ -25,7 +25,12 @@ import orc
 # classified neighbour across that face, times the transmittance at the sample.  delta_k = 2^-11 voxel (the
 # coordinate evaluation) + k x 2^-25 world units (the reference's pos += step rounds by up to half an ulp per
 # addition; after k steps of a brick segment its sample sits that far from start + k x step, which is what the
-# fixed-point stepping of the kernel evaluates): 3e-5 voxel per step in a 1024-voxel volume.  An outlier pixel is
+# fixed-point stepping of the kernel evaluates): 3e-5 voxel per step in a 1024-voxel volume.
+# Second part of B: a brick the ray merely grazes (it passes a brick edge or corner: the slab test of a brick it
+# only touches comes out with tfar within 4e-6 (relative) of tnear).  A last bit of the ray decides whether such
+# a brick gets its one sample (cuda/Renderer.cu:79, :208); a host whose matrices differ in the last bit from the
+# oracle's (another, equally valid restatement of the un-vendored vmmlib) decides differently.  B includes the
+# weight that sample has or would have.  An outlier pixel is
 # thus only accepted where the oracle's own arithmetic says a one-voxel flip is possible, and by no more
 # than that flip can make (x 2: the flipped sample's alpha also rescales everything behind it).  Pixels
 # without such samples get the bare E0.  There is no allowance for "a few pixels over the line" any more,
