@@ -157,6 +157,8 @@ struct vrc_ctx
     /* one event pair per raycast launch since the last vrc_get_stats (ring, grows on demand) */
     std::vector< std::pair< hipEvent_t, hipEvent_t > > evPairs;
     size_t evUsed = 0;
+    double evFoldedMs = 0.0;      /* pairs taken out of a full ring before anyone asked for the statistics */
+    uint32_t evFoldedLaunches = 0;
     bool timed = false;
 
     int64_t optKernel = VRC_KERNEL_AUTO;
@@ -1139,8 +1141,20 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         VRC_HIP_CHECK( hipMemsetAsync( c->dCounter, 0, sizeof( unsigned long long ), c->stream ) );
     if( c->evUsed == c->evPairs.size() )
     {
-        if( c->evPairs.size() >= 4096 ) /* nobody is reading the timings: start over */
+        if( c->evPairs.size() >= 4096 )
+        {
+            /* nobody has read the timings for 4096 launches: fold them into running sums (waits for the
+             * launches still in flight, once per 4096) so that vrc_get_stats still accounts for every one */
+            VRC_HIP_CHECK( hipEventSynchronize( c->evPairs[c->evUsed - 1].second ) );
+            for( size_t i = 0; i < c->evUsed; ++i )
+            {
+                float ms = 0.f;
+                VRC_HIP_CHECK( hipEventElapsedTime( &ms, c->evPairs[i].first, c->evPairs[i].second ) );
+                c->evFoldedMs += ms;
+            }
+            c->evFoldedLaunches += (uint32_t)c->evUsed;
             c->evUsed = 0;
+        }
         else
         {
             hipEvent_t a0 = nullptr, a1 = nullptr;
@@ -1237,6 +1251,10 @@ int vrc_get_stats( vrc_ctx* c, vrc_stats* out )
         c->stats.kernel_launches = (uint32_t)c->evUsed;
         c->stats.kernel_ms = ms; /* the last launch */
         c->evUsed = 0;
+        c->stats.kernel_ms_sum += c->evFoldedMs;
+        c->stats.kernel_launches += c->evFoldedLaunches;
+        c->evFoldedMs = 0.0;
+        c->evFoldedLaunches = 0;
         if( c->optCount )
         {
             VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );

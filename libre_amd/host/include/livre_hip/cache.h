@@ -8,6 +8,7 @@
 
 #include <atomic>
 #include <deque>
+#include <list>
 #include <exception>
 #include <sstream>
 
@@ -196,6 +197,7 @@ public:
         std::unique_lock< std::shared_timed_mutex > lock( _mutex );
         _statistics.clear();
         _lru.clear();
+        _lruPos.clear();
         _cacheMap.clear();
     }
     void purge( const CacheId& cacheId )
@@ -211,19 +213,19 @@ private:
         ObjectPtr obj;
     };
 
+    /* least recently loaded first (Cache.ipp:146-166 keeps a deque and scans it); list + index: O(1) */
     void lruInsert( const CacheId& id )
     {
         lruRemove( id );
-        _lru.push_back( id );
+        _lruPos[id] = _lru.insert( _lru.end(), id );
     }
     void lruRemove( const CacheId& id )
     {
-        for( auto it = _lru.begin(); it != _lru.end(); ++it )
-            if( *it == id )
-            {
-                _lru.erase( it );
-                return;
-            }
+        const auto it = _lruPos.find( id );
+        if( it == _lruPos.end() )
+            return;
+        _lru.erase( it->second );
+        _lruPos.erase( it );
     }
     bool unloadLocked( const CacheId& cacheId )
     {
@@ -243,9 +245,10 @@ private:
     {
         if( _cacheMap.empty() || _statistics.getUsedMemory() < _maxMemBytes )
             return;
-        const std::deque< CacheId > ids = _lru;
-        for( const CacheId& id : ids )
+        for( auto it = _lru.begin(); it != _lru.end(); )
         {
+            const CacheId id = *it;
+            ++it; /* unloadLocked erases the element it is given, nothing else */
             unloadLocked( id );
             if( _statistics.getUsedMemory() < _maxMemBytes )
                 return;
@@ -257,7 +260,8 @@ private:
     std::atomic< size_t > _hits{ 0 };
     mutable std::shared_timed_mutex _mutex;
     std::unordered_map< CacheId, std::shared_ptr< Entry > > _cacheMap;
-    std::deque< CacheId > _lru;
+    std::list< CacheId > _lru;
+    std::unordered_map< CacheId, typename std::list< CacheId >::iterator > _lruPos;
 };
 
 /** livre/lib/cache/DataObject.h:31-60: a brick in CPU memory */

@@ -39,6 +39,7 @@ public:
 private:
     vrc_ctx* _ctx;
     vrc_pool* _pool;
+    int _device; /* whose shared pool-creation context _ctx is */
 };
 
 /** renderers/cudaRaycaster/CudaTextureObject.h:36-70 */

@@ -11,6 +11,8 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <exception>
+#include <map>
 #include <queue>
 #include <thread>
 
@@ -50,14 +52,39 @@ PluginRegisterer< HipRaycastPipeline, const std::string& > pipelineRegisterer;
 
 std::atomic< int > g_device( 0 );
 std::mutex g_deviceMutex;
-vrc_ctx* g_deviceCtx = nullptr; /* context the pools are created on */
+/* the context the texture pools of a device are created on: one per device (an application on a second
+ * device must not get its atlas on the first), shared by the pools of that device and destroyed with the
+ * last of them (not at static-destruction time: the HIP runtime may be gone by then) */
+struct DeviceContext
+{
+    vrc_ctx* ctx = nullptr;
+    size_t users = 0;
+};
+std::map< int, DeviceContext > g_deviceContexts;
 
-vrc_ctx* deviceContext()
+vrc_ctx* acquireDeviceContext( int* deviceOut )
 {
     std::lock_guard< std::mutex > lock( g_deviceMutex );
-    if( !g_deviceCtx )
-        throwOnVrcError( vrc_ctx_create( g_device.load(), &g_deviceCtx ), "vrc_ctx_create" );
-    return g_deviceCtx;
+    const int device = g_device.load();
+    DeviceContext& d = g_deviceContexts[device];
+    if( !d.ctx )
+        throwOnVrcError( vrc_ctx_create( device, &d.ctx ), "vrc_ctx_create" );
+    ++d.users;
+    *deviceOut = device;
+    return d.ctx;
+}
+
+void releaseDeviceContext( int device )
+{
+    std::lock_guard< std::mutex > lock( g_deviceMutex );
+    const auto it = g_deviceContexts.find( device );
+    if( it == g_deviceContexts.end() || it->second.users == 0 )
+        return;
+    if( --it->second.users == 0 )
+    {
+        vrc_ctx_destroy( it->second.ctx );
+        g_deviceContexts.erase( it );
+    }
 }
 
 /** LIVRE_HIP_PROFILE=1: host time of the stages of a frame, summed and printed when the pipeline goes */
@@ -164,7 +191,20 @@ private:
                 _tasks.pop();
                 ++_busy;
             }
-            try { task(); } catch( ... ) {}
+            try
+            {
+                task();
+            }
+            catch( const std::exception& e )
+            {
+                /* tasks report their own failures to whoever waits for them; one that still leaks an
+                 * exception must at least not vanish */
+                std::fprintf( stderr, "[livre_hip] executor: task failed: %s\n", e.what() );
+            }
+            catch( ... )
+            {
+                std::fprintf( stderr, "[livre_hip] executor: task failed with a non-standard exception\n" );
+            }
             {
                 std::lock_guard< std::mutex > lock( _mutex );
                 --_busy;
@@ -199,8 +239,19 @@ int getHipDevice() { return g_device; }
 
 /* ---- HipTexturePool: CudaTexturePool.cpp:31-122 --------------------------------------------- */
 HipTexturePool::HipTexturePool( const DataSource& dataSource, size_t textureMemory )
-    : _ctx( deviceContext() ), _pool( nullptr )
+    : _ctx( nullptr ), _pool( nullptr ), _device( 0 )
 {
+    _ctx = acquireDeviceContext( &_device );
+    struct Release /* a constructor that throws runs no destructor */
+    {
+        int device;
+        bool armed;
+        ~Release()
+        {
+            if( armed )
+                releaseDeviceContext( device );
+        }
+    } guard{ _device, true };
     const VolumeInformation& volInfo = dataSource.getVolumeInfo();
     bool isSigned = false, isFloat = false;
     switch( volInfo.dataType )
@@ -216,9 +267,14 @@ HipTexturePool::HipTexturePool( const DataSource& dataSource, size_t textureMemo
     throwOnVrcError( vrc_pool_create( _ctx, volInfo.getBytesPerVoxel(), isSigned, isFloat,
                                       volInfo.compCount, maxBlock, textureMemory, &_pool ),
                      "vrc_pool_create" );
+    guard.armed = false;
 }
 
-HipTexturePool::~HipTexturePool() { vrc_pool_destroy( _pool ); }
+HipTexturePool::~HipTexturePool()
+{
+    vrc_pool_destroy( _pool );
+    releaseDeviceContext( _device );
+}
 
 Vector3f HipTexturePool::copyToSlot( const unsigned char* ptr, const Vector3ui& size )
 {
@@ -689,6 +745,7 @@ struct HipRaycastPipeline::Impl
         std::atomic< size_t > pending( 0 );
         std::mutex doneMutex;
         std::condition_variable doneCv;
+        std::exception_ptr firstError; /* first failure on a loader thread, rethrown on this one */
         for( size_t i = 0; i < nUploadThreads; ++i )
         {
             const size_t begin = perThread * i;
@@ -697,32 +754,53 @@ struct HipRaycastPipeline::Impl
             const size_t end = ( i == nUploadThreads - 1 ) ? ids.size() : std::min( begin + perThread, ids.size() );
             ++pending;
             _uploadExecutor.schedule( [&, begin, end] {
-                double tData = 0.0, tTex = 0.0;
-                const bool trace = std::getenv( "LIVRE_HIP_TRACE" ) != nullptr;
-                for( size_t k = begin; k < end; ++k )
+                /* Completion is signalled on every way out of the task.  Cache::load only absorbs
+                 * CacheLoadException; a reader error (std::runtime_error from the UVF source), an allocation
+                 * failure or a failed device call in vrc_pool_copy_to_slot leaves through here too -- the
+                 * reference hands such failures to the waiting thread through its futures
+                 * (CudaRaycastPipeline.cpp:255-297), a lost notification would park the render thread for good.
+                 * Notify under the mutex: the waiter owns the condition variable on its stack and may
+                 * destroy it as soon as it can re-acquire the mutex and sees 0 (found by ThreadSanitizer,
+                 * tests/host_san/pipeline_stress.cpp). */
+                struct Done
                 {
-                    const CacheId id = ids[k].getId();
-                    const auto t0 = std::chrono::steady_clock::now();
-                    const bool have = bool( _dataCache->load( id, dataSource ) );
-                    const auto t1 = std::chrono::steady_clock::now();
-                    if( have )
-                        loaded[k] = _hipCache->load( id, *_dataCache, dataSource, *_texturePool );
-                    if( trace )
+                    std::mutex& m;
+                    std::condition_variable& cv;
+                    std::atomic< size_t >& pending;
+                    ~Done()
                     {
-                        tData += std::chrono::duration< double, std::milli >( t1 - t0 ).count();
-                        tTex += std::chrono::duration< double, std::milli >( std::chrono::steady_clock::now() - t1 ).count();
+                        std::lock_guard< std::mutex > lock( m );
+                        --pending;
+                        cv.notify_all();
                     }
-                }
-                if( trace )
-                    std::fprintf( stderr, "[livre_hip] loader: %zu bricks, data source + CPU cache %.1f ms, texture upload %.1f ms\n",
-                                  end - begin, tData, tTex );
+                } done{ doneMutex, doneCv, pending };
+                try
                 {
-                    /* notify under the mutex: the waiter owns the condition variable on its stack
-                     * and may destroy it as soon as it can re-acquire the mutex and sees 0
-                     * (found by ThreadSanitizer, tests/host_san/pipeline_stress.cpp) */
+                    double tData = 0.0, tTex = 0.0;
+                    const bool trace = std::getenv( "LIVRE_HIP_TRACE" ) != nullptr;
+                    for( size_t k = begin; k < end; ++k )
+                    {
+                        const CacheId id = ids[k].getId();
+                        const auto t0 = std::chrono::steady_clock::now();
+                        const bool have = bool( _dataCache->load( id, dataSource ) );
+                        const auto t1 = std::chrono::steady_clock::now();
+                        if( have )
+                            loaded[k] = _hipCache->load( id, *_dataCache, dataSource, *_texturePool );
+                        if( trace )
+                        {
+                            tData += std::chrono::duration< double, std::milli >( t1 - t0 ).count();
+                            tTex += std::chrono::duration< double, std::milli >( std::chrono::steady_clock::now() - t1 ).count();
+                        }
+                    }
+                    if( trace )
+                        std::fprintf( stderr, "[livre_hip] loader: %zu bricks, data source + CPU cache %.1f ms, texture upload %.1f ms\n",
+                                      end - begin, tData, tTex );
+                }
+                catch( ... )
+                {
                     std::lock_guard< std::mutex > lock( doneMutex );
-                    --pending;
-                    doneCv.notify_all();
+                    if( !firstError )
+                        firstError = std::current_exception();
                 }
             } );
         }
@@ -730,6 +808,8 @@ struct HipRaycastPipeline::Impl
             std::unique_lock< std::mutex > lock( doneMutex );
             doneCv.wait( lock, [&] { return pending == 0; } );
         }
+        if( firstError )
+            std::rethrow_exception( firstError );
         /* Two uploaders can both pass the cache's "has space" test while only one slot is
          * free (the policy evicts until used < max, i.e. one slot; the reference has the same
          * window, Cache.ipp:132-144 + TexturePool.cu:180-181); the loser's load comes back
@@ -977,6 +1057,16 @@ struct HipRaycastPipeline::Impl
         plain.vrParameters.rayLOD = false;
         const RenderInputs& inputs = rayLod ? in : plain;
         const bool allAvailable = statistics.nNotAvailable == 0;
+        {
+            /* a failure of the upload pipeline behind an earlier frame surfaces here */
+            std::exception_ptr pendingError;
+            {
+                std::lock_guard< std::mutex > lock( _asyncErrorMutex );
+                std::swap( pendingError, _asyncError );
+            }
+            if( pendingError )
+                std::rethrow_exception( pendingError );
+        }
         if( !allAvailable )
         {
             /* one upload pipeline in flight at a time on the async executor */
@@ -988,13 +1078,29 @@ struct HipRaycastPipeline::Impl
                 DataSource* ds = &in.dataSource;
                 _asyncUploadExecutor.schedule( [this, visibles, ds] {
                     /* the upload pipeline of the reference's async executor: the misses go
-                     * through the same nUploadThreads loaders as a synchronous pass */
-                    NodeIds missing;
-                    for( const NodeId& id : visibles )
-                        if( !_hipCache->get( id.getId() ) )
-                            missing.push_back( id );
-                    loadParallel( missing, *ds );
-                    _asyncBusy = false;
+                     * through the same nUploadThreads loaders as a synchronous pass.  The busy flag
+                     * is lowered on every way out, and a failed load is kept for the render thread
+                     * (asyncError(): the next frame reports it instead of waiting for bricks that
+                     * will never arrive) */
+                    struct Lower
+                    {
+                        std::atomic< bool >& flag;
+                        ~Lower() { flag = false; }
+                    } lower{ _asyncBusy };
+                    try
+                    {
+                        NodeIds missing;
+                        for( const NodeId& id : visibles )
+                            if( !_hipCache->get( id.getId() ) )
+                                missing.push_back( id );
+                        loadParallel( missing, *ds );
+                    }
+                    catch( ... )
+                    {
+                        std::lock_guard< std::mutex > lock( _asyncErrorMutex );
+                        if( !_asyncError )
+                            _asyncError = std::current_exception();
+                    }
                 } );
             }
         }
@@ -1036,6 +1142,8 @@ struct HipRaycastPipeline::Impl
     std::unique_ptr< HipTextureCache > _hipCache;
     Executor _uploadExecutor, _asyncUploadExecutor;
     std::atomic< bool > _asyncBusy{ false };
+    std::mutex _asyncErrorMutex;
+    std::exception_ptr _asyncError; /* first failure of an asynchronous upload pipeline, not yet reported */
     std::mutex _initMutex;
     uint32_t _lastPasses;
     bool _lastRayLod = false;

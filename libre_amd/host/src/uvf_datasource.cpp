@@ -146,11 +146,18 @@ public:
         const Vector3ui dims = node.getBlockSize() + _volumeInfo.overlap * 2u;
         const size_t bytes = size_t( dims[0] ) * dims[1] * dims[2] * _volumeInfo.compCount *
                              _volumeInfo.getBytesPerVoxel();
-        if( _offset + e.offset + e.length > _size )
+        /* offsets and lengths come from the file: compare without letting a hostile value wrap */
+        if( _offset > _size || e.offset > _size - _offset || e.length > _size - _offset - e.offset )
             throw std::runtime_error( "UVF: brick outside the file" );
         const uint8_t* src = static_cast< const uint8_t* >( _map ) + _offset + e.offset;
         if( e.compression == 0 ) /* CT_NONE: the mapped file is the brick */
+        {
+            /* the uploader copies the brick's full size from this pointer: a shorter entry would be read
+             * past its end (and, at the end of the file, past the mapping) */
+            if( e.length != bytes )
+                throw std::runtime_error( "UVF: raw brick of the wrong size" );
             return MemoryUnitPtr( new ConstMemoryUnit( src, size_t( e.length ) ) );
+        }
         if( e.compression != 1 ) /* CT_ZLIB is the only codec the reference decodes (:274-287) */
             throw std::runtime_error( "UVF: unsupported brick compression" );
         std::shared_ptr< AllocMemoryUnit > mem( new AllocMemoryUnit( bytes ) );

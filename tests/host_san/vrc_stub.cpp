@@ -114,3 +114,35 @@ int vrc_post_render( vrc_ctx*, float* ) { return VRC_OK; }
 int vrc_synchronize( vrc_ctx* ) { return VRC_OK; }
 int vrc_get_stats( vrc_ctx*, vrc_stats* out ) { std::memset( out, 0, sizeof( *out ) ); return VRC_OK; }
 }
+
+/* sort-first tile exchange: a world of one rank, nothing to move */
+struct vrc_comm
+{
+    int rank, world;
+};
+extern "C" {
+int vrc_comm_unique_id( uint8_t id[VRC_COMM_ID_BYTES] )
+{
+    std::memset( id, 7, VRC_COMM_ID_BYTES );
+    return VRC_OK;
+}
+int vrc_comm_create( vrc_ctx*, int rank, int world, const uint8_t*, vrc_comm** out )
+{
+    if( world != 1 )
+        return VRC_ECOMM;
+    *out = new vrc_comm{ rank, world };
+    return VRC_OK;
+}
+void vrc_comm_destroy( vrc_comm* c ) { delete c; }
+int vrc_comm_info( const vrc_comm* c, int* rank, int* world )
+{
+    if( rank ) *rank = c->rank;
+    if( world ) *world = c->world;
+    return VRC_OK;
+}
+int vrc_gather_tiles( vrc_ctx*, vrc_comm*, const vrc_band*, uint32_t, uint32_t, uint32_t, const void*, size_t, void*,
+                      size_t, int, void* )
+{
+    return VRC_OK;
+}
+}

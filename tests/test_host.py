@@ -346,3 +346,6 @@ def test_pipeline_threads_under_thread_sanitizer(tmp_path):
         assert out.returncode == 0 and "DONE" in out.stdout, text
         assert "ThreadSanitizer" not in text, text
         assert "sync 1 cache 2 MB: available 512 not available 0 passes 4" in text
+        # a data source that throws on a loader thread: the render call reports it, nothing hangs
+        assert 'failing source, sync 1: render call 0 reported "' in text and "brick could not be read" in text
+        assert "failing source, sync 0: render call" in text and "reported \"nothing\"" not in text
