@@ -14,6 +14,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -227,13 +229,51 @@ private:
 class RawDataSource : public DataSourcePlugin
 {
 public:
-    explicit RawDataSource( const DataSourcePluginData& initData ) : _mmapPtr( nullptr ), _fd( -1 ), _size( 0 )
+    explicit RawDataSource( const DataSourcePluginData& initData )
+        : _mmapPtr( nullptr ), _fd( -1 ), _size( 0 ), _dataOffset( 0 )
     {
         const URI& uri = initData.getURI();
         const std::string& path = uri.getPath();
-        if( !endsWith( path, ".raw" ) && !endsWith( path, ".img" ) )
+        const bool isRaw = endsWith( path, ".raw" ) || endsWith( path, ".img" );
+        const bool isNrrd = endsWith( path, ".nrrd" );
+        if( !isRaw && !isNrrd )
             throw std::runtime_error( "Volume extension does not include raw or nrrd" );
-        _fd = ::open( path.c_str(), O_RDONLY );
+        std::vector< std::string > p = split( uri.getFragment(), ',' );
+        std::string dataFile = path;
+        if( isNrrd )
+        {
+            /* RawDataSource.cpp:181-215 + nrrd/nrrd.hxx parseHeader: "field: value" lines up to the first
+             * empty line; dimension must be 3, encoding raw; the voxels follow the header, or live in the
+             * file named by "datafile" next to the header.  (The reference applies the header's length
+             * to a detached data file as well, RawDataSource.cpp:189-197 + :126: bytes that are not a
+             * header are skipped.  Here a detached file is read from its start, as the format says.) */
+            std::map< std::string, std::string > fields;
+            const size_t headerSize = parseNrrdHeader( path, fields );
+            if( headerSize == 0 )
+                throw std::runtime_error( "Cannot parse nrrd file" );
+            if( fields.count( "encoding" ) && fields["encoding"] != "raw" )
+                throw std::runtime_error( "NRRD encoding is not raw" );
+            if( toUint( fields["dimension"] ) != 3u )
+                throw std::runtime_error( "NRRD is not 3D data" );
+            const std::vector< std::string > sizes = split( fields["sizes"], ' ' );
+            if( sizes.size() < 3 )
+                throw std::runtime_error( "NRRD sizes" );
+            if( fields.count( "datafile" ) )
+            {
+                const size_t slash = path.find_last_of( '/' );
+                dataFile = ( slash == std::string::npos ? std::string() : path.substr( 0, slash + 1 ) ) + fields["datafile"];
+            }
+            else
+                _dataOffset = headerSize;
+            _volumeInfo.bigEndian = fields.count( "endian" ) && fields["endian"] == "big";
+            /* the URI fragment of a .nrrd may still carry the bricking extension: "#,,,,block" is awkward, so
+             * a single number is taken as the block size */
+            const std::string block = p.size() == 1 && !p[0].empty() ? p[0] : std::string();
+            p = { sizes[0], sizes[1], sizes[2], nrrdTypeName( fields["type"] ) };
+            if( !block.empty() )
+                p.push_back( block );
+        }
+        _fd = ::open( dataFile.c_str(), O_RDONLY );
         struct stat sb;
         if( _fd == -1 || ::fstat( _fd, &sb ) == -1 )
             throw std::runtime_error( "Cannot mmap file" );
@@ -245,7 +285,6 @@ public:
             _mmapPtr = nullptr;
             throw std::runtime_error( "Cannot mmap file" );
         }
-        const std::vector< std::string > p = split( uri.getFragment(), ',' );
         if( p.size() < 4 )
             throw std::runtime_error( "Not enough parameters for the raw file" );
         _volumeInfo.voxels = Vector3ui( toUint( p[0] ), toUint( p[1] ), toUint( p[2] ) );
@@ -258,8 +297,8 @@ public:
         _volumeInfo.overlap = Vector3ui( 0u );
         _volumeInfo.rootNode = RootNode( 1, Vector3ui( 1 ) ); /* one brick = whole volume, depth 1 */
         _volumeInfo.maximumBlockSize = _volumeInfo.voxels;
-        if( size_t( _volumeInfo.voxels[0] ) * _volumeInfo.voxels[1] * _volumeInfo.voxels[2] *
-                _volumeInfo.getBytesPerVoxel() > _size )
+        if( _dataOffset > _size || size_t( _volumeInfo.voxels[0] ) * _volumeInfo.voxels[1] * _volumeInfo.voxels[2] *
+                                       _volumeInfo.getBytesPerVoxel() > _size - _dataOffset )
             throw std::runtime_error( "raw file smaller than the declared volume" );
         /* EXTENSION (beyond the reference, whose raw source is the single brick above): a fifth
          * fragment parameter = block size turns the file into an out-of-core bricked volume with
@@ -296,10 +335,60 @@ public:
         /* RawDataSource.cpp:123-129 reports blockSize.product() bytes whatever the voxel type
          * (quirk Q14); here the size includes bytes per voxel */
         const size_t dataSize = size_t( node.getBlockSize().product() ) * _volumeInfo.getBytesPerVoxel();
-        return MemoryUnitPtr( new ConstMemoryUnit( static_cast< const uint8_t* >( _mmapPtr ), dataSize ) );
+        return MemoryUnitPtr( new ConstMemoryUnit( static_cast< const uint8_t* >( _mmapPtr ) + _dataOffset, dataSize ) );
     }
 
 private:
+    /* nrrd/nrrd.hxx parseHeader: skip the magic line, then "field: value" / "key:=value" / "# comment" lines
+     * up to the first empty line; returns the offset of the first byte after it (0: cannot read) */
+    static size_t parseNrrdHeader( const std::string& path, std::map< std::string, std::string >& fields )
+    {
+        std::ifstream file( path.c_str(), std::ios::binary );
+        if( !file.good() )
+            return 0;
+        std::string line;
+        std::getline( file, line ); /* "NRRD000X" */
+        size_t offset = 0;
+        while( file.good() && std::getline( file, line ) )
+        {
+            if( file.tellg() != std::streampos( -1 ) )
+                offset = size_t( file.tellg() );
+            if( !line.empty() && line.back() == '\r' )
+                line.pop_back();
+            if( line.empty() ) /* beginning of the data chunk */
+                break;
+            if( line[0] == '#' )
+                continue;
+            const size_t colon = line.find( ':' );
+            if( colon == std::string::npos || colon + 1 >= line.size() )
+                return 0;
+            if( line[colon + 1] == ' ' )
+                fields[line.substr( 0, colon )] = line.substr( colon + 2 );
+            else if( line[colon + 1] != '=' )
+                return 0;
+        }
+        return offset;
+    }
+    /* nrrd.hxx maps every NRRD type name to its C type; RawDataSource::setDataType takes those */
+    static std::string nrrdTypeName( const std::string& t )
+    {
+        static const char* names[][2] = {
+            { "int8_t", "char" }, { "int8", "char" }, { "signed char", "char" }, { "char", "char" },
+            { "uchar", "unsigned char" }, { "uint8_t", "unsigned char" }, { "uint8", "unsigned char" },
+            { "unsigned char", "unsigned char" },
+            { "int16_t", "short" }, { "int16", "short" }, { "signed short int", "short" }, { "short int", "short" },
+            { "short", "short" },
+            { "ushort", "unsigned short" }, { "uint16_t", "unsigned short" }, { "uint16", "unsigned short" },
+            { "unsigned short int", "unsigned short" }, { "unsigned short", "unsigned short" },
+            { "int32_t", "int" }, { "int32", "int" }, { "signed int", "int" }, { "int", "int" },
+            { "uint32_t", "unsigned int" }, { "uint32", "unsigned int" }, { "uint", "unsigned int" },
+            { "unsigned int", "unsigned int" }, { "float", "float" } };
+        for( const auto& n : names )
+            if( t == n[0] )
+                return n[1];
+        throw std::runtime_error( "Cannot parse nrrd file" ); /* parseHeader returns 0 for an unknown type */
+    }
+
     /* brick + overlap of one LOD node, cut out of the mapped volume */
     MemoryUnitPtr cutBrick( const LODNode& node ) const
     {
@@ -307,7 +396,7 @@ private:
         const Vector3ui bs = node.getBlockSize() + _volumeInfo.overlap * 2u;
         std::shared_ptr< AllocMemoryUnit > mem( new AllocMemoryUnit( size_t( bs[0] ) * bs[1] * bs[2] * bpv ) );
         uint8_t* dst = mem->getData< uint8_t >();
-        const uint8_t* src = static_cast< const uint8_t* >( _mmapPtr );
+        const uint8_t* src = static_cast< const uint8_t* >( _mmapPtr ) + _dataOffset;
         uint32_t shift = _volumeInfo.rootNode.getDepth() - 1 - node.getRefLevel();
         const Vector3ui o = node.getVoxelBox().getMin();
         int64_t vx = _volumeInfo.voxels[0], vy = _volumeInfo.voxels[1], vz = _volumeInfo.voxels[2];
@@ -390,7 +479,7 @@ private:
             if( _pyramid[l].data )
                 continue;
             const size_t bpv = _volumeInfo.getBytesPerVoxel();
-            const uint8_t* prev = l == 1 ? static_cast< const uint8_t* >( _mmapPtr ) : _pyramid[l - 1].data.get();
+            const uint8_t* prev = l == 1 ? static_cast< const uint8_t* >( _mmapPtr ) + _dataOffset : _pyramid[l - 1].data.get();
             int64_t pd[3];
             for( int a = 0; a < 3; ++a )
                 pd[a] = l == 1 ? int64_t( _volumeInfo.voxels[a] ) : _pyramid[l - 1].dim[a];
@@ -438,6 +527,7 @@ private:
     void* _mmapPtr;
     int _fd;
     size_t _size;
+    size_t _dataOffset; /* .nrrd with the voxels behind the header: where they start */
     bool _bricked = false;
     mutable std::mutex _pyramidMutex;
     mutable std::vector< PyramidLevel > _pyramid;

@@ -702,3 +702,21 @@ def test_random_frame_sequences_equal_fresh_applications(drv, seed):
                 apply(ref, state)
                 want = ref.render_frame()[0]
             assert got.shape == want.shape and (got == want).all(), (seed, step, what, state, sync)
+
+
+def test_nrrd_volume_through_the_plugin_matches_the_oracle(drv):
+    # the reference's NRRD fixture (tests/lib/nucleon.nrrd -> nucleon.raw, 41^3 uint8, one brick, overlap 0)
+    # through data source, caches, upload and kernel, against the oracle's render of the same brick
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    s = scenes.nucleon_scene(viewport=(48, 48), spin=(0.4, 0.3), alpha=0.3)
+    want, n_want = orc.oracle_render(s, threads=8)
+    from libre_amd import vrc
+    with drv.App("raw://" + os.path.join(gdir, "nucleon.nrrd"), 48, 48, synchronous=True, gpu_cache_mb=16) as app:
+        app.set_camera(spin=(0.4, 0.3))
+        app.set_colormap(orc.linear_ramp_tf(0.3))
+        app.set_option(vrc.OPT_COUNT_SAMPLES, 1)
+        fb, st = app.render_frame()
+        assert st.n_available == 1 and st.samples_per_ray == s.render.samplesPerRay
+        scenes.assert_parity(fb, want, "nucleon.nrrd through the plugin")
+        assert abs(int(app.stats().samples) - n_want) <= 8

@@ -148,6 +148,49 @@ def test_raw_data_source_single_brick(drv):
     assert b"No plugin implementation available" in L.lvh_last_error()
 
 
+def test_raw_data_source_nrrd_header(drv, tmp_path):
+    # tests/lib/rawDatasource.cpp:70-74 (NRRDDataSource) with the reference's fixture nucleon.nrrd, whose
+    # voxels live in the detached nucleon.raw next to it (datasources/raw/RawDataSource.cpp:181-215,
+    # nrrd/nrrd.hxx parseHeader): the known answers of createAndCheckDataSource (:32-68) -- uint8, 41^3, depth 1,
+    # one brick = the volume, brick bytes = blockSize.product() * compCount * bytesPerVoxel -- and the voxels
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    uri = "raw://" + os.path.join(gdir, "nucleon.nrrd")
+    info = drv.datasource_info(uri)
+    assert info["voxels"] == [41, 41, 41] and info["max_block"] == [41, 41, 41] and info["overlap"] == [0, 0, 0]
+    assert info["depth"] == 1 and info["data_type"] == 1 and info["comp_count"] == 1 and info["root_blocks"] == [1, 1, 1]
+    node = drv.datasource_node(uri, orc.pack(0, 0, 0, 0))
+    assert node["valid"] and node["block_size"] == [41, 41, 41]
+    raw = np.fromfile(os.path.join(gdir, "nucleon.raw"), dtype=np.uint8)
+    got = drv.datasource_brick(uri, orc.pack(0, 0, 0, 0))
+    assert got.size == 41 ** 3 and (got == raw).all()
+    # the same volume with the voxels behind the header in one file, 16-bit, declared little endian, with a
+    # comment, a key/value pair and CR LF line ends: the data starts behind the first empty line
+    vol = (np.arange(6 * 5 * 4, dtype=np.uint16) * 517).reshape(4, 5, 6)
+    hdr = ("NRRD0004\r\n# made by a test\r\ntype: unsigned short\r\ndimension: 3\r\nsizes: 6 5 4\r\n"
+           "encoding: raw\r\nendian: little\r\nmodality:=test\r\n\r\n").encode()
+    attached = tmp_path / "attached.nrrd"
+    attached.write_bytes(hdr + vol.tobytes())
+    uri2 = "raw://" + str(attached)
+    info2 = drv.datasource_info(uri2)
+    assert info2["voxels"] == [6, 5, 4] and info2["data_type"] == 2 and info2["depth"] == 1
+    got2 = drv.datasource_brick(uri2, orc.pack(0, 0, 0, 0)).view(np.uint16)
+    assert (got2 == vol.reshape(-1)).all()
+    # what the reference refuses: not three-dimensional, unknown type, another encoding, no header at all
+    L = drv.load_library()
+    n = C.c_size_t()
+    for bad, msg in ((b"NRRD0004\ntype: uchar\ndimension: 2\nsizes: 4 4\nencoding: raw\n\n" + bytes(16), b"not 3D"),
+                     (b"NRRD0004\ntype: complex\ndimension: 3\nsizes: 2 2 2\nencoding: raw\n\n" + bytes(8), b"parse"),
+                     (b"NRRD0004\ntype: uchar\ndimension: 3\nsizes: 2 2 2\nencoding: gzip\n\n" + bytes(8), b"encoding"),
+                     (b"NRRD0004\ntype: uchar\ndimension: 3\nsizes: 4 4 4\nencoding: raw\n\n" + bytes(8), b"smaller")):
+        f = tmp_path / "bad.nrrd"
+        f.write_bytes(bad)
+        assert L.lvh_datasource_brick(("raw://" + str(f)).encode(), 0, None, 0, C.byref(n)) != 0
+        assert msg in L.lvh_last_error(), (msg, L.lvh_last_error())
+    assert L.lvh_datasource_brick(b"raw:///tmp/volume.txt#4,4,4,uint8", 0, None, 0, C.byref(n)) != 0
+    assert b"does not include raw or nrrd" in L.lvh_last_error()
+
+
 @pytest.mark.parametrize("dtype", ["uint8", "uint16"])
 def test_raw_data_source_bricked_out_of_core(drv, tmp_path, dtype):
     # EXTENSION (BASELINE C3): a fifth fragment parameter bricks the raw file with the tree and
