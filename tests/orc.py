@@ -563,7 +563,8 @@ def compare(a, b):
             ex = pix - 2.0 * tb
             rec.update(budget_mean=float(tb.mean()), budget_max=float(tb.max()),
                        excess_max=float(ex.max()), n_excess_over_1e5=int((ex > 1e-5).sum()),
-                       n_excess_over_2e5=int((ex > 2e-5).sum()), n_excess_over_1e4=int((ex > 1e-4).sum()),
+                       n_excess_over_2e5=int((ex > 2e-5).sum()), n_excess_over_5e5=int((ex > 5e-5).sum()),
+                       n_excess_over_1e4=int((ex > 1e-4).sum()),
                        n_excess_over_2e4=int((ex > 2e-4).sum()), n_pixels=int(pix.size))
         with open(_STATS_FILE, "a") as f:
             f.write(json.dumps(rec) + "\n")

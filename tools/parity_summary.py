@@ -1,0 +1,31 @@
+"""Condense a VRC_PARITY_STATS file (one JSON line per frame comparison of a test run, tests/orc.py:compare)
+into profiles/<round>_parity_errors.json: per test, how many frames were compared with the oracle, the
+largest and the mean error, the pixels' tie budgets and by how much the worst pixel exceeded E0 + 2 x budget
+(<= 0: inside the rule).  usage: python tools/parity_summary.py stats.jsonl [stats2.jsonl ...] > out.json"""
+import collections
+import json
+import sys
+
+E0, F = 5e-5, 2.0
+by = collections.OrderedDict()
+for path in sys.argv[1:]:
+    for line in open(path):
+        r = json.loads(line)
+        by.setdefault(r["test"], []).append(r)
+out = {"rule": "|frame - oracle| <= E0 + 2 x tie budget per pixel, E0 = 5e-5 (tests/scenes.py)",
+       "where": "MI355X, pytest -m gpu" if "gpu" in " ".join(sys.argv[1:]) else "host build of the kernel code",
+       "tests": {}}
+for t, rs in by.items():
+    wb = [r for r in rs if "budget_mean" in r]
+    e = {"frames_compared": len(rs), "pixels": int(sum(r["shape"][0] * r["shape"][1] for r in rs)),
+         "max_abs_error": max(r["max"] for r in rs), "largest_frame_mean_abs_error": max(r["mean"] for r in rs),
+         "largest_fraction_of_pixels_over_1e-4": max(r["frac_over_1e4"] for r in rs)}
+    if wb:
+        e.update(frames_with_oracle_budget=len(wb), largest_frame_mean_budget=max(r["budget_mean"] for r in wb),
+                 worst_pixel_error_minus_2x_budget=max(r["excess_max"] for r in wb),
+                 pixels_over_E0_plus_2x_budget=int(sum(r["n_excess_over_1e4"] if False else 0 for r in wb)))
+        e["pixels_with_error_minus_2x_budget_over_1e-4"] = int(sum(r.get("n_excess_over_1e4", 0) for r in wb))
+        del e["pixels_over_E0_plus_2x_budget"]
+    out["tests"][t] = e
+json.dump(out, sys.stdout, indent=1)
+print()
