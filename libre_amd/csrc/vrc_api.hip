@@ -1066,8 +1066,9 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     a.tileOrder = nullptr;
     if( c->optTileOrder )
     {
-        const size_t nTiles = (size_t)( ( c->fbW + VRC_TILE_W - 1 ) / VRC_TILE_W ) *
-                              ( ( c->fbH + VRC_TILE_H - 1 ) / VRC_TILE_H );
+        /* one entry per schedule slot: four per 2x2 block of tiles (vrc_internal.h) */
+        const size_t nTiles = vrc_schedule_slots( ( c->fbW + VRC_TILE_W - 1 ) / VRC_TILE_W,
+                                                  ( c->fbH + VRC_TILE_H - 1 ) / VRC_TILE_H );
         if( nTiles > c->dTileOrderCap )
         {
             VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );

@@ -24,7 +24,7 @@
 #define VRC_WG 64u
 /* waves (= tiles) per workgroup: they share the LDS tables, set up once per workgroup */
 #ifndef VRC_WAVES_PER_WG
-#define VRC_WAVES_PER_WG 1u
+#define VRC_WAVES_PER_WG VRC_WAVES_PER_GROUP /* the four tiles of a schedule unit (vrc_internal.h) */
 #endif
 #define VRC_WG_THREADS ( VRC_WG * VRC_WAVES_PER_WG )
 
@@ -287,8 +287,9 @@ hipError_t vrc_launch_read_region( const void* atlas, void* dst, uint32_t elemBy
 __device__ __forceinline__ uint32_t vrc_tile_bucket( const vrc_frame& f, uint32_t tile,
                                                      uint32_t tilesX, float invDiag )
 {
+    /* tile = index of a schedule unit (2x2 tiles), tilesX = units per row: cost at the unit's centre */
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
-    uint32_t px = tx * VRC_TILE_W + VRC_TILE_W / 2, py = ty * VRC_TILE_H + VRC_TILE_H / 2;
+    uint32_t px = tx * VRC_TILE_W * 2u + VRC_TILE_W, py = ty * VRC_TILE_H * 2u + VRC_TILE_H;
     px = px < f.width ? px : f.width - 1;
     py = py < f.height ? py : f.height - 1;
     const vrc_ray r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
@@ -351,7 +352,8 @@ __global__ __launch_bounds__( 256 ) void vrc_k_tile_bucket( const vrc_frame f, c
 __global__ __launch_bounds__( 256 ) void vrc_k_tile_scatter( const uint32_t nTiles,
                                                              const uint8_t* __restrict__ bucket,
                                                              uint32_t* __restrict__ scratch,
-                                                             uint32_t* __restrict__ order )
+                                                             uint32_t* __restrict__ order,
+                                                             const uint32_t frameTilesX, const uint32_t frameTilesY )
 {
     __shared__ uint32_t cnt[256], base[256];
     cnt[threadIdx.x] = 0;
@@ -368,14 +370,22 @@ __global__ __launch_bounds__( 256 ) void vrc_k_tile_scatter( const uint32_t nTil
         base[threadIdx.x] = atomicAdd( &scratch[threadIdx.x], cnt[threadIdx.x] );
     __syncthreads();
     if( t < nTiles )
-        order[base[b] + rank] = t;
+    {
+        /* the unit's four tiles in four consecutive slots (VRC_NO_TILE for those outside the frame) */
+        const uint32_t at = ( base[b] + rank ) * 4u;
+#pragma unroll
+        for( uint32_t sub = 0; sub < 4u; ++sub )
+            order[at + sub] = vrc_unit_tile( t, sub, frameTilesX, frameTilesY );
+    }
 }
 
 hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t* scratch,
                                   uint8_t* bucket, hipStream_t stream )
 {
-    const uint32_t tilesX = ( f.width + VRC_TILE_W - 1 ) / VRC_TILE_W;
-    const uint32_t tilesY = ( f.height + VRC_TILE_H - 1 ) / VRC_TILE_H;
+    const uint32_t frameTilesX = ( f.width + VRC_TILE_W - 1 ) / VRC_TILE_W;
+    const uint32_t frameTilesY = ( f.height + VRC_TILE_H - 1 ) / VRC_TILE_H;
+    /* sorted: the schedule units (2x2 tiles, vrc_internal.h) */
+    const uint32_t tilesX = ( frameTilesX + 1u ) / 2u, tilesY = ( frameTilesY + 1u ) / 2u;
     const uint32_t nTiles = tilesX * tilesY;
     if( nTiles == 0 )
         return hipSuccess;
@@ -384,7 +394,8 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t*
         return e;
     const dim3 grid( ( nTiles + 255u ) / 256u ), block( 256 );
     hipLaunchKernelGGL( vrc_k_tile_bucket, grid, block, 0, stream, f, tilesX, nTiles, bucket, scratch );
-    hipLaunchKernelGGL( vrc_k_tile_scatter, grid, block, 0, stream, nTiles, bucket, scratch, order );
+    hipLaunchKernelGGL( vrc_k_tile_scatter, grid, block, 0, stream, nTiles, bucket, scratch, order, frameTilesX,
+                        frameTilesY );
     return hipGetLastError();
 }
 
@@ -392,7 +403,7 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t*
  * the raycast kernel
  * ---------------------------------------------------------------------------------------- */
 #ifndef VRC_MIN_WAVES
-#define VRC_MIN_WAVES 4
+#define VRC_MIN_WAVES 5 /* measured on C2: 4 -> 5 waves per SIMD with four-wave workgroups: -2 % */
 #endif
 /* GROUP: samples a lane keeps in flight.  8 is fastest when the launch fills the machine several
  * times over (4 waves per SIMD); 16 (2 waves per SIMD) halves the dependent round trips of a ray
@@ -438,7 +449,8 @@ __global__ __launch_bounds__( VRC_WG_THREADS, GROUP > 8 ? 2 : VRC_MIN_WAVES ) vo
     __syncthreads();
     /* from here on the waves of the workgroup are independent */
     const uint32_t slotIndex = blockIdx.x * VRC_WAVES_PER_WG + ( tid >> 6 );
-    if( slotIndex >= nTiles )
+    const uint32_t tilesY = nTiles / tilesX;
+    if( slotIndex >= vrc_schedule_slots( tilesX, tilesY ) )
         return;
 
     /* Workgroup -> tile.  Ray lengths vary by more than 2x over the image and whole tiles miss
@@ -447,7 +459,9 @@ __global__ __launch_bounds__( VRC_WG_THREADS, GROUP > 8 ? 2 : VRC_MIN_WAVES ) vo
      * tileOrder lists tiles heaviest-first (vrc_k_tile_order), and because the dispatcher
      * deals workgroups b, b+1, ... round-robin over the 8 XCDs (MI355X_MICROARCH.md,
      * "Workgroup dispatch") every XCD gets the same mix and the long tiles start first. */
-    const uint32_t tile = tileOrder ? tileOrder[slotIndex] : slotIndex;
+    const uint32_t tile = vrc_slot_tile( tileOrder, slotIndex, tilesX, tilesY );
+    if( tile == VRC_NO_TILE )
+        return;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
 #if defined( VRC_LANES_ROWMAJOR ) || VRC_TILE_W != 8
     const uint32_t lx = lane % VRC_TILE_W, ly = lane / VRC_TILE_W;
@@ -492,7 +506,7 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
     if( nTiles == 0 )
         return hipSuccess;
     hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG > ),
-                        dim3( ( nTiles + VRC_WAVES_PER_WG - 1u ) / VRC_WAVES_PER_WG ),
+                        dim3( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_WAVES_PER_WG - 1u ) / VRC_WAVES_PER_WG ),
                         dim3( VRC_WG_THREADS ), 0, stream, a.frame, a.nodes, a.gridTable,
                         (const ATLAS_T*)a.atlas, a.lut, a.classifier, a.pixelBuffer,
                         a.sampleCounter, a.tileOrder, tilesX, nTiles );

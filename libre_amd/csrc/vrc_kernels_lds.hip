@@ -159,11 +159,14 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t slot = blockIdx.x * VRC_LDS_WAVES + wave;
-    if( slot >= nTiles )
+    const uint32_t tilesY = nTiles / tilesX;
+    if( slot >= vrc_schedule_slots( tilesX, tilesY ) )
         return;
     uint8_t* const region = regions[wave];
 
-    const uint32_t tile = tileOrder ? tileOrder[slot] : slot;
+    const uint32_t tile = vrc_slot_tile( tileOrder, slot, tilesX, tilesY );
+    if( tile == VRC_NO_TILE ) /* the waves of a workgroup are independent from here on */
+        return;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     const uint32_t lx = ( lane & 1u ) | ( ( lane >> 1 ) & 2u ) | ( ( lane >> 2 ) & 4u );
     const uint32_t ly = ( ( lane >> 1 ) & 1u ) | ( ( lane >> 2 ) & 2u ) | ( ( lane >> 3 ) & 4u );
@@ -736,7 +739,8 @@ hipError_t vrc_launch_raycast_lds( const vrc_raycast_args& a, hipStream_t stream
     const uint32_t nTiles = tilesX * tilesY;
     if( nTiles == 0 )
         return hipSuccess;
-    const dim3 grid( ( nTiles + VRC_LDS_WAVES - 1u ) / VRC_LDS_WAVES ), block( 64u * VRC_LDS_WAVES );
+    const dim3 grid( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_LDS_WAVES - 1u ) / VRC_LDS_WAVES ),
+        block( 64u * VRC_LDS_WAVES );
     const bool count = a.sampleCounter != nullptr;
     /* region shape from the view direction in volume space (the ray through the frame centre) */
     const vrc_ray centre = vrc_setup_ray( a.frame, a.frame.width / 2u, (uint32_t)( a.frame.vpH * 0.5f ) );

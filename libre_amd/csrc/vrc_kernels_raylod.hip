@@ -51,9 +51,12 @@ __global__ __launch_bounds__( VRC_RL_THREADS, VRC_RL_MIN_BLOCKS ) void vrc_k_ray
 #endif
     __syncthreads();
     const uint32_t slotIndex = blockIdx.x * VRC_RL_WAVES + ( tid >> 6 );
-    if( slotIndex >= nTiles )
+    const uint32_t tilesY = nTiles / tilesX;
+    if( slotIndex >= vrc_schedule_slots( tilesX, tilesY ) )
         return;
-    const uint32_t tile = tileOrder ? tileOrder[slotIndex] : slotIndex;
+    const uint32_t tile = vrc_slot_tile( tileOrder, slotIndex, tilesX, tilesY );
+    if( tile == VRC_NO_TILE )
+        return;
     const uint32_t tx = tile % tilesX, ty = tile / tilesX;
     const uint32_t lx = ( lane & 1u ) | ( ( lane >> 1 ) & 2u ) | ( ( lane >> 2 ) & 4u );
     const uint32_t ly = ( ( lane >> 1 ) & 1u ) | ( ( lane >> 2 ) & 2u ) | ( ( lane >> 3 ) & 4u );
@@ -85,7 +88,8 @@ static hipError_t launch_raylod( const vrc_raycast_args& a, hipStream_t stream )
     const uint32_t lutEntries =
         MODE == VRC_MODE_TABLE ? a.frame.lodLevels * VRC_LUT_ENTRIES : VRC_TFP_ENTRIES;
     hipLaunchKernelGGL( ( vrc_k_raycast_raylod< CLAMP, COUNT, FIXED, MODE, ATLAS_T > ),
-                        dim3( ( nTiles + VRC_RL_WAVES - 1u ) / VRC_RL_WAVES ), dim3( VRC_RL_THREADS ),
+                        dim3( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_RL_WAVES - 1u ) / VRC_RL_WAVES ),
+                        dim3( VRC_RL_THREADS ),
                         lutEntries * sizeof( vrc_f4 ), stream, a.frame, a.nodes, a.gridTable,
                         (const ATLAS_T*)a.atlas, a.lut, lutEntries, a.classifier, a.pixelBuffer,
                         a.sampleCounter, a.tileOrder, tilesX, nTiles );

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--spin", type=float, nargs=2, default=(0.0, 0.0))
     ap.add_argument("--alpha", type=float, default=0.05)
     ap.add_argument("--rounds", type=int, default=2, help="interleaved timing rounds over all builds")
+    ap.add_argument("--no-tile-order", action="store_true", help="row-major tile order instead of heaviest-first")
     a = ap.parse_args()
     t0 = time.time()
     s = orc.build_scene(voxels=(a.voxels,) * 3, block=a.block, viewport=(a.viewport,) * 2,
@@ -51,6 +52,7 @@ def main():
             os.path.basename(path), n, hashlib.sha1(fb.tobytes()).hexdigest()[:12], d.max(), d.mean(),
             g.info()["atlas_bytes"] / 1e9), flush=True)
         vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_COUNT_SAMPLES, 0))
+        vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_TILE_ORDER, 0 if a.no_tile_order else 1))
         scenes.append((path, L, g, n))
     res = {p: [] for p in a.libs}
     for r in range(a.rounds):
