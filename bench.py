@@ -145,6 +145,27 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+
+    if os.environ.get("BENCH_DRY_RUN"):
+        # launcher + control plane only (tests/test_sortfirst_gloo.py, no GPU): ranks rendezvous, agree on the
+        # world size, exchange what the real run exchanges, and rank 0 says so
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            assert dist.get_world_size() == a.gpus == world
+            uid = torch.full((128,), 7 if rank == 0 else 0, dtype=torch.uint8)
+            dist.broadcast(uid, src=0)
+            t = torch.tensor([float(rank)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.barrier()
+            ok = bool((uid == 7).all()) and int(t.item()) == world - 1
+            dist.destroy_process_group()
+        else:
+            ok = True
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ok": ok}), flush=True)
+        sys.exit(0 if ok else 1)
+
     from libre_amd import driver, sortfirst, vrc
 
     if not torch.cuda.is_available():

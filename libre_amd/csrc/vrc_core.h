@@ -771,7 +771,10 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
 #if defined( VRC_TAIL_GROUP )
     constexpr int TAILG = VRC_TAIL_GROUP;
 #else
-    constexpr int TAILG = GROUP / 2; /* measured on C2: 0.500 -> 0.491 ms against tail groups of GROUP */
+    /* measured on C2 (groups of 8): tail groups of 8 / 4 / 2 / 1: 0.500 / 0.491 / 0.484 / 0.502 ms relative:
+     * fewer gather slots spent on steps no lane takes, until the dependent round trips of a short group
+     * cost more than the slots did */
+    constexpr int TAILG = GROUP >= 8 ? GROUP / 4 : ( GROUP >= 2 ? GROUP / 2 : 1 );
 #endif
     while( travel > 0.0f && !done )
     {

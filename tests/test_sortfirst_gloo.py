@@ -144,3 +144,30 @@ def test_batched_gather_refuses_unequal_row_counts():
     from libre_amd import sortfirst
     with pytest.raises(ValueError):
         sortfirst.BatchedTileGather(sortfirst.band_layout(50, 3, 2), 8, 0, "cpu", 2)
+
+
+def test_bench_starts_its_own_ranks():
+    # `python bench.py --gpus N` with no launcher around it starts N ranks itself (RANK / LOCAL_RANK /
+    # WORLD_SIZE / MASTER_* set, fresh processes) and relays their exit status; BENCH_DRY_RUN stops each
+    # rank after the rendezvous and the control-plane exchanges (no GPU here)
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BENCH_DRY_RUN="1", BENCH_FORCE_DEVICE="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_run": True, "n_gpus": 3, "ok": True}
+    # under a launcher (WORLD_SIZE set) the process is one rank: no second level of processes
+    env1 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], env=env1,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    # more ranks than GPUs, no rehearsal knob: refused loudly, nothing started
+    env2 = {k: v for k, v in env.items() if k != "BENCH_FORCE_DEVICE"}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "GPU(s) visible" in out.stderr
