@@ -603,7 +603,7 @@ def main():
         # measured HBM traffic per launch, from the committed rocprofv3 PMC passes (bench.py cannot
         # run the profiler on itself); only quoted for the workload it was measured on
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_traffic_c2.json")
+        tpath = os.path.join(ROOT, "profiles", "r2_traffic_c2.json")
         if (world == 1 and a.voxels == 1024 and a.block == 128 and a.viewport == 1024
                 and tuple(a.spin) == (0.0, 0.0) and not ray_lod_on and os.path.exists(tpath)):
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
@@ -666,7 +666,7 @@ def main():
                          "note": "the kernel is bound by the texture-addresser (byte gathers, "
                                  "TA_BUSY ~90 %) with VALU issue close behind, not by HBM "
                                  "(DESIGN.md section 4); traffic = FETCH_SIZE + WRITE_SIZE bytes per "
-                                 "launch from profiles/r1_traffic_c2.json"},
+                                 "launch from profiles/r2_traffic_c2.json"},
         }
         if world == 1 and not a.no_cpu_baseline and not ray_lod_on:
             try:
