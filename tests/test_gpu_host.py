@@ -273,6 +273,63 @@ def test_out_of_core_raw_uint16_volume_matches_oracle(drv, tmp_path):
         assert (out == fb).all()
 
 
+def test_c3_shape_out_of_core_uint16_136_cubed_slots_async_upload_and_lod_cut(drv, tmp_path):
+    # BASELINE C3 at a size a test can afford, in C3's shapes: a 512^3 uint16 raw:// file (256 MB) bricked on demand
+    # with block 128 -> slots of 136^3 two-byte voxels, LOD octree (depth 3), 512^2 viewport.  (i) synchronous,
+    # leaves only: every 32nd row against the oracle, sample counts equal; (ii) asynchronous upload overlapped
+    # with the march, screen-space-error LOD cut (mixed levels): converges to the frame the synchronous
+    # pipeline renders for the same cut, and that frame matches the oracle.  The full 2048^3 run (17 GB file,
+    # 22.6 GB atlas of more than 2^32 voxels) is tools/dev_c3.py (profiles/r1_c3_out_of_core_uint16_2048.txt).
+    from libre_amd import vrc
+    vol = (orc.hash_volume(512, 512, 512).astype(np.uint16) * np.uint16(257)) ^ np.uint16(0x0155)
+    path = str(tmp_path / "vol512_u16.raw")
+    vol.tofile(path)
+    uri = "raw://%s#512,512,512,uint16,128" % path
+    rng_ = (0.0, 65535.0)
+    with drv.App(uri, 512, 512, synchronous=True, min_lod=2, max_lod=2, gpu_cache_mb=1024, cpu_cache_mb=2048) as app:
+        assert app.volume_info()["depth"] == 3 and app.volume_info()["max_block"] == [136, 136, 136]
+        app.set_camera(spin=(0.3, 0.2))
+        app.set_colormap(orc.linear_ramp_tf(0.05))
+        app.set_data_range(*rng_)
+        app.set_option(vrc.OPT_COUNT_SAMPLES, 1)
+        fb, st = app.render_frame()
+        assert st.n_available == 64 and st.n_passes == 1
+        n_gpu = int(app.stats().samples)
+        s = orc.build_scene(voxels=(512, 512, 512), block=128, viewport=(512, 512), spin=(0.3, 0.2), volume=vol,
+                            dtype="u16", ids=app.visible_set(), data_range=rng_, order=app.node_order())
+        assert s.slot_dim == [136, 136, 136]
+        want, n_rows = orc.oracle_render(s, threads=16, rows=(0, 512, 32))
+        scenes.assert_parity(fb[::32], want[::32], "C3 shape, leaves, synchronous")
+        full, n_want = orc.oracle_render(s, threads=16)
+        assert n_gpu == n_want
+    kw = dict(sse=2.0, gpu_cache_mb=1024, cpu_cache_mb=2048)
+    with drv.App(uri, 512, 512, synchronous=True, **kw) as app:
+        app.set_camera(spin=(0.3, 0.2))
+        app.set_colormap(orc.linear_ramp_tf(0.05))
+        app.set_data_range(*rng_)
+        cut, st = app.render_frame()
+        ids = app.visible_set()
+        assert len({i & 0xF for i in ids}) >= 2  # the cut mixes levels
+        s2 = orc.build_scene(voxels=(512, 512, 512), block=128, viewport=(512, 512), spin=(0.3, 0.2), volume=vol,
+                             dtype="u16", ids=ids, data_range=rng_, order=app.node_order())
+        want2, _ = orc.oracle_render(s2, threads=16, rows=(0, 512, 32))
+        scenes.assert_parity(cut[::32], want2[::32], "C3 shape, LOD cut, synchronous")
+    with drv.App(uri, 512, 512, synchronous=False, **kw) as app:
+        app.set_camera(spin=(0.3, 0.2))
+        app.set_colormap(orc.linear_ramp_tf(0.05))
+        app.set_data_range(*rng_)
+        frames = 0
+        for frames in range(1, 400):
+            out, st = app.render_frame()  # marches what is resident while the loaders work
+            assert np.isfinite(out).all()
+            if st.n_not_available == 0:
+                break
+            app.wait_uploads()
+        assert st.n_not_available == 0 and frames >= 2  # the first frame had bricks missing
+        out, _ = app.render_frame()
+        scenes.assert_same_frame(out, cut, "C3 shape, asynchronous upload converged")
+
+
 def test_glraycaster_variant_through_the_plugin(drv):
     # VRC_OPT_VARIANT on the renderer plugin: GLSL-twin semantics + RGBA8 transfer function
     from libre_amd import vrc
