@@ -101,6 +101,10 @@ typedef struct
                                    * finds the bricks of a ray through the brick grid: the order of the node
                                    * list does not matter to it */
 
+#define VRC_OPT_KERNEL_TIMING 9    /* 1 (default): a HIP event pair around every raycast launch feeds vrc_get_stats'
+                                   * kernel times; 0: no events (two host calls less per vrc_render; vrc_get_stats
+                                   * then reports 0 ms and 0 launches) */
+
 #define VRC_VARIANT_CUDARAYCASTER 0 /* renderers/cudaRaycaster/cuda/Renderer.cu:95-230 */
 #define VRC_VARIANT_GLRAYCASTER 1   /* renderers/glRaycaster/shaders/fragRaycast.glsl:113-215: pixel centre
                                      * +0.5, hit test t0 <= t1, first sample of a brick snapped to the

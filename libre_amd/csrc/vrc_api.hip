@@ -165,6 +165,7 @@ struct vrc_ctx
     int64_t optFilter = 0;
     int64_t optTfFracBits = 8;
     int64_t optCount = 0;
+    int64_t optTiming = 1;
 
     vrc_stats stats = {};
 };
@@ -291,6 +292,7 @@ int vrc_set_option( vrc_ctx* c, int option, int64_t value )
     case VRC_OPT_COUNT_SAMPLES: c->optCount = value ? 1 : 0; return VRC_OK;
     case VRC_OPT_TILE_ORDER: c->optTileOrder = value ? 1 : 0; return VRC_OK;
     case VRC_OPT_STEPPING: c->optStepping = value ? 1 : 0; return VRC_OK;
+    case VRC_OPT_KERNEL_TIMING: c->optTiming = value ? 1 : 0; return VRC_OK;
     case VRC_OPT_VARIANT:
         if( value != VRC_VARIANT_CUDARAYCASTER && value != VRC_VARIANT_GLRAYCASTER )
             return fail( VRC_EINVAL, "vrc_set_option: variant is 0 (cudaRaycaster) or 1 (glRaycaster)" );
@@ -312,6 +314,7 @@ int vrc_get_option( vrc_ctx* c, int option, int64_t* value )
     case VRC_OPT_COUNT_SAMPLES: *value = c->optCount; return VRC_OK;
     case VRC_OPT_TILE_ORDER: *value = c->optTileOrder; return VRC_OK;
     case VRC_OPT_STEPPING: *value = c->optStepping; return VRC_OK;
+    case VRC_OPT_KERNEL_TIMING: *value = c->optTiming; return VRC_OK;
     case VRC_OPT_VARIANT: *value = c->optVariant; return VRC_OK;
     case VRC_OPT_KERNEL_USED: *value = c->stats.kernel_variant; return VRC_OK;
     default: return fail( VRC_EINVAL, "vrc_get_option: unknown option" );
@@ -1140,7 +1143,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     }
     if( c->optCount )
         VRC_HIP_CHECK( hipMemsetAsync( c->dCounter, 0, sizeof( unsigned long long ), c->stream ) );
-    if( c->evUsed == c->evPairs.size() )
+    if( c->optTiming && c->evUsed == c->evPairs.size() )
     {
         if( c->evPairs.size() >= 4096 )
         {
@@ -1164,12 +1167,15 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
             c->evPairs.push_back( { a0, a1 } );
         }
     }
-    const auto& evp = c->evPairs[c->evUsed++];
-    VRC_HIP_CHECK( hipEventRecord( evp.first, c->stream ) );
+    const std::pair< hipEvent_t, hipEvent_t > evp =
+        c->optTiming ? c->evPairs[c->evUsed++] : std::pair< hipEvent_t, hipEvent_t >( nullptr, nullptr );
+    if( c->optTiming )
+        VRC_HIP_CHECK( hipEventRecord( evp.first, c->stream ) );
     VRC_HIP_CHECK( c->rayLod ? vrc_launch_raycast_raylod( a, c->stream )
                    : useLds  ? vrc_launch_raycast_lds( a, c->stream )
                              : vrc_launch_raycast( a, c->stream ) );
-    VRC_HIP_CHECK( hipEventRecord( evp.second, c->stream ) );
+    if( c->optTiming )
+        VRC_HIP_CHECK( hipEventRecord( evp.second, c->stream ) );
     {
         /* render fence of this context on the pool (see pool_upload) */
         std::lock_guard< std::mutex > lock( pool->mutex );
@@ -1187,7 +1193,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     if( c->optCount )
         VRC_HIP_CHECK( hipMemcpyAsync( c->hCounter, c->dCounter, sizeof( unsigned long long ),
                                        hipMemcpyDeviceToHost, c->stream ) );
-    c->timed = true;
+    c->timed = true; /* a render has happened: vrc_get_stats has something to report */
     c->stats.kernel_variant =
         c->rayLod ? VRC_KERNEL_RAY_LOD
         : useLds  ? VRC_KERNEL_LDS
@@ -1240,7 +1246,7 @@ int vrc_get_stats( vrc_ctx* c, vrc_stats* out )
     VRC_HIP_CHECK( hipSetDevice( c->device ) );
     c->stats.kernel_ms_sum = 0.0;
     c->stats.kernel_launches = 0;
-    if( c->timed && c->evUsed > 0 )
+    if( c->evUsed > 0 )
     {
         VRC_HIP_CHECK( hipEventSynchronize( c->evPairs[c->evUsed - 1].second ) );
         float ms = 0.f;
@@ -1256,6 +1262,12 @@ int vrc_get_stats( vrc_ctx* c, vrc_stats* out )
         c->stats.kernel_launches += c->evFoldedLaunches;
         c->evFoldedMs = 0.0;
         c->evFoldedLaunches = 0;
+    }
+    else if( !c->optTiming )
+        c->stats.kernel_ms = 0.f;
+    if( c->timed )
+    {
+        /* the sample counter of the last vrc_render (VRC_OPT_COUNT_SAMPLES) */
         if( c->optCount )
         {
             VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );

@@ -922,3 +922,17 @@ def test_gather_tiles_places_bands_at_their_rows(vrc):
     assert any(uid.raw)
     L.vrc_comm_destroy(comm)
     L.vrc_ctx_destroy(ctx)
+
+
+def test_kernel_timing_can_be_switched_off(vrc):
+    # VRC_OPT_KERNEL_TIMING = 0: no event pair around the launch; the frame and the sample counter are unaffected
+    s = scenes.get("hash64_spin")
+    with _gpu(s) as g:
+        fb, n, st = g.render()
+        assert st.kernel_launches == 1 and st.kernel_ms > 0.0
+        vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_KERNEL_TIMING, 0))
+        fb2, n2, st2 = g.render()
+        assert (fb2 == fb).all() and n2 == n and st2.kernel_launches == 0 and st2.kernel_ms_sum == 0.0
+        vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_KERNEL_TIMING, 1))
+        _, _, st3 = g.render()
+        assert st3.kernel_launches == 1 and st3.kernel_ms > 0.0
