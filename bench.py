@@ -253,7 +253,17 @@ def main():
             bgather.send[0, 0].fill_(float(rank + 1))
             torch.cuda.synchronize()
             bgather.gather(0, 1, torch.cuda.current_stream().cuda_stream)
-            torch.cuda.synchronize()
+            # a first exchange that never completes (a link that does not come up) must not look like a hung
+            # benchmark: give it a minute, then stop this rank with a message (the launcher stops the others)
+            done = torch.cuda.Event()
+            done.record()
+            t_wait = time.perf_counter()
+            while not done.query():
+                if time.perf_counter() - t_wait > 60.0:
+                    sys.stderr.write("bench.py rank %d: the first RCCL tile exchange did not complete within 60 s\n" % rank)
+                    sys.stderr.flush()
+                    os._exit(3)
+                time.sleep(0.01)
             ok = True
             if rank == 0:
                 got = bgather.frames[0, :, 0, 0].cpu().numpy()
