@@ -30,8 +30,12 @@ def test_grid_dda_matches_oracle(name):
     got, n_got, grid_ok = orc.harness_render(s, kernel=2)
     assert grid_ok
     scenes.assert_parity(got, want, name)
-    # the DDA may step over brick slivers: at most one sample per such crossing
-    assert abs(n_got - n_want) <= 2e-4 * n_want + 8
+    # the walk hands the cells around tied edges / corners to the reference's slab test: the same samples, one
+    # for one (the high-opacity noise scene: a ray may cross the early-exit threshold a sample sooner or later)
+    if name == "hash64_ert":
+        assert abs(n_got - n_want) <= 1e-4 * n_want
+    else:
+        assert n_got == n_want
 
 
 def test_reference_order_is_bit_exact_on_constant_bricks():
@@ -321,7 +325,10 @@ def test_random_views_all_kernel_forms_match_the_oracle(seed):
     for kernel in (1, 2, 4):
         got, n_got, grid_ok = orc.harness_render(s, kernel=kernel)
         _fuzz_parity(got, want, "seed %d k%d %r" % (seed, kernel, kw))
-        assert abs(n_got - n_want) <= 3e-4 * n_want + 16, (seed, kernel, kw)
+        # the same samples, one for one; with an opaque transfer function a ray may cross the early-exit
+        # threshold a sample sooner or later where a tie (tests/scenes.py) falls the other way
+        assert n_got == n_want or (kw.get("alpha", 0.05) >= 0.3 and abs(n_got - n_want) <= 1e-4 * n_want + 8), \
+            (seed, kernel, kw, n_got, n_want)
     want_lin, _ = orc.oracle_render(s, threads=4, filter_mode=1)
     got, _, _ = orc.harness_render(s, kernel=6)
     _fuzz_parity(got, want_lin, "seed %d trilinear %r" % (seed, kw))

@@ -70,7 +70,9 @@ def test_scene_parity_both_kernels(vrc, golden, name):
         dda, n_dda, st = g.render(kernel=vrc.KERNEL_GRID_DDA)
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
         scenes.assert_parity(dda, want, name + " dda vs oracle")
-        assert abs(n_dda - n_want) <= 2e-4 * n_want + 8
+        # the grid walk composites the reference's samples, one for one (opaque noise scene: a ray may cross
+        # the early-exit threshold a sample sooner or later where a tie falls the other way)
+        assert n_dda == n_want or (name == "hash64_ert" and abs(n_dda - n_want) <= 1e-4 * n_want)
         auto, _, st = g.render(kernel=vrc.KERNEL_AUTO, count=False)
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
         used = C.c_int64(-1)  # the same answer without the synchronisation of vrc_get_stats
@@ -380,11 +382,11 @@ def test_noise_in_136_cubed_slots_every_kernel_form(vrc, spin):
         ref, n_ref, st = g.render(kernel=vrc.KERNEL_REFERENCE_ORDER)
         assert st.kernel_variant == vrc.KERNEL_REFERENCE_ORDER
         scenes.assert_parity(ref, want, "136^3 noise, reference order")
-        assert abs(n_ref - n_want) <= 1e-4 * n_want + 8
+        assert n_ref == n_want
         dda, n_dda, st = g.render(kernel=vrc.KERNEL_GRID_DDA)
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
         scenes.assert_parity(dda, want, "136^3 noise, grid DDA, fixed-point stepping")
-        assert abs(n_dda - n_want) <= 2e-4 * n_want + 8
+        assert n_dda == n_want
         flt, n_flt, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, stepping=0)
         scenes.assert_parity(flt, want, "136^3 noise, grid DDA, float stepping")
         assert n_flt == n_dda
@@ -435,7 +437,7 @@ def test_c2_noise_volume_rows_at_1024_and_2048(vrc, c2_noise_scene):
     scenes.assert_parity(got[::64], want[::64], "C2 noise rows")
     scenes.assert_parity(ref[::64], want[::64], "C2 noise rows, reference order")
     scenes.assert_parity(flt[::64], want[::64], "C2 noise rows, float stepping")
-    assert abs(n_want * 64 - n_got) <= 0.03 * n_got and n_flt == n_got and abs(n_ref - n_got) <= 2e-4 * n_got
+    assert abs(n_want * 64 - n_got) <= 0.03 * n_got and n_flt == n_got and n_ref == n_got
     scenes.assert_parity(got2[::128], want2[::128], "C4 frame (2048^2) noise rows")
     assert abs(n_want2 * 128 - n_got2) <= 0.03 * n_got2
 
@@ -456,7 +458,8 @@ def test_random_views_all_gpu_kernels_match_the_oracle(vrc, seed):
         for k in (vrc.KERNEL_REFERENCE_ORDER, vrc.KERNEL_GRID_DDA, vrc.KERNEL_LDS):
             got, n_got, _ = g.render(kernel=k)
             _fuzz_parity(got, want, "seed %d k%d %r" % (seed, k, kw))
-            assert abs(n_got - n_want) <= 3e-4 * n_want + 16, (seed, k, kw)
+            assert n_got == n_want or (kw.get("alpha", 0.05) >= 0.3 and abs(n_got - n_want) <= 1e-4 * n_want + 8), \
+                (seed, k, kw, n_got, n_want)
             got, _, _ = g.render(kernel=k, filter_mode=vrc.FILTER_TRILINEAR)
             _fuzz_parity(got, want_lin, "seed %d k%d trilinear %r" % (seed, k, kw))
             got, _, _ = g.render(kernel=k, variant=vrc.VARIANT_GLRAYCASTER)
