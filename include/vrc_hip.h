@@ -105,6 +105,14 @@ typedef struct
                                    * kernel times; 0: no events (two host calls less per vrc_render; vrc_get_stats
                                    * then reports 0 ms and 0 launches) */
 
+#define VRC_OPT_DEPTH_SPLIT 10     /* 0 (default) | 1: two waves per 8x8 tile, one for the bricks in the near and one for
+                                   * those in the far half of every ray, composited with `over`: halves the
+                                   * latency of launches too small to fill the GPU (a rank's share of a sort-first
+                                   * frame) at ~15 % more work.  Same samples (every brick is marched whole by one of
+                                   * the two); taken only where exact: frames in which early ray termination cannot
+                                   * occur (largest classified opacity ^ most samples per ray), first pass of a
+                                   * frame, the point-sampling grid-walk kernel; silently the plain kernel else */
+
 #define VRC_VARIANT_CUDARAYCASTER 0 /* renderers/cudaRaycaster/cuda/Renderer.cu:95-230 */
 #define VRC_VARIANT_GLRAYCASTER 1   /* renderers/glRaycaster/shaders/fragRaycast.glsl:113-215: pixel centre
                                      * +0.5, hit test t0 <= t1, first sample of a brick snapped to the

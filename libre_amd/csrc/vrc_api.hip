@@ -100,6 +100,7 @@ struct vrc_ctx
     bool lutValid = false;
     uint64_t lutTfVersion = 0;
     vrc_lut_params lutParams = { 0, 0, 0, 0 };
+    float lutMaxAlpha = 1.0f; /* largest opacity in the classified table (1: unknown) */
     bool lutLinear = false;
     uint32_t lutLevels = 1;
 
@@ -166,6 +167,7 @@ struct vrc_ctx
     int64_t optTfFracBits = 8;
     int64_t optCount = 0;
     int64_t optTiming = 1;
+    int64_t optDepthSplit = 0;
 
     vrc_stats stats = {};
 };
@@ -293,6 +295,7 @@ int vrc_set_option( vrc_ctx* c, int option, int64_t value )
     case VRC_OPT_TILE_ORDER: c->optTileOrder = value ? 1 : 0; return VRC_OK;
     case VRC_OPT_STEPPING: c->optStepping = value ? 1 : 0; return VRC_OK;
     case VRC_OPT_KERNEL_TIMING: c->optTiming = value ? 1 : 0; return VRC_OK;
+    case VRC_OPT_DEPTH_SPLIT: c->optDepthSplit = value ? 1 : 0; return VRC_OK;
     case VRC_OPT_VARIANT:
         if( value != VRC_VARIANT_CUDARAYCASTER && value != VRC_VARIANT_GLRAYCASTER )
             return fail( VRC_EINVAL, "vrc_set_option: variant is 0 (cudaRaycaster) or 1 (glRaycaster)" );
@@ -315,6 +318,7 @@ int vrc_get_option( vrc_ctx* c, int option, int64_t* value )
     case VRC_OPT_TILE_ORDER: *value = c->optTileOrder; return VRC_OK;
     case VRC_OPT_STEPPING: *value = c->optStepping; return VRC_OK;
     case VRC_OPT_KERNEL_TIMING: *value = c->optTiming; return VRC_OK;
+    case VRC_OPT_DEPTH_SPLIT: *value = c->optDepthSplit; return VRC_OK;
     case VRC_OPT_VARIANT: *value = c->optVariant; return VRC_OK;
     case VRC_OPT_KERNEL_USED: *value = c->stats.kernel_variant; return VRC_OK;
     default: return fail( VRC_EINVAL, "vrc_get_option: unknown option" );
@@ -951,6 +955,16 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         c->lutLevels = lutLevels;
         c->lutTfVersion = c->tfVersion;
         c->lutValid = true;
+        /* the largest classified opacity of a sample (same function as the device table, evaluated on the
+         * pinned copy of the transfer function): decides whether early ray termination can occur at all */
+        c->lutMaxAlpha = 1.0f;
+        if( !classify )
+        {
+            float m = 0.0f;
+            for( uint32_t d = 0; d < 256u; ++d )
+                m = std::max( m, vrc_lut_entry( c->hTf, d, lp ).w );
+            c->lutMaxAlpha = m;
+        }
     }
 
     /* node table + grid, re-derived and re-uploaded only when the node list changed
@@ -1133,6 +1147,19 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     a.linear = linear;
     a.elemBytes = pool->elemBytes;
     a.bigAtlas = pool->bigAtlas;
+    /* depth split: only where it is exact.  (i) The far half cannot know the near half's opacity, so early ray
+     * termination must be impossible: (1 - largest classified alpha)^(most samples a ray can take) stays above
+     * 1 - 0.999 (a ray crosses at most sqrt(3) world units -- the volume's longest edge is 1 -- plus one
+     * restart sample per brick).  (ii) The frame starts from zero (first pass: the clear is folded in).
+     * (iii) the table-driven point-sampling walk kernel. */
+    a.depthSplit = false;
+    if( c->optDepthSplit && useDda && !useLds && !c->rayLod && !linear && pool->elemBytes == 1 && !pool->bigAtlas &&
+        !c->cachedClamp && c->optStepping != 0 && f.clearFirst )
+    {
+        const double nMax = 1.7320508 * (double)render->samplesPerRay +
+                            3.0 * ( f.gridDim[0] + f.gridDim[1] + f.gridDim[2] ) + 8.0;
+        a.depthSplit = c->lutMaxAlpha < 1.0f && nMax * std::log1p( -(double)c->lutMaxAlpha ) > std::log( 1.0 - 0.999 );
+    }
     a.classifier = vrc_make_classifier( lp );
 
     /* order the march after every brick upload issued so far (fixes quirk Q9) */

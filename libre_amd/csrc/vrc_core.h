@@ -405,6 +405,7 @@ struct vrc_segment
     vrc_f3 pos;   /* rayStart */
     vrc_f3 step;  /* normalize(stop-start)*stepSize */
     float dist;
+    float tNear;  /* ray parameter of rayStart */
 };
 
 VRC_HD bool vrc_brick_segment( const vrc_frame& f, const vrc_ray& r, const vrc_dev_node& n,
@@ -477,6 +478,7 @@ VRC_HD bool vrc_brick_segment( const vrc_frame& f, const vrc_ray& r, const vrc_d
     s->step.y = diff.y * invLen * stepSize;
     s->step.z = diff.z * invLen * stepSize;
     s->dist = sqrtf( d2 );
+    s->tNear = tNear;
     return true;
 }
 
@@ -1090,27 +1092,16 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
  * For a regular single-LOD grid the along-ray order equals the reference's host order for
  * every pair of bricks that share a ray ("brick order").
  * ---------------------------------------------------------------------------------------- */
+/* The walk of one prepared ray; color is read-modify-write.  half: -1 = every brick the ray meets; 0 / 1 = only
+ * the bricks whose segment starts in the near / far half of the ray's interval inside the grid (depth split:
+ * two waves march the two halves of a tile's rays and the halves are composited with the `over` operator --
+ * every brick is marched whole by exactly one of them, so the sample sets are the reference's). */
 template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP, bool BIG = false >
-VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
-                                const int32_t* __restrict__ gridTable,
-                                const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
-                                const vrc_classifier& cls,
-                                vrc_f4* __restrict__ pixelBuffer, uint32_t px, uint32_t py,
-                                uint32_t& nSamples )
+VRC_HD void vrc_ray_grid_dda( const vrc_frame& f, const vrc_ray& r, const vrc_dev_node* __restrict__ nodes,
+                              const int32_t* __restrict__ gridTable, const ATLAS_T* __restrict__ atlas,
+                              const vrc_f4* lut, const vrc_classifier& cls, vrc_f4& color, uint32_t& nSamples,
+                              int half = -1 )
 {
-    const vrc_ray r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
-    const uint32_t pixelPos = py * f.width + px;
-    const vrc_f4 zero = { 0.f, 0.f, 0.f, 0.f };
-    if( !r.hit )
-    {
-        if( f.clearFirst )
-            pixelBuffer[pixelPos] = zero;
-        return;
-    }
-    vrc_f4 color = f.clearFirst ? zero : pixelBuffer[pixelPos];
-    if( color.w > VRC_EARLY_EXIT )
-        return;
-
     /* ray interval inside the brick grid */
     const vrc_f3 gmin = { f.gridMin[0], f.gridMin[1], f.gridMin[2] };
     const vrc_f3 gmax = { f.gridMin[0] + f.cellSize[0] * (float)f.gridDim[0],
@@ -1174,6 +1165,7 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
         int32_t recent[4] = { -1, -1, -1, -1 };
         const int maxSteps = f.gridDim[0] + f.gridDim[1] + f.gridDim[2] + 3;
         bool finished = false;
+        const float tSplit = 0.5f * ( t0 + t1 );
         auto visit = [&]( int cx, int cy, int cz ) {
             const int32_t node = gridTable[( cz * f.gridDim[1] + cy ) * f.gridDim[0] + cx];
             if( node < 0 || node == recent[0] || node == recent[1] || node == recent[2] || node == recent[3] )
@@ -1187,6 +1179,8 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
             bool stop;
             if( vrc_brick_segment( f, r, n, f.stepSize, &s, &stop ) )
             {
+                if( half >= 0 && ( s.tNear < tSplit ? 0 : 1 ) != half )
+                    return; /* the other half's brick */
                 if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >( f, n, s, atlas, lut, cls, color,
                                                                              nSamples ) )
                     finished = true;
@@ -1266,6 +1260,30 @@ VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restri
             multi = ( tied & ( tied - 1u ) ) != 0u;
         }
     }
+}
+
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP, bool BIG = false >
+VRC_HD void vrc_pixel_grid_dda( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
+                                const int32_t* __restrict__ gridTable,
+                                const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
+                                const vrc_classifier& cls,
+                                vrc_f4* __restrict__ pixelBuffer, uint32_t px, uint32_t py,
+                                uint32_t& nSamples )
+{
+    const vrc_ray r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
+    const uint32_t pixelPos = py * f.width + px;
+    const vrc_f4 zero = { 0.f, 0.f, 0.f, 0.f };
+    if( !r.hit )
+    {
+        if( f.clearFirst )
+            pixelBuffer[pixelPos] = zero;
+        return;
+    }
+    vrc_f4 color = f.clearFirst ? zero : pixelBuffer[pixelPos];
+    if( color.w > VRC_EARLY_EXIT )
+        return;
+    vrc_ray_grid_dda< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >( f, r, nodes, gridTable, atlas, lut, cls, color,
+                                                                   nSamples );
     pixelBuffer[pixelPos] = color;
 }
 
@@ -1304,6 +1322,7 @@ VRC_HD vrc_segment vrc_run_segment( const vrc_ray& r, float tA, float tB, float 
     const float d2 = vrc_dot( diff, diff );
     vrc_segment s;
     s.pos = rayStart;
+    s.tNear = tA;
     if( d2 > 0.0f )
     {
         const float invLen = 1.0f / sqrtf( d2 );

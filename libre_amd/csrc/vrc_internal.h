@@ -81,6 +81,8 @@ struct vrc_raycast_args
                          * transfer function whenever samples are classified one by one */
     vrc_classifier classifier;
     bool bigAtlas; /* more than 2^32 voxels: node slot bases are 64-bit (BIG kernel instances) */
+    bool depthSplit; /* two waves per tile, near / far half of every ray (vrc_k_raycast_split): set by the host
+                      * only when early ray termination cannot occur in this frame and the frame is cleared */
 };
 
 /* heaviest-first tile schedule for the frame (order: vrc_schedule_slots() uint32; scratch:

@@ -513,6 +513,104 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
     return hipGetLastError();
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Depth split (VRC_OPT_DEPTH_SPLIT): the same integrator with TWO waves per tile -- wave h of a tile marches the
+ * bricks whose segments start in half h of each ray's interval inside the brick grid -- composited with the
+ * `over` operator through LDS.  For launches that cannot fill the machine (a rank's share of a sort-first frame):
+ * the time of such a launch is the longest ray's dependent chain of samples, and this halves it.  Every brick
+ * is marched whole by exactly one of the two waves, so the samples are the reference's; compositing the far half
+ * from zero and blending it in afterwards regroups the float additions (differences ~1e-7, inside E0).  Early ray
+ * termination would need the near half's opacity inside the far half: the launcher takes this kernel only for frames
+ * whose classified table cannot reach the threshold (vrc_api.hip), and only for the first pass of a frame.
+ * Workgroup = 8 waves: waves 0-3 the near halves of the unit's four tiles, waves 4-7 the far halves.
+ * ---------------------------------------------------------------------------------------- */
+template < bool COUNT, int GROUP >
+__global__ __launch_bounds__( 512, GROUP > 8 ? 2 : 4 ) void vrc_k_raycast_split(
+    const vrc_frame f, const vrc_dev_node* __restrict__ nodes, const int32_t* __restrict__ gridTable,
+    const uint8_t* __restrict__ atlas, const vrc_f4* __restrict__ lutGlobal, const vrc_classifier cls,
+    vrc_f4* __restrict__ pixelBuffer, unsigned long long* __restrict__ sampleCounter,
+    const uint32_t* __restrict__ tileOrder, const uint32_t tilesX, const uint32_t nTiles )
+{
+    __shared__ vrc_f4 lut[VRC_TFP_ENTRIES];
+    __shared__ vrc_f4 farColor[4][64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, sub = wave & 3u;
+    const int half = (int)( wave >> 2 );
+    if( tid < 256u )
+        lut[tid] = lutGlobal[tid];
+    if( tid < VRC_TFP_ENTRIES - 256u )
+        lut[256u + tid] = lutGlobal[256u + tid];
+#if defined( VRC_ADDR_TABLES )
+    if( tid < 256u )
+    {
+        const vrc_lay lay = vrc_make_lay( f.sbx, f.sby );
+        vrc_addr_tab[tid] = vrc_lay_x( lay, tid );
+        vrc_addr_tab[256u + tid] = vrc_lay_y( lay, tid );
+        vrc_addr_tab[512u + tid] = vrc_lay_z( lay, tid );
+    }
+#endif
+    __syncthreads();
+    const uint32_t tilesY = nTiles / tilesX;
+    const uint32_t slotIndex = blockIdx.x * 4u + sub;
+    const uint32_t tile = slotIndex < vrc_schedule_slots( tilesX, tilesY )
+                              ? vrc_slot_tile( tileOrder, slotIndex, tilesX, tilesY )
+                              : VRC_NO_TILE;
+    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
+    const uint32_t lx = ( lane & 1u ) | ( ( lane >> 1 ) & 2u ) | ( ( lane >> 2 ) & 4u );
+    const uint32_t ly = ( ( lane >> 1 ) & 1u ) | ( ( lane >> 2 ) & 2u ) | ( ( lane >> 3 ) & 4u );
+    const uint32_t px = tx * 8u + lx, py = ty * 8u + ly;
+    const bool inFrame = tile != VRC_NO_TILE && px < f.width && py < f.height;
+
+    uint32_t nSamples = 0;
+    vrc_f4 color = { 0.f, 0.f, 0.f, 0.f };
+    bool hit = false;
+    if( inFrame )
+    {
+        const vrc_ray r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
+        hit = r.hit;
+        if( hit )
+            vrc_ray_grid_dda< false, COUNT, true, VRC_MODE_TABLE, uint8_t, GROUP, false >(
+                f, r, nodes, gridTable, atlas, lut, cls, color, nSamples, half );
+    }
+    if( half == 1 )
+        farColor[sub][lane] = color;
+    __syncthreads(); /* every wave of the workgroup gets here: nothing above returns */
+    if( half == 0 && inFrame )
+    {
+        if( hit )
+        {
+            /* front-to-back `over`: near + (1 - near.alpha) * far; both hold opacity-weighted colour */
+            const vrc_f4 farC = farColor[sub][lane];
+            const float t = 1.0f - color.w;
+            color.x += farC.x * t;
+            color.y += farC.y * t;
+            color.z += farC.z * t;
+            color.w += farC.w * t;
+        }
+        pixelBuffer[py * f.width + px] = color; /* the folded clear: a missed pixel is written as 0 */
+    }
+    if( COUNT )
+    {
+        unsigned long long s = nSamples;
+#pragma unroll
+        for( int off = 32; off > 0; off >>= 1 )
+            s += __shfl_down( s, off, 64 );
+        if( lane == 0 && s != 0 )
+            atomicAdd( sampleCounter, s );
+    }
+}
+
+template < bool COUNT, int GROUP >
+static hipError_t launch_split( const vrc_raycast_args& a, hipStream_t stream )
+{
+    const uint32_t tilesX = ( a.frame.width + 7u ) / 8u, tilesY = ( a.frame.height + 7u ) / 8u;
+    if( tilesX * tilesY == 0 )
+        return hipSuccess;
+    hipLaunchKernelGGL( ( vrc_k_raycast_split< COUNT, GROUP > ), dim3( vrc_schedule_slots( tilesX, tilesY ) / 4u ),
+                        dim3( 512 ), 0, stream, a.frame, a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut,
+                        a.classifier, a.pixelBuffer, a.sampleCounter, a.tileOrder, tilesX, tilesX * tilesY );
+    return hipGetLastError();
+}
+
 /* per-sample classification modes (float stepping): trilinear or point, u8 or u16 voxels */
 template < int MODE, typename ATLAS_T >
 static hipError_t launch_classify( const vrc_raycast_args& a, bool count, hipStream_t stream )
@@ -580,6 +678,8 @@ hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
 #define VRC_SMALL_LAUNCH_TILES 6144u
 #endif
     const bool smallLaunch = nTilesLaunch <= VRC_SMALL_LAUNCH_TILES;
+    if( a.depthSplit && ( key == 12 || key == 13 ) && VRC_TILE_W == 8u )
+        return count ? launch_split< true, 8 >( a, stream ) : launch_split< false, 8 >( a, stream );
     switch( key )
     {
     case 0: return launch_variant< false, false, false, false, VRC_MODE_TABLE, uint8_t >( a, stream );

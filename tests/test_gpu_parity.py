@@ -939,3 +939,39 @@ def test_kernel_timing_can_be_switched_off(vrc):
         vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_KERNEL_TIMING, 1))
         _, _, st3 = g.render()
         assert st3.kernel_launches == 1 and st3.kernel_ms > 0.0
+
+
+def test_depth_split_composites_the_same_samples(vrc):
+    # VRC_OPT_DEPTH_SPLIT: two waves per tile (near / far half of every ray) composited with `over`: the sample set
+    # is the plain kernel's (counts equal), the frame equal up to the regrouped float additions, the oracle rule
+    # holds; with an opaque transfer function (early termination possible) and on later passes of a multipass
+    # frame the option falls back to the plain kernel, bit for bit
+    for name in ("hash64_spin", "mem64_axis", "hash_clip", "mem_inside"):
+        s = scenes.get(name)
+        want, n_want = orc.oracle_render(s, threads=8)
+        with _gpu(s) as g:
+            plain, n_plain, _ = g.render()
+            vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_DEPTH_SPLIT, 1))
+            split, n_split, st = g.render()
+            assert st.kernel_variant == vrc.KERNEL_GRID_DDA and n_split == n_plain == n_want
+            assert np.abs(split - plain).max() <= 2e-6 and not (split == plain).all()  # really another kernel
+            scenes.assert_parity(split, want, name + " depth split")
+            # multipass: the first pass may be split (the frame starts from zero), later ones accumulate in
+            h = s.n_nodes // 2
+            two, n_two, _ = g.render(passes=[(0, h), (h, s.n_nodes)])
+            scenes.assert_parity(two, want, name + " depth split, two passes")
+            assert n_two == n_want
+    s = scenes.get("hash64_ert")  # alpha 1.0: early termination happens, the split would not be exact
+    with _gpu(s) as g:
+        plain, n_plain, _ = g.render()
+        vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_DEPTH_SPLIT, 1))
+        again, n_again, _ = g.render()
+        assert (again == plain).all() and n_again == n_plain
+    # the judged shape: C2's 136^3 slots with noise, one whole frame
+    s = orc.build_scene(voxels=(256, 256, 256), block=128, viewport=(256, 256), volume="hash", spin=(0.5236, 0.349))
+    want, n_want = orc.oracle_render(s, threads=16)
+    with _gpu(s) as g:
+        vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_DEPTH_SPLIT, 1))
+        split, n_split, _ = g.render()
+        scenes.assert_parity(split, want, "136^3 noise, depth split")
+        assert n_split == n_want

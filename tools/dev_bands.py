@@ -11,12 +11,14 @@ ap.add_argument("--world", type=int, nargs="+", default=[1, 2, 4, 8])
 ap.add_argument("--bands", type=int, default=4)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--viewport", type=int, default=1024)
+ap.add_argument("--depth-split", type=int, default=0, help="VRC_OPT_DEPTH_SPLIT: two waves per tile (near / far half)")
 a = ap.parse_args()
 W = H = a.viewport
 i = np.arange(256, dtype=np.float32) / np.float32(255.0)
 tf = np.ascontiguousarray(np.stack([i, i, i, np.float32(0.05) * i], axis=1))
 app = driver.App("mem://#1024,1024,1024,128", W, H, synchronous=True, min_lod=3, max_lod=3, gpu_cache_mb=3072)
 app.set_colormap(tf)
+app.set_option(vrc.OPT_DEPTH_SPLIT, a.depth_split)
 app.render_frame(readback=False)
 for world in a.world:
     lay = sortfirst.band_layout(H, world, a.bands)
