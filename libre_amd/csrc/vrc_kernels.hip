@@ -679,7 +679,12 @@ hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
 #endif
     const bool smallLaunch = nTilesLaunch <= VRC_SMALL_LAUNCH_TILES;
     if( a.depthSplit && ( key == 12 || key == 13 ) && VRC_TILE_W == 8u )
-        return count ? launch_split< true, 8 >( a, stream ) : launch_split< false, 8 >( a, stream );
+    {
+#ifndef VRC_SPLIT_GROUP
+#define VRC_SPLIT_GROUP 8
+#endif
+        return count ? launch_split< true, VRC_SPLIT_GROUP >( a, stream ) : launch_split< false, VRC_SPLIT_GROUP >( a, stream );
+    }
     switch( key )
     {
     case 0: return launch_variant< false, false, false, false, VRC_MODE_TABLE, uint8_t >( a, stream );
