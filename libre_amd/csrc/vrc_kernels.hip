@@ -411,7 +411,12 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t*
  * latency sets the time -- the per-rank share of a sort-first frame from 4 ranks up. */
 template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP,
            bool BIG = false >
-__global__ __launch_bounds__( VRC_WG_THREADS, GROUP > 8 ? 2 : VRC_MIN_WAVES ) void vrc_k_raycast(
+/* waves per SIMD: 5 for the table-driven point-sampling instances (48 VGPRs); the per-sample classification modes,
+ * the float position chain, the clamped sampler and 64-bit slot bases need more registers than 5 waves leave (they
+ * spilled at 5: the trilinear gather form ran 5.3 instead of 2.9 ms) */
+__global__ __launch_bounds__( VRC_WG_THREADS, GROUP > 8 ? 2
+                                              : ( MODE == VRC_MODE_TABLE && FIXED && !CLAMP && !BIG ? VRC_MIN_WAVES
+                                                                                                    : 4 ) ) void vrc_k_raycast(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ gridTable, const ATLAS_T* __restrict__ atlas,
     const vrc_f4* __restrict__ lutGlobal, const vrc_classifier cls,

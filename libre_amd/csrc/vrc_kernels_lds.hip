@@ -141,7 +141,10 @@ struct lds_box
 
 template < bool COUNT, bool LINEAR, typename S >
 /* the deep region leaves LDS for three workgroups per CU (3 waves per SIMD), the flat one for four */
-__global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) void vrc_k_raycast_lds(
+#ifndef VRC_LDS_LINEAR_WAVES
+#define VRC_LDS_LINEAR_WAVES 4 /* measured: 4 waves with 11 spilled dwords (2.52 ms) beat 3 waves without (2.71 ms) */
+#endif
+__global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINEAR ? VRC_LDS_LINEAR_WAVES : 4 ) ) void vrc_k_raycast_lds(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ gridTable, const uint8_t* __restrict__ atlas,
     const vrc_f4* __restrict__ lutGlobal, const vrc_classifier cls,
@@ -260,9 +263,9 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
     int32_t recent0 = -1, recent1 = -1, recent2 = -1, recent3 = -1;
     /* work list of cells around an edge / corner (encoding: vrc_pixel_grid_dda), the faces the ray leaves
      * the current cell through, and whether the step through them is still to be taken */
-    uint32_t pending = (uint32_t)( ( 0x7F68544032201000ull >> ( back * 8u ) ) & 0x7Fu );
-    uint32_t tied = 0u;
-    bool needAdvance = false;
+    /* bits 0-13: the work list; bits 16-18: tied axes; bit 20: the step through them is still to be taken
+     * (one register: the trilinear form is short of them) */
+    uint32_t walk = (uint32_t)( ( 0x7F68544032201000ull >> ( back * 8u ) ) & 0x7Fu );
     uint32_t fx = 0, fy = 0, fz = 0, fdx = 0, fdy = 0, fdz = 0; /* 8.24 slot-local voxel */
     float travel = 0.0f;
     uint32_t laneSlotBase = 0;
@@ -308,10 +311,12 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
                      * through, then the step through every tied face and the cell behind it */
                     int cx = cell[0], cy = cell[1], cz = cell[2];
                     bool look = false, endAfter = false;
-                    if( pending != 0u )
+                    if( ( walk & 0x3FFFu ) != 0u )
                     {
-                        const uint32_t slot = (uint32_t)__builtin_ctz( pending );
-                        pending &= pending - 1u;
+                        const uint32_t slot = (uint32_t)__builtin_ctz( walk );
+                        walk &= walk - 1u;
+                        const uint32_t tied = ( walk >> 16 ) & 7u;
+                        (void)tied;
                         const uint32_t sub = slot < 7u ? ( 0x4216537u >> ( slot * 4u ) ) & 7u
                                                        : ( 0x653421u >> ( ( slot - 8u ) * 4u ) ) & 7u;
                         const int sgn = slot < 7u ? -1 : 1;
@@ -323,8 +328,9 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
                     }
                     else
                     {
-                        if( needAdvance )
+                        if( walk & ( 1u << 20 ) )
                         {
+                            const uint32_t tied = ( walk >> 16 ) & 7u;
                             if( tied & 1u )
                             {
                                 cell[0] += stepDir[0];
@@ -340,7 +346,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
                                 cell[2] += stepDir[2];
                                 tMax[2] += tDelta[2];
                             }
-                            needAdvance = false;
+                            walk = 0u;
                             ddaEnd = cell[0] < 0 || cell[0] >= f.gridDim[0] || cell[1] < 0 ||
                                      cell[1] >= f.gridDim[1] || cell[2] < 0 || cell[2] >= f.gridDim[2];
                         }
@@ -356,11 +362,11 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : 4 ) vo
                             else
                             {
                                 const float thr = tNext + fabsf( tNext ) * 2e-6f;
-                                tied = ( tMax[0] <= thr ? 1u : 0u ) | ( tMax[1] <= thr ? 2u : 0u ) |
-                                       ( tMax[2] <= thr ? 4u : 0u );
+                                const uint32_t tied = ( tMax[0] <= thr ? 1u : 0u ) | ( tMax[1] <= thr ? 2u : 0u ) |
+                                                      ( tMax[2] <= thr ? 4u : 0u );
+                                walk = ( tied << 16 ) | ( 1u << 20 );
                                 if( ( tied & ( tied - 1u ) ) != 0u )
-                                    pending = (uint32_t)( ( 0x3F06050003000000ull >> ( tied * 8u ) ) & 0x3Fu ) << 8;
-                                needAdvance = true;
+                                    walk |= (uint32_t)( ( 0x3F06050003000000ull >> ( tied * 8u ) ) & 0x3Fu ) << 8;
                             }
                         }
                     }
