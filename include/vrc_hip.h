@@ -113,6 +113,17 @@ typedef struct
                                    * occur (largest classified opacity ^ most samples per ray), first pass of a
                                    * frame, the point-sampling grid-walk kernel; silently the plain kernel else */
 
+#define VRC_OPT_ERT_COMPACTION 11  /* 0 (default) | 2..8 = P: ray compaction for early ray termination
+                                   * (cuda/Renderer.cu:219-226).  The march runs in P launches, one per slab of the
+                                   * brick grid along the view axis; after each, a wave-level ballot packs the rays
+                                   * that are still below the opacity threshold into a list, and the next launch marches
+                                   * 64 live rays per wave from it instead of tiles whose lanes have mostly finished.
+                                   * Same bricks, same order, same arithmetic per ray: the frame is bit-identical to
+                                   * the single launch.  Pays only for frames in which many, but not all, rays of a
+                                   * tile end early (DESIGN.md section 4 has the measurements); the point-sampling
+                                   * grid-walk kernel only, silently the plain kernel else.  With per-launch lists:
+                                   * vrc_get_ray_counts */
+
 #define VRC_VARIANT_CUDARAYCASTER 0 /* renderers/cudaRaycaster/cuda/Renderer.cu:95-230 */
 #define VRC_VARIANT_GLRAYCASTER 1   /* renderers/glRaycaster/shaders/fragRaycast.glsl:113-215: pixel centre
                                      * +0.5, hit test t0 <= t1, first sample of a brick snapped to the
@@ -230,6 +241,10 @@ int vrc_render( vrc_ctx* ctx, const vrc_view_data* view, const vrc_node_data* no
 int vrc_post_render( vrc_ctx* ctx, float* host_rgba );
 int vrc_synchronize( vrc_ctx* ctx );
 int vrc_get_stats( vrc_ctx* ctx, vrc_stats* out );
+/* Ray compaction (VRC_OPT_ERT_COMPACTION = P) of the last vrc_render: counts[p] = rays still alive after launch p
+ * (p = 0..P-2: the length of the list launch p + 1 marched), 0 for the rest of the 8 entries; *parts = P, or 0 when
+ * that render did not use compaction.  Waits for the render. */
+int vrc_get_ray_counts( vrc_ctx* ctx, uint32_t counts[8], int* parts );
 
 /* ---- sort-first tile exchange (multi-GPU) ------------------------------------------------------- */
 /* One process per GPU renders row bands of the frame (vrc_set_row_map); the display rank receives

@@ -168,6 +168,10 @@ struct vrc_ctx
     int64_t optCount = 0;
     int64_t optTiming = 1;
     int64_t optDepthSplit = 0;
+    int64_t optErtParts = 0;     /* VRC_OPT_ERT_COMPACTION */
+    uint32_t* dRayList = nullptr; /* counts | two ray lists (vrc_internal.h) */
+    size_t dRayListCap = 0;       /* pixels */
+    int lastErtParts = 0;         /* of the last vrc_render */
 
     vrc_stats stats = {};
 };
@@ -248,6 +252,7 @@ void vrc_ctx_destroy( vrc_ctx* c )
     for( hipEvent_t e : c->stageEvent )
         if( e ) (void)hipEventDestroy( e );
     if( c->dTileOrder ) (void)hipFree( c->dTileOrder );
+    if( c->dRayList ) (void)hipFree( c->dRayList );
     if( c->dRowMap ) (void)hipFree( c->dRowMap );
     if( c->dCounter ) (void)hipFree( c->dCounter );
     if( c->hCounter ) (void)hipHostFree( c->hCounter );
@@ -296,6 +301,12 @@ int vrc_set_option( vrc_ctx* c, int option, int64_t value )
     case VRC_OPT_STEPPING: c->optStepping = value ? 1 : 0; return VRC_OK;
     case VRC_OPT_KERNEL_TIMING: c->optTiming = value ? 1 : 0; return VRC_OK;
     case VRC_OPT_DEPTH_SPLIT: c->optDepthSplit = value ? 1 : 0; return VRC_OK;
+    case VRC_OPT_ERT_COMPACTION:
+        if( value < 0 || value > VRC_MAX_ERT_PARTS )
+            return fail( VRC_EINVAL, "VRC_OPT_ERT_COMPACTION: 0 (off) or 2.." + std::to_string( VRC_MAX_ERT_PARTS ) +
+                                         " launches per frame" );
+        c->optErtParts = value < 2 ? 0 : value;
+        return VRC_OK;
     case VRC_OPT_VARIANT:
         if( value != VRC_VARIANT_CUDARAYCASTER && value != VRC_VARIANT_GLRAYCASTER )
             return fail( VRC_EINVAL, "vrc_set_option: variant is 0 (cudaRaycaster) or 1 (glRaycaster)" );
@@ -319,6 +330,7 @@ int vrc_get_option( vrc_ctx* c, int option, int64_t* value )
     case VRC_OPT_STEPPING: *value = c->optStepping; return VRC_OK;
     case VRC_OPT_KERNEL_TIMING: *value = c->optTiming; return VRC_OK;
     case VRC_OPT_DEPTH_SPLIT: *value = c->optDepthSplit; return VRC_OK;
+    case VRC_OPT_ERT_COMPACTION: *value = c->optErtParts; return VRC_OK;
     case VRC_OPT_VARIANT: *value = c->optVariant; return VRC_OK;
     case VRC_OPT_KERNEL_USED: *value = c->stats.kernel_variant; return VRC_OK;
     default: return fail( VRC_EINVAL, "vrc_get_option: unknown option" );
@@ -1160,6 +1172,26 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
                             3.0 * ( f.gridDim[0] + f.gridDim[1] + f.gridDim[2] ) + 8.0;
         a.depthSplit = c->lutMaxAlpha < 1.0f && nMax * std::log1p( -(double)c->lutMaxAlpha ) > std::log( 1.0 - 0.999 );
     }
+    /* ray compaction: the table-driven point-sampling walk kernel; packed 16-bit pixel coordinates */
+    a.ertParts = 0;
+    a.rayList = nullptr;
+    if( c->optErtParts > 1 && !a.depthSplit && useDda && !useLds && !c->rayLod && !linear && pool->elemBytes == 1 &&
+        !pool->bigAtlas && !c->cachedClamp && c->optStepping != 0 && c->fbW < 65536u && c->fbH < 65536u )
+    {
+        const size_t pixels = (size_t)c->fbW * c->fbH;
+        if( pixels > c->dRayListCap )
+        {
+            VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
+            if( c->dRayList ) VRC_HIP_CHECK( hipFree( c->dRayList ) );
+            c->dRayList = nullptr;
+            c->dRayListCap = 0;
+            VRC_HIP_CHECK( hipMalloc( &c->dRayList, ( VRC_MAX_ERT_PARTS + 2 * pixels ) * sizeof( uint32_t ) ) );
+            c->dRayListCap = pixels;
+        }
+        a.ertParts = (int)c->optErtParts;
+        a.rayList = c->dRayList;
+    }
+    c->lastErtParts = a.ertParts;
     a.classifier = vrc_make_classifier( lp );
 
     /* order the march after every brick upload issued so far (fixes quirk Q9) */
@@ -1263,6 +1295,23 @@ int vrc_synchronize( vrc_ctx* c )
             return rc;
     }
     VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
+    return VRC_OK;
+}
+
+int vrc_get_ray_counts( vrc_ctx* c, uint32_t counts[8], int* parts )
+{
+    if( !c || !counts || !parts )
+        return fail( VRC_EINVAL, "vrc_get_ray_counts: NULL argument" );
+    static_assert( VRC_MAX_ERT_PARTS == 8, "vrc_get_ray_counts reports 8 entries" );
+    VRC_HIP_CHECK( hipSetDevice( c->device ) );
+    for( int i = 0; i < 8; ++i )
+        counts[i] = 0;
+    *parts = c->lastErtParts;
+    if( c->lastErtParts > 1 )
+    {
+        VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
+        VRC_HIP_CHECK( hipMemcpy( counts, c->dRayList, VRC_MAX_ERT_PARTS * sizeof( uint32_t ), hipMemcpyDeviceToHost ) );
+    }
     return VRC_OK;
 }
 

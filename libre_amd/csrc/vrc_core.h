@@ -1092,15 +1092,32 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
  * For a regular single-LOD grid the along-ray order equals the reference's host order for
  * every pair of bricks that share a ray ("brick order").
  * ---------------------------------------------------------------------------------------- */
-/* The walk of one prepared ray; color is read-modify-write.  half: -1 = every brick the ray meets; 0 / 1 = only
- * the bricks whose segment starts in the near / far half of the ray's interval inside the grid (depth split:
- * two waves march the two halves of a tile's rays and the halves are composited with the `over` operator --
- * every brick is marched whole by exactly one of them, so the sample sets are the reference's). */
+/* the axis the view looks along most, and which way: the slabs of vrc_ray_grid_dda's parts */
+VRC_HD int vrc_part_dir( const vrc_frame& f )
+{
+    const vrc_ray c = vrc_setup_ray( f, f.width / 2u, (uint32_t)( f.vpH * 0.5f ) );
+    const float ax = c.dir.x < 0.f ? -c.dir.x : c.dir.x, ay = c.dir.y < 0.f ? -c.dir.y : c.dir.y,
+                az = c.dir.z < 0.f ? -c.dir.z : c.dir.z;
+    const int a = ax >= ay && ax >= az ? 0 : ( ay >= az ? 1 : 2 );
+    const float d = a == 0 ? c.dir.x : ( a == 1 ? c.dir.y : c.dir.z );
+    return a | ( d < 0.f ? 4 : 0 );
+}
+
+/* The walk of one prepared ray; color is read-modify-write.  part: -1 = every brick the ray meets; 0 .. parts-1 =
+ * only the bricks met in that one of `parts` equal slabs of the brick grid along axis partDir & 3, counted in the
+ * direction the view looks along it (partDir & 4: towards smaller coordinates; vrc_part_dir).  The slab is a
+ * property of the grid cell, the same for every ray: the lanes of a wave agree on which launch marches a brick.
+ * Every brick is marched whole in exactly one part, and a brick's part never falls below that of a brick met
+ * before it, so marching the parts one after the other composites the reference's samples in the reference's
+ * order.  Two users: the depth split (two waves march the two halves of a tile's rays at the same time and the
+ * halves are composited with `over`) and ray compaction (VRC_OPT_ERT_COMPACTION: one launch per part, the rays
+ * that early termination has not ended are packed into full waves for the next).
+ * Returns whether the ray is still alive (it meets the grid and its opacity is below the early-exit threshold). */
 template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP, bool BIG = false >
-VRC_HD void vrc_ray_grid_dda( const vrc_frame& f, const vrc_ray& r, const vrc_dev_node* __restrict__ nodes,
+VRC_HD bool vrc_ray_grid_dda( const vrc_frame& f, const vrc_ray& r, const vrc_dev_node* __restrict__ nodes,
                               const int32_t* __restrict__ gridTable, const ATLAS_T* __restrict__ atlas,
                               const vrc_f4* lut, const vrc_classifier& cls, vrc_f4& color, uint32_t& nSamples,
-                              int half = -1 )
+                              int part = -1, int parts = 2, int partDir = 2 )
 {
     /* ray interval inside the brick grid */
     const vrc_f3 gmin = { f.gridMin[0], f.gridMin[1], f.gridMin[2] };
@@ -1165,7 +1182,7 @@ VRC_HD void vrc_ray_grid_dda( const vrc_frame& f, const vrc_ray& r, const vrc_de
         int32_t recent[4] = { -1, -1, -1, -1 };
         const int maxSteps = f.gridDim[0] + f.gridDim[1] + f.gridDim[2] + 3;
         bool finished = false;
-        const float tSplit = 0.5f * ( t0 + t1 );
+        int lastPart = 0;
         auto visit = [&]( int cx, int cy, int cz ) {
             const int32_t node = gridTable[( cz * f.gridDim[1] + cy ) * f.gridDim[0] + cx];
             if( node < 0 || node == recent[0] || node == recent[1] || node == recent[2] || node == recent[3] )
@@ -1179,8 +1196,19 @@ VRC_HD void vrc_ray_grid_dda( const vrc_frame& f, const vrc_ray& r, const vrc_de
             bool stop;
             if( vrc_brick_segment( f, r, n, f.stepSize, &s, &stop ) )
             {
-                if( half >= 0 && ( s.tNear < tSplit ? 0 : 1 ) != half )
-                    return; /* the other half's brick */
+                if( part >= 0 )
+                {
+                    const int ax = partDir & 3;
+                    const int dim = f.gridDim[ax];
+                    const int c = ax == 0 ? cx : ( ax == 1 ? cy : cz );
+                    int sp = ( ( ( partDir & 4 ) ? dim - 1 - c : c ) * parts ) / dim;
+                    sp = sp > lastPart ? sp : lastPart;
+                    lastPart = sp;
+                    if( sp > part )
+                        finished = true; /* nothing of this part lies behind a brick of a later one */
+                    if( sp != part )
+                        return; /* another part's brick */
+                }
                 if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >( f, n, s, atlas, lut, cls, color,
                                                                              nSamples ) )
                     finished = true;
@@ -1259,7 +1287,9 @@ VRC_HD void vrc_ray_grid_dda( const vrc_frame& f, const vrc_ray& r, const vrc_de
             tied = ( tMax[0] <= thr ? 1u : 0u ) | ( tMax[1] <= thr ? 2u : 0u ) | ( tMax[2] <= thr ? 4u : 0u );
             multi = ( tied & ( tied - 1u ) ) != 0u;
         }
+        return !( color.w > VRC_EARLY_EXIT );
     }
+    return false;
 }
 
 template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP, bool BIG = false >

@@ -63,6 +63,8 @@ hipError_t vrc_launch_brick_histogram( const void* slot, uint32_t elemBytes, uin
                                        uint32_t binCount, unsigned long long scale,
                                        unsigned long long* bins, hipStream_t stream );
 
+#define VRC_MAX_ERT_PARTS 8
+
 struct vrc_raycast_args
 {
     vrc_frame frame;
@@ -81,6 +83,9 @@ struct vrc_raycast_args
                          * transfer function whenever samples are classified one by one */
     vrc_classifier classifier;
     bool bigAtlas; /* more than 2^32 voxels: node slot bases are 64-bit (BIG kernel instances) */
+    int ertParts;      /* > 1: ray compaction, the march in this many launches (vrc_k_raycast_part); the host sets it
+                        * only for the table-driven point-sampling walk kernel and frames below 65536 pixels a side */
+    uint32_t* rayList; /* counts[VRC_MAX_ERT_PARTS] | two lists of width * height packed pixels */
     bool depthSplit; /* two waves per tile, near / far half of every ray (vrc_k_raycast_split): set by the host
                       * only when early ray termination cannot occur in this frame and the frame is cleared */
 };

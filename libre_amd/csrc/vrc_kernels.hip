@@ -520,7 +520,7 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
 
 /* ------------------------------------------------------------------------------------------
  * Depth split (VRC_OPT_DEPTH_SPLIT): the same integrator with TWO waves per tile -- wave h of a tile marches the
- * bricks whose segments start in half h of each ray's interval inside the brick grid -- composited with the
+ * bricks of the near (h = 0) or far (h = 1) half of the brick grid along the view axis (vrc_ray_grid_dda) -- composited with the
  * `over` operator through LDS.  For launches that cannot fill the machine (a rank's share of a sort-first frame):
  * the time of such a launch is the longest ray's dependent chain of samples, and this halves it.  Every brick
  * is marched whole by exactly one of the two waves, so the samples are the reference's; compositing the far half
@@ -534,7 +534,7 @@ __global__ __launch_bounds__( 512, GROUP > 8 ? 2 : 4 ) void vrc_k_raycast_split(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes, const int32_t* __restrict__ gridTable,
     const uint8_t* __restrict__ atlas, const vrc_f4* __restrict__ lutGlobal, const vrc_classifier cls,
     vrc_f4* __restrict__ pixelBuffer, unsigned long long* __restrict__ sampleCounter,
-    const uint32_t* __restrict__ tileOrder, const uint32_t tilesX, const uint32_t nTiles )
+    const uint32_t* __restrict__ tileOrder, const uint32_t tilesX, const uint32_t nTiles, const int partDir )
 {
     __shared__ vrc_f4 lut[VRC_TFP_ENTRIES];
     __shared__ vrc_f4 farColor[4][64];
@@ -574,7 +574,7 @@ __global__ __launch_bounds__( 512, GROUP > 8 ? 2 : 4 ) void vrc_k_raycast_split(
         hit = r.hit;
         if( hit )
             vrc_ray_grid_dda< false, COUNT, true, VRC_MODE_TABLE, uint8_t, GROUP, false >(
-                f, r, nodes, gridTable, atlas, lut, cls, color, nSamples, half );
+                f, r, nodes, gridTable, atlas, lut, cls, color, nSamples, half, 2, partDir );
     }
     if( half == 1 )
         farColor[sub][lane] = color;
@@ -612,7 +612,175 @@ static hipError_t launch_split( const vrc_raycast_args& a, hipStream_t stream )
         return hipSuccess;
     hipLaunchKernelGGL( ( vrc_k_raycast_split< COUNT, GROUP > ), dim3( vrc_schedule_slots( tilesX, tilesY ) / 4u ),
                         dim3( 512 ), 0, stream, a.frame, a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut,
-                        a.classifier, a.pixelBuffer, a.sampleCounter, a.tileOrder, tilesX, tilesX * tilesY );
+                        a.classifier, a.pixelBuffer, a.sampleCounter, a.tileOrder, tilesX, tilesX * tilesY,
+                        vrc_part_dir( a.frame ) );
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Ray compaction (VRC_OPT_ERT_COMPACTION = P): the march in P launches, one per slab of the brick grid along the
+ * view axis (vrc_ray_grid_dda's `part`).  The first launch is the tile-scheduled kernel above; at its
+ * end every wave takes a ballot of the rays that early termination (Renderer.cu:219-226) has not ended, reserves
+ * popcount(ballot) entries of a ray list with one atomic and each live lane writes its pixel at the position
+ * mbcnt(ballot) gives it.  The following launches take their rays from that list, 64 consecutive entries per wave:
+ * full waves of live rays instead of tiles in which most lanes have finished.  A ray's bricks are marched in the same
+ * order with the same arithmetic as in one launch and its colour travels through the pixel buffer as float32, so the
+ * frame is bit-identical to the single launch; rays that end early never reach the later, sparser launches.
+ * What it costs: the dead lanes it removes cost the vector ALUs issue slots but almost no L1 tag look-ups (a quad
+ * without live lanes is skipped), while packed survivors from different tiles share fewer cache lines per quad
+ *  -- so it is an option, measured in DESIGN.md, and off by default.
+ * ---------------------------------------------------------------------------------------- */
+template < bool COUNT, bool LISTED >
+__global__ __launch_bounds__( VRC_WG_THREADS, 4 ) void vrc_k_raycast_part(
+    const vrc_frame f, const vrc_dev_node* __restrict__ nodes, const int32_t* __restrict__ gridTable,
+    const uint8_t* __restrict__ atlas, const vrc_f4* __restrict__ lutGlobal, const vrc_classifier cls,
+    vrc_f4* __restrict__ pixelBuffer, unsigned long long* __restrict__ sampleCounter,
+    const uint32_t* __restrict__ tileOrder, const uint32_t tilesX, const uint32_t nTiles, const int part,
+    const int parts, const int partDir, const uint32_t* __restrict__ listIn, const uint32_t* __restrict__ countIn,
+    uint32_t* __restrict__ listOut, uint32_t* __restrict__ countOut )
+{
+    __shared__ vrc_f4 lut[VRC_TFP_ENTRIES];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    uint32_t nRays = 0;
+    if( LISTED )
+    {
+        nRays = *countIn;
+        if( blockIdx.x * VRC_WG_THREADS >= nRays ) /* the whole workgroup: the grid is sized for every pixel */
+            return;
+    }
+#pragma unroll
+    for( uint32_t i = 0; i < ( 256u + VRC_WG_THREADS - 1u ) / VRC_WG_THREADS; ++i )
+        if( tid + i * VRC_WG_THREADS < 256u )
+            lut[tid + i * VRC_WG_THREADS] = lutGlobal[tid + i * VRC_WG_THREADS];
+    if( tid < VRC_TFP_ENTRIES - 256u )
+        lut[256u + tid] = lutGlobal[256u + tid];
+#if defined( VRC_ADDR_TABLES )
+    {
+        const vrc_lay lay = vrc_make_lay( f.sbx, f.sby );
+#pragma unroll
+        for( uint32_t i = 0; i < ( 256u + VRC_WG_THREADS - 1u ) / VRC_WG_THREADS; ++i )
+        {
+            const uint32_t u = tid + i * VRC_WG_THREADS;
+            if( u < 256u )
+            {
+                vrc_addr_tab[u] = vrc_lay_x( lay, u );
+                vrc_addr_tab[256u + u] = vrc_lay_y( lay, u );
+                vrc_addr_tab[512u + u] = vrc_lay_z( lay, u );
+            }
+        }
+    }
+#endif
+    __syncthreads();
+    /* from here on the waves of the workgroup are independent */
+    uint32_t px = 0, py = 0;
+    bool valid;
+    if( LISTED )
+    {
+        const uint32_t gid = blockIdx.x * VRC_WG_THREADS + tid;
+        valid = gid < nRays;
+        const uint32_t packed = valid ? listIn[gid] : 0u;
+        px = packed & 0xFFFFu;
+        py = packed >> 16;
+    }
+    else
+    {
+        const uint32_t slotIndex = blockIdx.x * VRC_WAVES_PER_WG + ( tid >> 6 );
+        const uint32_t tilesY = nTiles / tilesX;
+        if( slotIndex >= vrc_schedule_slots( tilesX, tilesY ) )
+            return;
+        const uint32_t tile = vrc_slot_tile( tileOrder, slotIndex, tilesX, tilesY );
+        if( tile == VRC_NO_TILE )
+            return;
+        const uint32_t lx = ( lane & 1u ) | ( ( lane >> 1 ) & 2u ) | ( ( lane >> 2 ) & 4u );
+        const uint32_t ly = ( ( lane >> 1 ) & 1u ) | ( ( lane >> 2 ) & 2u ) | ( ( lane >> 3 ) & 4u );
+        px = ( tile % tilesX ) * 8u + lx;
+        py = ( tile / tilesX ) * 8u + ly;
+        valid = px < f.width && py < f.height;
+    }
+
+    uint32_t nSamples = 0;
+    bool alive = false;
+    if( valid )
+    {
+        const vrc_ray r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
+        const uint32_t pixelPos = py * f.width + px;
+        const vrc_f4 zero = { 0.f, 0.f, 0.f, 0.f };
+        if( !r.hit )
+        {
+            if( !LISTED && f.clearFirst )
+                pixelBuffer[pixelPos] = zero;
+        }
+        else
+        {
+            /* the first launch starts like vrc_pixel_grid_dda; the later ones go on from what the one before
+             * left in the pixel buffer */
+            vrc_f4 color = ( LISTED || !f.clearFirst ) ? pixelBuffer[pixelPos] : zero;
+            if( !( color.w > VRC_EARLY_EXIT ) )
+            {
+                alive = vrc_ray_grid_dda< false, COUNT, true, VRC_MODE_TABLE, uint8_t, VRC_GROUP, false >(
+                    f, r, nodes, gridTable, atlas, lut, cls, color, nSamples, part, parts, partDir );
+                pixelBuffer[pixelPos] = color;
+            }
+        }
+    }
+    if( listOut )
+    {
+        /* wave-level compaction: one atomic per wave, order inside the wave kept (Morton order of a tile) */
+        const uint64_t live = __builtin_amdgcn_ballot_w64( alive );
+        if( live != 0ull )
+        {
+            uint32_t base = 0;
+            const uint32_t first = (uint32_t)__builtin_ctzll( live );
+            if( lane == first )
+                base = atomicAdd( countOut, (uint32_t)__builtin_popcountll( live ) );
+            base = (uint32_t)__builtin_amdgcn_readlane( (int)base, (int)first );
+            if( alive )
+            {
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi( (uint32_t)( live >> 32 ),
+                                                                  __builtin_amdgcn_mbcnt_lo( (uint32_t)live, 0u ) );
+                listOut[base + below] = ( py << 16 ) | px;
+            }
+        }
+    }
+    if( COUNT )
+    {
+        unsigned long long s = nSamples;
+#pragma unroll
+        for( int off = 32; off > 0; off >>= 1 )
+            s += __shfl_down( s, off, 64 );
+        if( lane == 0 && s != 0 )
+            atomicAdd( sampleCounter, s );
+    }
+}
+
+template < bool COUNT >
+static hipError_t launch_parts( const vrc_raycast_args& a, hipStream_t stream )
+{
+    const uint32_t tilesX = ( a.frame.width + 7u ) / 8u, tilesY = ( a.frame.height + 7u ) / 8u;
+    if( tilesX * tilesY == 0 )
+        return hipSuccess;
+    const int parts = a.ertParts;
+    const int partDir = vrc_part_dir( a.frame );
+    /* rayList: counts[VRC_MAX_ERT_PARTS] | list 0 [width * height] | list 1 [width * height] */
+    uint32_t* const counts = a.rayList;
+    uint32_t* const lists[2] = { a.rayList + VRC_MAX_ERT_PARTS,
+                                 a.rayList + VRC_MAX_ERT_PARTS + (size_t)a.frame.width * a.frame.height };
+    hipError_t e = hipMemsetAsync( counts, 0, VRC_MAX_ERT_PARTS * sizeof( uint32_t ), stream );
+    if( e != hipSuccess )
+        return e;
+    hipLaunchKernelGGL( ( vrc_k_raycast_part< COUNT, false > ),
+                        dim3( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_WAVES_PER_WG - 1u ) / VRC_WAVES_PER_WG ),
+                        dim3( VRC_WG_THREADS ), 0, stream, a.frame, a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut,
+                        a.classifier, a.pixelBuffer, a.sampleCounter, a.tileOrder, tilesX, tilesX * tilesY, 0, parts, partDir,
+                        (const uint32_t*)nullptr, (const uint32_t*)nullptr, lists[0], counts );
+    const uint32_t allRays = ( a.frame.width * a.frame.height + VRC_WG_THREADS - 1u ) / VRC_WG_THREADS;
+    for( int p = 1; p < parts; ++p )
+        hipLaunchKernelGGL( ( vrc_k_raycast_part< COUNT, true > ), dim3( allRays ), dim3( VRC_WG_THREADS ), 0, stream,
+                            a.frame, a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut, a.classifier, a.pixelBuffer,
+                            a.sampleCounter, a.tileOrder, tilesX, tilesX * tilesY, p, parts, partDir,
+                            (const uint32_t*)lists[( p - 1 ) & 1], (const uint32_t*)( counts + ( p - 1 ) ),
+                            p + 1 < parts ? lists[p & 1] : (uint32_t*)nullptr, counts + p );
     return hipGetLastError();
 }
 
@@ -683,6 +851,8 @@ hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
 #define VRC_SMALL_LAUNCH_TILES 6144u
 #endif
     const bool smallLaunch = nTilesLaunch <= VRC_SMALL_LAUNCH_TILES;
+    if( a.ertParts > 1 && ( key == 12 || key == 13 ) && VRC_TILE_W == 8u )
+        return count ? launch_parts< true >( a, stream ) : launch_parts< false >( a, stream );
     if( a.depthSplit && ( key == 12 || key == 13 ) && VRC_TILE_W == 8u )
     {
 #ifndef VRC_SPLIT_GROUP

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvrc_hip.so")
 
 VRC_OK, VRC_EINVAL, VRC_EHIP, VRC_EFULL, VRC_ENOMEM, VRC_EUNSUPPORTED, VRC_EHIERARCHY, VRC_ECOMM = range(8)
-OPT_KERNEL, OPT_FILTER, OPT_TF_FRAC_BITS, OPT_COUNT_SAMPLES, OPT_TILE_ORDER, OPT_STEPPING, OPT_VARIANT, OPT_KERNEL_USED, OPT_KERNEL_TIMING, OPT_DEPTH_SPLIT = range(1, 11)
+OPT_KERNEL, OPT_FILTER, OPT_TF_FRAC_BITS, OPT_COUNT_SAMPLES, OPT_TILE_ORDER, OPT_STEPPING, OPT_VARIANT, OPT_KERNEL_USED, OPT_KERNEL_TIMING, OPT_DEPTH_SPLIT, OPT_ERT_COMPACTION = range(1, 12)
 VARIANT_CUDARAYCASTER, VARIANT_GLRAYCASTER = 0, 1
 FILTER_NEAREST, FILTER_TRILINEAR = 0, 1
 KERNEL_AUTO, KERNEL_REFERENCE_ORDER, KERNEL_GRID_DDA, KERNEL_LDS, KERNEL_RAY_LOD = 0, 1, 2, 3, 4
@@ -56,7 +56,7 @@ EXPORTS = [
     "vrc_pool_release_slot", "vrc_pool_info", "vrc_pool_synchronize", "vrc_pool_read_region",
     "vrc_pool_histogram",
     "vrc_update", "vrc_pre_render", "vrc_set_row_map", "vrc_set_framebuffer", "vrc_get_framebuffer", "vrc_render",
-    "vrc_post_render", "vrc_synchronize", "vrc_get_stats", "vrc_last_error", "vrc_abi_version",
+    "vrc_post_render", "vrc_synchronize", "vrc_get_stats", "vrc_get_ray_counts", "vrc_last_error", "vrc_abi_version",
     "vrc_comm_unique_id", "vrc_comm_create", "vrc_comm_destroy", "vrc_comm_info", "vrc_gather_tiles",
 ]
 COMM_ID_BYTES = 128
@@ -112,6 +112,7 @@ def load_library(path=None):
     L.vrc_post_render.argtypes = [vp, vp]
     L.vrc_synchronize.argtypes = [vp]
     L.vrc_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.vrc_get_ray_counts.argtypes = [vp, C.POINTER(C.c_uint32 * 8), C.POINTER(C.c_int)]
     L.vrc_comm_unique_id.argtypes = [C.c_char_p]
     L.vrc_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]
     L.vrc_comm_destroy.argtypes = [vp]

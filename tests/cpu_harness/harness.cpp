@@ -10,6 +10,8 @@
 
 #include "../../libre_amd/csrc/vrc_tables.h"
 
+static int g_parts = 0;
+
 static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3],
                         const uint32_t slotDim[3], float* pixelBuffer, uint32_t W,
                         uint32_t H, const float* planes, uint32_t nPlanes, const float* tf,
@@ -150,6 +152,29 @@ static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3]
             else if( dda )
             {
                 if( t.clamp ) vrc_pixel_grid_dda< true, true, false, VRC_MODE_TABLE, uint8_t >( ARGS_DDA( atlas.data() ) );
+                else if( fixed && g_parts > 1 )
+                {
+                    /* the march in g_parts slices of the ray (ray compaction, vrc_k_raycast_part): one walk per
+                     * slice, the colour carried from one to the next */
+                    const vrc_ray r = vrc_setup_ray( f, px, py );
+                    const uint32_t pos = py * f.width + px;
+                    if( !r.hit )
+                    {
+                        if( f.clearFirst )
+                            pb[pos] = vrc_f4{ 0.f, 0.f, 0.f, 0.f };
+                    }
+                    else
+                    {
+                        vrc_f4 color = f.clearFirst ? vrc_f4{ 0.f, 0.f, 0.f, 0.f } : pb[pos];
+                        bool alive = !( color.w > VRC_EARLY_EXIT );
+                        for( int p = 0; p < g_parts && alive; ++p )
+                        {
+                            alive = vrc_ray_grid_dda< false, true, true, VRC_MODE_TABLE, uint8_t >(
+                                f, r, t.nodes.data(), t.grid.data(), atlas.data(), table, cls, color, n, p, g_parts, vrc_part_dir( f ) );
+                            pb[pos] = color;
+                        }
+                    }
+                }
                 else if( fixed ) vrc_pixel_grid_dda< false, true, true, VRC_MODE_TABLE, uint8_t >( ARGS_DDA( atlas.data() ) );
                 else vrc_pixel_grid_dda< false, true, false, VRC_MODE_TABLE, uint8_t >( ARGS_DDA( atlas.data() ) );
             }
@@ -169,6 +194,9 @@ static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3]
         *samplesOut = total;
     return 0;
 }
+
+/* > 1: kernel 4 (grid walk, fixed-point stepping) marches every ray in this many slices (ray compaction) */
+extern "C" void harness_set_parts( int parts ) { g_parts = parts; }
 
 extern "C" int harness_render( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3],
                                const uint32_t slotDim[3], float* pixelBuffer, uint32_t W,

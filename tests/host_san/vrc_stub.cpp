@@ -113,6 +113,7 @@ int vrc_render( vrc_ctx*, const vrc_view_data*, const vrc_node_data*, uint32_t, 
 int vrc_post_render( vrc_ctx*, float* ) { return VRC_OK; }
 int vrc_synchronize( vrc_ctx* ) { return VRC_OK; }
 int vrc_get_stats( vrc_ctx*, vrc_stats* out ) { std::memset( out, 0, sizeof( *out ) ); return VRC_OK; }
+int vrc_get_ray_counts( vrc_ctx*, uint32_t counts[8], int* parts ) { std::memset( counts, 0, 32 ); *parts = 0; return VRC_OK; }
 }
 
 /* sort-first tile exchange: a world of one rank, nothing to move */

@@ -451,9 +451,13 @@ def oracle_render(s, frac_bits=8, threads=8, rows=None, fb=None, filter_mode=0, 
     return (fb, int(n), tb) if budget else (fb, int(n))
 
 
-def harness_render(s, kernel=2, frac_bits=8, fb=None, sanitize=False, pixel_off=(0, 0), variant=0):
-    """Run the host build of the HIP kernel's per-ray code (vrc_core.h)."""
+def harness_render(s, kernel=2, frac_bits=8, fb=None, sanitize=False, pixel_off=(0, 0), variant=0, parts=0):
+    """Run the host build of the HIP kernel's per-ray code (vrc_core.h).  parts > 1 (kernel 4 only): every ray is
+    marched in that many slices, as the launches of VRC_OPT_ERT_COMPACTION do."""
     H = harness(sanitize)
+    H.harness_set_parts.argtypes = [C.c_int]
+    H.harness_set_parts.restype = None
+    H.harness_set_parts(parts)
     if fb is None:
         fb = np.zeros((s.H, s.W, 4), dtype=np.float32)
     samples = C.c_uint64(0)

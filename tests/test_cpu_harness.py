@@ -201,6 +201,11 @@ def test_fixed_point_stepping_matches_oracle(name):
     # same sample count as the float chain: the stepping changes positions, never the count
     _, n_float, _ = orc.harness_render(s, kernel=2)
     assert n_got == n_float
+    # the march in slices of the ray (VRC_OPT_ERT_COMPACTION's launches): every brick in exactly one slice, in the
+    # order of the walk -- the same frame and count, bit for bit
+    for parts in (2, 5):
+        sliced, n_sliced, _ = orc.harness_render(s, kernel=4, parts=parts)
+        assert (sliced == got).all() and n_sliced == n_got, "%s in %d slices" % (name, parts)
 
 
 @pytest.mark.parametrize("name", sorted(scenes.SCENES))

@@ -975,3 +975,66 @@ def test_depth_split_composites_the_same_samples(vrc):
         split, n_split, _ = g.render()
         scenes.assert_parity(split, want, "136^3 noise, depth split")
         assert n_split == n_want
+
+
+def _ray_counts(g):
+    from libre_amd import vrc
+    counts = (C.c_uint32 * 8)()
+    parts = C.c_int()
+    vrc.check(g.L, g.L.vrc_get_ray_counts(g.ctx, C.byref(counts), C.byref(parts)))
+    return list(counts), parts.value
+
+
+def test_ray_compaction_is_bit_identical(vrc):
+    # VRC_OPT_ERT_COMPACTION = P: the march in P launches; after each a wave ballot packs the rays that early
+    # termination (Renderer.cu:219-226) has not ended into a list, the next launch marches 64 live rays per wave.
+    # Same bricks in the same order with the same arithmetic per ray: the frame and the sample count are the plain
+    # kernel's, bit for bit -- with early termination (alpha 1.0), without it, with clip planes, from inside the
+    # volume, on a multipass frame
+    for name in ("hash64_ert", "mem64_ert", "hash64_spin", "hash_clip", "mem_inside", "mem_ragged"):
+        s = scenes.get(name)
+        with _gpu(s) as g:
+            plain, n_plain, _ = g.render()
+            assert _ray_counts(g) == ([0] * 8, 0)
+            h = s.n_nodes // 2
+            plain2, n_plain2, _ = g.render(passes=[(0, h), (h, s.n_nodes)])
+            for parts in (2, 3, 8):
+                vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_ERT_COMPACTION, parts))
+                fb, n, st = g.render()
+                assert st.kernel_variant == vrc.KERNEL_GRID_DDA
+                assert (fb == plain).all() and n == n_plain, "%s, %d launches" % (name, parts)
+                counts, used = _ray_counts(g)
+                assert used == parts and counts[parts - 1:] == [0] * (9 - parts)
+                assert all(counts[p] >= counts[p + 1] for p in range(parts - 2)), counts  # rays only end
+                # a ray whose final opacity is below the threshold was alive after every launch
+                never_ended = int(((plain[..., 3] > 0) & (plain[..., 3] <= 0.999)).sum())
+                assert counts[parts - 2] >= never_ended and counts[0] <= s.W * s.H
+                if name.endswith("_ert"):  # opaque transfer function: rays did end before the last launch
+                    assert counts[parts - 2] < int((plain[..., 3] > 0).sum())
+                fb2, n2, _ = g.render(passes=[(0, h), (h, s.n_nodes)])
+                assert (fb2 == plain2).all() and n2 == n_plain2, "%s, %d launches, two passes" % (name, parts)
+            vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_ERT_COMPACTION, 0))
+            fb, n, _ = g.render()
+            assert (fb == plain).all() and _ray_counts(g)[1] == 0
+            assert g.L.vrc_set_option(g.ctx, vrc.OPT_ERT_COMPACTION, 9) != 0  # more launches than the list has counters
+    # other kernels ignore the option: reference order, trilinear filter
+    s = scenes.get("hash64_ert")
+    with _gpu(s) as g:
+        vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_ERT_COMPACTION, 4))
+        for kw in (dict(kernel=vrc.KERNEL_REFERENCE_ORDER), dict(filter_mode=1)):
+            g.render(**kw)
+            assert _ray_counts(g)[1] == 0
+    # the judged shape (136^3 slots, noise), an opaque transfer function: rays end inside the first bricks
+    s = orc.build_scene(voxels=(256, 256, 256), block=128, viewport=(256, 256), volume="hash", spin=(0.5236, 0.349),
+                        alpha=1.0)
+    want, n_want = orc.oracle_render(s, threads=16)
+    with _gpu(s) as g:
+        plain, n_plain, _ = g.render()
+        vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_ERT_COMPACTION, 4))
+        fb, n, _ = g.render()
+        counts, _ = _ray_counts(g)
+        # (against the oracle: a ray that crosses the threshold within float rounding of 0.999 ends a sample apart)
+        assert (fb == plain).all() and n == n_plain and abs(n - n_want) <= 1e-5 * n_want + 8
+        scenes.assert_parity(fb, want, "136^3 noise, 4 launches")
+        ended, hits = int((plain[..., 3] > 0.999).sum()), int((plain[..., 3] > 0).sum())
+        assert ended > 0 and counts[0] >= counts[2] and counts[2] <= hits - ended // 2, (counts, ended, hits)

@@ -39,13 +39,16 @@ def main():
                     help="screen-space error: time the per-ray LOD kernel on the same node list (add --levels)")
     ap.add_argument("--levels", type=int, nargs="*", default=None,
                     help="tree levels in the node list (default: the leaves; e.g. 0 1 2 3 = whole pyramid)")
+    ap.add_argument("--spr", type=int, default=0, help="samples per ray (0 = the automatic value)")
+    ap.add_argument("--ert-parts", type=int, nargs="*", default=[0],
+                    help="VRC_OPT_ERT_COMPACTION values to time (0 = one launch)")
     a = ap.parse_args()
     t0 = time.time()
     ids = None
     if a.levels is not None:
         ids = orc.all_level_ids(orc.mem_volume_info(a.voxels, a.voxels, a.voxels, a.block), a.levels)
     s = orc.build_scene(voxels=(a.voxels,) * 3, block=a.block, viewport=(a.viewport,) * 2,
-                        volume=a.volume, spin=tuple(a.spin), alpha=a.alpha, ids=ids, dtype=a.dtype,
+                        volume=a.volume, spin=tuple(a.spin), alpha=a.alpha, ids=ids, dtype=a.dtype, spr=a.spr,
                         tile=None if a.tile_offset < 0 else (a.tile_offset, a.tile_offset, a.viewport - 8,
                                                              a.viewport - 8, a.viewport, a.viewport))
     print("scene built in %.1fs: %d nodes spr %d atlas %s" % (time.time() - t0, s.n_nodes,
@@ -68,9 +71,10 @@ def main():
             kernels = a.kernels
         if lod:
             kernels = [vrc.KERNEL_AUTO]
-        for k, flt in [(k, flt) for flt in a.filters for k in kernels]:
+        for k, flt, parts in [(k, flt, parts) for flt in a.filters for k in kernels for parts in a.ert_parts]:
             vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_KERNEL, k))
             vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_FILTER, flt))
+            vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_ERT_COMPACTION, parts))
             ms = []
             stt = vrc.Stats()
             for i in range(a.steps + 2):
@@ -80,6 +84,12 @@ def main():
                 if i >= 2:
                     ms.append(stt.kernel_ms)
             ms = np.array(ms)
+            if parts:
+                counts = (C.c_uint32 * 8)()
+                used = C.c_int()
+                vrc.check(L, L.vrc_get_ray_counts(g.ctx, C.byref(counts), C.byref(used)))
+                print("ray compaction in %d launches: rays alive after each %s of %d pixels"
+                      % (used.value, list(counts)[:max(used.value - 1, 0)], a.viewport ** 2), flush=True)
             A = a.voxels ** 3 + a.viewport ** 2 * 16 + s.n_nodes * 48 + 4096
             print("kernel %d filter %d: median %.3f ms min %.3f ms -> %.1f Msamples/s, %.1f fps, algorithmic %.1f GB/s"
                   % (k, flt, np.median(ms), ms.min(), n / np.median(ms) / 1e3, 1e3 / np.median(ms),
