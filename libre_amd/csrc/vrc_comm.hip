@@ -18,6 +18,7 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -41,22 +42,29 @@ struct Rccl
     std::string error;
 };
 
+Rccl g_rccl;
+
 Rccl* rccl()
 {
-    static Rccl r;
     static std::once_flag once;
-    std::call_once( once, [] {
+    Rccl& r = g_rccl;
+    std::call_once( once, [&r] {
+        /* VRC_RCCL_LIBRARY: another build of RCCL (or the test double of tests/host_san/fake_rccl.cpp) */
+        const char* const forced = getenv( "VRC_RCCL_LIBRARY" );
         const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-        for( const char* n : names )
-        {
-            r.handle = dlopen( n, RTLD_NOW | RTLD_GLOBAL );
-            if( r.handle )
-                break;
-        }
+        if( forced && forced[0] )
+            r.handle = dlopen( forced, RTLD_NOW | RTLD_LOCAL );
+        else
+            for( const char* n : names )
+            {
+                r.handle = dlopen( n, RTLD_NOW | RTLD_GLOBAL );
+                if( r.handle )
+                    break;
+            }
         if( !r.handle )
         {
             const char* e = dlerror();
-            r.error = std::string( "RCCL not found (librccl.so.1): " ) + ( e ? e : "?" );
+            r.error = std::string( "RCCL not found (" ) + ( forced && forced[0] ? forced : "librccl.so.1" ) + "): " + ( e ? e : "?" );
             return;
         }
         bool ok = true;
@@ -85,6 +93,9 @@ Rccl* rccl()
     } );
     return r.handle ? &r : nullptr;
 }
+
+/* after rccl() returned NULL: why */
+std::string rcclWhy() { return g_rccl.error.empty() ? std::string( "librccl.so.1 not loadable" ) : g_rccl.error; }
 
 int rcclFail( const char* what, ncclResult_t e )
 {
@@ -116,7 +127,7 @@ int vrc_comm_unique_id( uint8_t id[VRC_COMM_ID_BYTES] )
         return vrc_internal_fail( VRC_EINVAL, "vrc_comm_unique_id: id is NULL" );
     Rccl* r = rccl();
     if( !r )
-        return vrc_internal_fail( VRC_ECOMM, "vrc_comm_unique_id: RCCL unavailable (librccl.so.1 not loadable)" );
+        return vrc_internal_fail( VRC_ECOMM, "vrc_comm_unique_id: RCCL unavailable: " + rcclWhy() );
     ncclUniqueId u;
     VRC_RCCL_CHECK( "ncclGetUniqueId", r->GetUniqueId( &u ) );
     ::memcpy( id, u.internal, VRC_COMM_ID_BYTES );
@@ -142,8 +153,8 @@ int vrc_comm_create( vrc_ctx* ctx, int rank, int world, const uint8_t id[VRC_COM
         if( !r || !id )
         {
             delete c;
-            return vrc_internal_fail( VRC_ECOMM, !id ? "vrc_comm_create: id is NULL"
-                                                     : "vrc_comm_create: RCCL unavailable (librccl.so.1 not loadable)" );
+            return vrc_internal_fail( VRC_ECOMM, !id ? std::string( "vrc_comm_create: id is NULL" )
+                                                     : "vrc_comm_create: RCCL unavailable: " + rcclWhy() );
         }
         const hipError_t he = hipSetDevice( device );
         if( he != hipSuccess )

@@ -777,3 +777,30 @@ def test_nrrd_volume_through_the_plugin_matches_the_oracle(drv):
         assert st.n_available == 1 and st.samples_per_ray == s.render.samplesPerRay
         scenes.assert_parity(fb, want, "nucleon.nrrd through the plugin")
         assert abs(int(app.stats().samples) - n_want) <= 8
+
+
+def _fake_rccl():
+    """tests/host_san/fake_rccl.cpp built next to its source (atomic rename: parallel workers)."""
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_san")
+    src, out = os.path.join(here, "fake_rccl.cpp"), os.path.join(here, "libfake_rccl.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        tmp = "%s.%d.tmp" % (out, os.getpid())
+        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O1", "-shared", "-fPIC",
+                        "--offload-arch=gfx950", "-o", tmp, src], check=True, capture_output=True, timeout=300)
+        os.replace(tmp, out)
+    return out
+
+
+@pytest.mark.parametrize("world,bands,batch", [(2, 1, 1), (2, 3, 2), (3, 2, 2), (4, 5, 1)])
+def test_abi_gather_with_several_ranks_on_one_gpu(drv, world, bands, batch):
+    # vrc_gather_tiles with world > 1: the ranks are threads with a plugin instance each, RCCL is replaced by a
+    # test double that moves the bands with device copies and fails on any unmatched send / receive
+    # (tests/gpu_fake_rccl_gather.py): bands land at their rows, frames bit-identical to the one-rank frames
+    import subprocess
+    import sys
+    env = dict(os.environ, VRC_RCCL_LIBRARY=_fake_rccl())
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_fake_rccl_gather.py")
+    r = subprocess.run([sys.executable, script, str(world), str(bands), str(batch)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "ok:" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
