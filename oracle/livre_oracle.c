@@ -727,6 +727,20 @@ static float sliver_budget( const job_t* j, const orc_node_data* nodeData, f3 or
     return fmaxf( fmaxf( here[0], here[1] ), fmaxf( here[2], here[3] ) ) * transmittance;
 }
 
+/* TEST INSTRUMENT (orc_options.tieBudget), third part: the last sample of a brick segment.  The march takes
+ * ceil(dist / stepSize) samples (Renderer.cu:208: travel = dist; travel > 0; travel -= stepSize); where dist is
+ * within rounding of a whole number of steps, a last bit of the ray (tnear, tfar of the slab test) decides
+ * whether the sample at the far face is taken.  Returns the weight of the sample at texPos. */
+static float sample_weight( const job_t* j, f3 texPos, float multiplyer, float addedValue, float alphaCorrection,
+                            float transmittance )
+{
+    const float density = fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
+    float tfn[4], here[4] = { 0, 0, 0, 0 };
+    orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, tfn );
+    orc_composite( tfn, here, alphaCorrection );
+    return fmaxf( fmaxf( here[0], here[1] ), fmaxf( here[2], here[3] ) ) * transmittance;
+}
+
 /* one pixel: Renderer.cu:106-229 */
 static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
 {
@@ -789,6 +803,16 @@ static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
     /* Renderer.cu:170: 1.0 / float(spr) is a double division rounded to float on store */
     const float stepSize = (float)( 1.0 / (double)(float)renderData->samplesPerRay );
 
+    /* TEST INSTRUMENT (orc_options.tieBudget), fourth part: the early-exit test itself (Renderer.cu:219-226).  Two
+     * evaluations whose opacities differ by ertEps (what the parity rule allows them to: E0 + 2 x the budget so far)
+     * end the ray at different samples when an opacity comes out that close to the threshold: anywhere from the
+     * first sample that leaves the opacity above threshold - ertEps (ertLo = the opacity after it) to the first
+     * that leaves it above threshold + ertEps.  The results differ by at most the opacity gained in between, which
+     * is added to the budget; when the reference's own exit lies inside that window the march goes on on a copy
+     * (shadow, acc) until the window is left.  color and nSamples stay the restated algorithm's. */
+    float shadow[4] = { 0, 0, 0, 0 }, *acc = color, ertLo = -1.0f, ertEps = 0.0f;
+    int shadowMode = 0;
+
     for( uint32_t i = 0; i < j->nodeCount; ++i )
     {
         const orc_node_data* nodeData = &j->nodes[i];
@@ -798,7 +822,7 @@ static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
 
         float tNear = 0.0f, tFar = 0.0f;
         const int hitBox = intersect_box( origin, dir, boxMin, boxMax, &tNear, &tFar );
-        if( j->opt.tieBudget && !j->opt.filter && tFar >= tNearGlobal && tNear <= tFarGlobal &&
+        if( j->opt.tieBudget && !j->opt.filter && !shadowMode && tFar >= tNearGlobal && tNear <= tFarGlobal &&
             tFar >= tNearPlane ) /* test instrument, see orc_options */
             j->opt.tieBudget[pixelPos] += sliver_budget( j, nodeData, origin, dir, tNear, tFar, multiplyer,
                                                          addedValue, alphaCorrection, 1.0f - color[3] );
@@ -830,7 +854,10 @@ static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
         uint32_t kStep = 0; /* test instrument only (tie budget) */
         const f3 vpw = { texSize.x * (float)j->atlasDim[0] / boxSize.x, texSize.y * (float)j->atlasDim[1] / boxSize.y,
                          texSize.z * (float)j->atlasDim[2] / boxSize.z };
-        for( float travel = dist; travel > 0.0f;
+        /* test instrument only: how far a last bit of the ray moves the end of the segment (as sliver_budget) */
+        const float endEps = 4e-6f * fmaxf( 1.0f, fabsf( tFar ) );
+        float travel;
+        for( travel = dist; travel > 0.0f;
              pos.x += step.x, pos.y += step.y, pos.z += step.z, travel -= stepSize, ++kStep )
         {
             const f3 texPos = { ( ( pos.x - boxMin.x ) / boxSize.x ) * texSize.x + texMin.x,
@@ -840,19 +867,63 @@ static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
                                       ? fetch_trilinear( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos )
                                       : fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
             float transferFn[4];
-            if( j->opt.tieBudget && !j->opt.filter ) /* test instrument, see orc_options */
+            if( j->opt.tieBudget && !j->opt.filter && !shadowMode ) /* test instrument, see orc_options */
+            {
                 j->opt.tieBudget[pixelPos] += tie_budget( j, texPos, density, multiplyer, addedValue,
                                                           alphaCorrection, 1.0f - color[3], kStep, vpw );
+                if( travel <= endEps && kStep > 0 ) /* the sample at the far face barely made it */
+                    j->opt.tieBudget[pixelPos] += sample_weight( j, texPos, multiplyer, addedValue, alphaCorrection,
+                                                                 1.0f - color[3] );
+            }
             orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, transferFn );
-            orc_composite( transferFn, color, alphaCorrection );
-            ++nSamples;
-            isEarlyExit = color[3] > EARLY_EXIT;
+            orc_composite( transferFn, acc, alphaCorrection );
+            if( !shadowMode )
+            {
+                ++nSamples;
+                isEarlyExit = color[3] > EARLY_EXIT;
+            }
+            if( j->opt.tieBudget ) /* test instrument, fourth part: see ertLo below */
+            {
+                if( ertLo < 0.0f )
+                {
+                    ertEps = 5e-5f + 2.0f * j->opt.tieBudget[pixelPos];
+                    if( acc[3] > EARLY_EXIT - ertEps )
+                        ertLo = acc[3];
+                }
+                if( shadowMode )
+                {
+                    if( acc[3] > EARLY_EXIT + ertEps )
+                        break;
+                    continue;
+                }
+                if( isEarlyExit && color[3] <= EARLY_EXIT + ertEps )
+                {
+                    /* the reference's ray ends here; an evaluation whose opacity is ertEps lower goes on: follow
+                     * it on a copy until it, too, must have ended */
+                    shadowMode = 1;
+                    shadow[0] = color[0], shadow[1] = color[1], shadow[2] = color[2], shadow[3] = color[3];
+                    acc = shadow;
+                    continue;
+                }
+            }
             if( isEarlyExit )
                 break;
         }
-        if( isEarlyExit )
+        if( shadowMode && shadow[3] > EARLY_EXIT + ertEps )
             break;
+        if( isEarlyExit && !shadowMode )
+            break;
+        if( j->opt.tieBudget && !j->opt.filter && !shadowMode && travel > -endEps && kStep > 0 ) /* ... or barely did not */
+        {
+            const f3 texPos = { ( ( pos.x - boxMin.x ) / boxSize.x ) * texSize.x + texMin.x,
+                                ( ( pos.y - boxMin.y ) / boxSize.y ) * texSize.y + texMin.y,
+                                ( ( pos.z - boxMin.z ) / boxSize.z ) * texSize.z + texMin.z };
+            j->opt.tieBudget[pixelPos] += sample_weight( j, texPos, multiplyer, addedValue, alphaCorrection,
+                                                         1.0f - color[3] );
+        }
     }
+    if( j->opt.tieBudget && ertLo >= 0.0f )
+        j->opt.tieBudget[pixelPos] += fmaxf( 0.0f, acc[3] - ertLo );
     px[0] = color[0];
     px[1] = color[1];
     px[2] = color[2];

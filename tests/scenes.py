@@ -30,7 +30,18 @@ import orc
 # only touches comes out with tfar within 4e-6 (relative) of tnear).  A last bit of the ray decides whether such
 # a brick gets its one sample (cuda/Renderer.cu:79, :208); a host whose matrices differ in the last bit from the
 # oracle's (another, equally valid restatement of the un-vendored vmmlib) decides differently.  B includes the
-# weight that sample has or would have.  An outlier pixel is
+# weight that sample has or would have.  Third part: the LAST sample of a brick segment -- the march takes
+# ceil(dist / stepSize) samples (cuda/Renderer.cu:208), and where dist is within 4e-6 (relative to t) of a whole
+# number of steps the same last bit decides whether the sample at the far face is taken; B includes its weight
+# (found by the soak run VRC_FUZZ_SCALE=10: plugin seed 51, one pixel, one sample more than the oracle).
+# Fourth part: the early-exit test itself (cuda/Renderer.cu:219-226).  Two evaluations whose opacities differ by what
+# this rule allows them to (E0 + 2 x the budget so far) end a ray at different samples when an opacity comes out that
+# close to 0.999; the results then differ by the opacity gained between the first sample that leaves the ray
+# within that distance below the threshold and the first that leaves it that far above (the oracle follows the ray
+# on a copy past its own exit to find it); B includes that gain -- typically 1e-4 for a ray whose opacity creeps
+# up to the threshold, nothing for one that jumps over it (soak seed 249: the opacity after sample 31 is
+# 0.9990014 in the kernel, below 0.999 in the oracle, which takes sample 32).
+# An outlier pixel is
 # thus only accepted where the oracle's own arithmetic says a one-voxel flip is possible, and by no more
 # than that flip can make (x 2: the flipped sample's alpha also rescales everything behind it).  Pixels
 # without such samples get the bare E0.  There is no allowance for "a few pixels over the line" any more,

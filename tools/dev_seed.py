@@ -29,10 +29,11 @@ with drv.App(uri, W, H, synchronous=True, sse=sse, gpu_cache_mb=32) as app:
     ids = app.visible_set()
     fb, st = app.render_frame()
     n_plugin = int(app.stats().samples)
+    order = app.node_order()
     app.set_option(vrc.OPT_KERNEL, vrc.KERNEL_GRID_DDA)
     fb_dda, _ = app.render_frame()
 s = orc.build_scene(voxels=(vox, vox, vox), block=block, viewport=(W, H), ids=ids, spin=spin, eye=eye,
-                    volume=volume, alpha=0.3)
+                    volume=volume, alpha=0.3, order=order)
 want, n_want = orc.oracle_render(s, threads=8)
 tb = orc.budget_of(want)
 
