@@ -66,7 +66,10 @@ struct vrc_pool
     };
     std::vector< RenderFence > renderFences; /* last march of every context that used this pool */
 
-    hipStream_t uploadStream = nullptr;
+    hipStream_t uploadStream = nullptr; /* every write to the atlas (the repack kernels), in issue order */
+    /* the host-to-device copies into the staging buffers alternate between two streams of their own: the DMA of
+     * one brick runs while the repack kernel of the brick before it writes the atlas */
+    hipStream_t copyStream[2] = { nullptr, nullptr };
     hipEvent_t lastUpload = nullptr;
     bool hasUpload = false;
 
@@ -75,7 +78,8 @@ struct vrc_pool
         std::mutex mutex;
         void* pinned = nullptr;
         void* device = nullptr;
-        hipEvent_t done = nullptr;
+        hipEvent_t copied = nullptr; /* the brick is in `device` */
+        hipEvent_t done = nullptr;   /* ... and has been repacked into the atlas: both buffers are free */
         bool used = false;
     };
     Staging staging[kStagingSlots];
@@ -437,10 +441,14 @@ int vrc_pool_create( vrc_ctx* c, size_t bytesPerVoxel, int isSigned, int isFloat
     if( e == hipSuccess ) e = hipMemset( p->dAtlas, 0, p->atlasBytes );
     if( e == hipSuccess ) e = hipStreamCreateWithFlags( &p->uploadStream, hipStreamNonBlocking );
     if( e == hipSuccess ) e = hipEventCreateWithFlags( &p->lastUpload, hipEventDisableTiming );
+    for( int k = 0; k < 2 && e == hipSuccess; ++k )
+        e = hipStreamCreateWithFlags( &p->copyStream[k], hipStreamNonBlocking );
     for( int s = 0; s < kStagingSlots && e == hipSuccess; ++s )
     {
         e = hipHostMalloc( &p->staging[s].pinned, p->slotBytes );
         if( e == hipSuccess ) e = hipMalloc( &p->staging[s].device, p->slotBytes );
+        if( e == hipSuccess )
+            e = hipEventCreateWithFlags( &p->staging[s].copied, hipEventDisableTiming );
         if( e == hipSuccess )
             e = hipEventCreateWithFlags( &p->staging[s].done, hipEventDisableTiming );
     }
@@ -465,8 +473,11 @@ void vrc_pool_destroy( vrc_pool* p )
     {
         if( p->staging[s].pinned ) (void)hipHostFree( p->staging[s].pinned );
         if( p->staging[s].device ) (void)hipFree( p->staging[s].device );
+        if( p->staging[s].copied ) (void)hipEventDestroy( p->staging[s].copied );
         if( p->staging[s].done ) (void)hipEventDestroy( p->staging[s].done );
     }
+    for( int k = 0; k < 2; ++k )
+        if( p->copyStream[k] ) (void)hipStreamDestroy( p->copyStream[k] );
     if( p->lastUpload ) (void)hipEventDestroy( p->lastUpload );
     for( auto& f : p->renderFences )
         (void)hipEventDestroy( f.event );
@@ -549,8 +560,10 @@ static int pool_upload( vrc_pool* p, const void* src, bool srcIsDevice, const ui
         if( e == hipSuccess && !srcIsDevice )
         {
             std::memcpy( st.pinned, src, bytes ); /* the host pointer is only borrowed */
-            e = hipMemcpyAsync( st.device, st.pinned, bytes, hipMemcpyHostToDevice,
-                                p->uploadStream );
+            hipStream_t const cs = p->copyStream[si & 1u];
+            e = hipMemcpyAsync( st.device, st.pinned, bytes, hipMemcpyHostToDevice, cs );
+            if( e == hipSuccess ) e = hipEventRecord( st.copied, cs );
+            if( e == hipSuccess ) e = hipStreamWaitEvent( p->uploadStream, st.copied, 0 );
             devSrc = st.device;
         }
         if( e == hipSuccess )
