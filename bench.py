@@ -668,7 +668,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": ("vrc_k_raycast_raylod<false,false,true,0,unsigned char>" if ray_lod_on else
-                                    "vrc_k_raycast<true,false,false,true,0,unsigned char>"),
+                                    # grey transfer function (the linear ramp is one): the two-float table form,
+                                    # MODE 3 = VRC_MODE_GREY, bit-identical frames (VRC_OPT_GREY_TABLE)
+                                    "vrc_k_raycast<true,false,false,true,%d,unsigned char>"
+                                    % (0 if os.environ.get("VRC_GREY_TABLE", "1")[:1] == "0" else 3)),
                          "kernel_ms_per_frame": kernel_ms_per_frame,
                          "algorithmic_bytes_per_launch": per_rank_alg,
                          "algorithmic_bytes_per_frame_all_ranks": alg_bytes,

@@ -124,6 +124,14 @@ typedef struct
                                    * grid-walk kernel only, silently the plain kernel else.  With per-launch lists:
                                    * vrc_get_ray_counts */
 
+#define VRC_OPT_GREY_TABLE 12      /* 1 (default) | 0.  A transfer function whose red, green and blue are equal in every
+                                   * entry (bit for bit) lets the point-sampling grid-walk kernel keep (grey, alpha)
+                                   * instead of four floats per classified-table entry and per colour: half the
+                                   * table bytes in LDS and three fused multiply-adds less per sample.  The three colour
+                                   * channels of the reference's blend (cuda/Renderer.cu:83-93) are then the same
+                                   * operations on the same numbers, so the frame is bit-identical; first pass of
+                                   * a frame only (the pixel starts from zero).  0: always the four-float form */
+
 #define VRC_VARIANT_CUDARAYCASTER 0 /* renderers/cudaRaycaster/cuda/Renderer.cu:95-230 */
 #define VRC_VARIANT_GLRAYCASTER 1   /* renderers/glRaycaster/shaders/fragRaycast.glsl:113-215: pixel centre
                                      * +0.5, hit test t0 <= t1, first sample of a brick snapped to the

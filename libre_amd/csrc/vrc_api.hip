@@ -105,6 +105,8 @@ struct vrc_ctx
     uint64_t lutTfVersion = 0;
     vrc_lut_params lutParams = { 0, 0, 0, 0 };
     float lutMaxAlpha = 1.0f; /* largest opacity in the classified table (1: unknown) */
+    bool tfGrey = false;      /* red == green == blue in every entry of the transfer function (bitwise) */
+    int64_t optGreyTable = 1; /* VRC_OPT_GREY_TABLE */
     bool lutLinear = false;
     uint32_t lutLevels = 1;
 
@@ -228,6 +230,9 @@ int vrc_ctx_create( int device, vrc_ctx** out )
     for( int i = 0; i < 256; ++i )
         tf[i * 4 + 0] = tf[i * 4 + 1] = tf[i * 4 + 2] = tf[i * 4 + 3] = (float)i / 255.0f;
     std::memcpy( c->hTf, tf, sizeof( tf ) );
+    c->tfGrey = true;
+    if( const char* g = std::getenv( "VRC_GREY_TABLE" ) ) /* default of VRC_OPT_GREY_TABLE for this process */
+        c->optGreyTable = g[0] != '0';
     e = hipMemcpy( c->dTf, tf, sizeof( tf ), hipMemcpyHostToDevice );
     if( e != hipSuccess )
     {
@@ -305,6 +310,7 @@ int vrc_set_option( vrc_ctx* c, int option, int64_t value )
     case VRC_OPT_STEPPING: c->optStepping = value ? 1 : 0; return VRC_OK;
     case VRC_OPT_KERNEL_TIMING: c->optTiming = value ? 1 : 0; return VRC_OK;
     case VRC_OPT_DEPTH_SPLIT: c->optDepthSplit = value ? 1 : 0; return VRC_OK;
+    case VRC_OPT_GREY_TABLE: c->optGreyTable = value ? 1 : 0; return VRC_OK;
     case VRC_OPT_ERT_COMPACTION:
         if( value < 0 || value > VRC_MAX_ERT_PARTS )
             return fail( VRC_EINVAL, "VRC_OPT_ERT_COMPACTION: 0 (off) or 2.." + std::to_string( VRC_MAX_ERT_PARTS ) +
@@ -335,6 +341,7 @@ int vrc_get_option( vrc_ctx* c, int option, int64_t* value )
     case VRC_OPT_KERNEL_TIMING: *value = c->optTiming; return VRC_OK;
     case VRC_OPT_DEPTH_SPLIT: *value = c->optDepthSplit; return VRC_OK;
     case VRC_OPT_ERT_COMPACTION: *value = c->optErtParts; return VRC_OK;
+    case VRC_OPT_GREY_TABLE: *value = c->optGreyTable; return VRC_OK;
     case VRC_OPT_VARIANT: *value = c->optVariant; return VRC_OK;
     case VRC_OPT_KERNEL_USED: *value = c->stats.kernel_variant; return VRC_OK;
     default: return fail( VRC_EINVAL, "vrc_get_option: unknown option" );
@@ -755,6 +762,10 @@ int vrc_update( vrc_ctx* c, const float tf[256 * 4], const float* planes, uint32
          * rewritten once the previous async copy from it has been consumed. */
         VRC_HIP_CHECK( hipStreamSynchronize( c->stream ) );
         std::memcpy( c->hTf, tf, 256 * 4 * sizeof( float ) );
+        c->tfGrey = true;
+        for( int i = 0; i < 256 && c->tfGrey; ++i )
+            c->tfGrey = std::memcmp( c->hTf + 4 * i, c->hTf + 4 * i + 1, sizeof( float ) ) == 0 &&
+                        std::memcmp( c->hTf + 4 * i, c->hTf + 4 * i + 2, sizeof( float ) ) == 0;
         VRC_HIP_CHECK( hipMemcpyAsync( c->dTf, c->hTf, 256 * 4 * sizeof( float ),
                                        hipMemcpyHostToDevice, c->stream ) );
         ++c->tfVersion;
@@ -1205,6 +1216,8 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         a.rayList = c->dRayList;
     }
     c->lastErtParts = a.ertParts;
+    /* grey transfer function, frame starting from zero: two-float table entries, the same bits (VRC_MODE_GREY) */
+    a.greyTable = c->optGreyTable && c->tfGrey && f.clearFirst;
     a.classifier = vrc_make_classifier( lp );
 
     /* order the march after every brick upload issued so far (fixes quirk Q9) */

@@ -57,6 +57,11 @@ struct vrc_f4
 {
     float x, y, z, w;
 };
+/* (grey, alpha): a colour or a classified-table entry whose red, green and blue are one number (VRC_MODE_GREY) */
+struct vrc_f2
+{
+    float x, w;
+};
 
 /* Kernel-side copy of vrc_node_data plus what the sampler needs per brick. 64 bytes. */
 struct vrc_dev_node
@@ -674,6 +679,16 @@ VRC_HD void vrc_composite( vrc_f4& c, const vrc_f4& e, bool frozen = false )
     c.z = c.z + e.z * t;
     c.w = c.w + e.w * t;
 }
+/* the same blend for a grey table: red, green and blue of the four-float form are the same three operations on the
+ * same numbers, so doing them once gives the same bits */
+VRC_HD void vrc_composite( vrc_f2& c, const vrc_f2& e, bool frozen = false )
+{
+    VRC_FAST_FP
+    float t = 1.0f - c.w;
+    t = frozen ? 0.0f : t;
+    c.x = c.x + e.x * t;
+    c.w = c.w + e.w * t;
+}
 
 /* ------------------------------------------------------------------------------------------
  * March one brick segment (Renderer.cu:206-223).
@@ -700,10 +715,10 @@ VRC_HD void vrc_composite( vrc_f4& c, const vrc_f4& e, bool frozen = false )
 #define VRC_GROUP 8
 #endif
 
-template < bool CLAMP, bool COUNT, bool FIXED, typename ATLAS_T, int GROUP = VRC_GROUP >
-VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_segment s,
-                               const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
-                               vrc_f4& color, uint32_t& nSamples, float levelStep = 0.0f )
+template < bool CLAMP, bool COUNT, bool FIXED, typename ATLAS_T, int GROUP, typename E >
+VRC_HD bool vrc_march_segment_as( const vrc_frame& f, const vrc_dev_node& n, vrc_segment s,
+                                  const ATLAS_T* __restrict__ atlas, const E* lut,
+                                  E& color, uint32_t& nSamples, float levelStep )
 {
     /* levelStep: step of a coarser brick under per-ray LOD (vrc_pixel_ray_lod); 0 = the frame's */
     const float stepSize = levelStep > 0.0f ? levelStep : f.stepSize;
@@ -731,7 +746,7 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
 #pragma unroll
         for( int k = 0; k < GROUP; ++k )
             travel -= stepSize; /* same sequential subtraction as the reference */
-        vrc_f4 e[GROUP];
+        E e[GROUP];
 #pragma unroll
         for( int k = 0; k < GROUP; ++k )
         {
@@ -745,7 +760,7 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
             e[k] = lut[(uint32_t)atlas[idx[k]]];
 #endif
         }
-        const vrc_f4 saved = color;
+        const E saved = color;
 #pragma unroll
         for( int k = 0; k < GROUP; ++k )
             vrc_composite( color, e[k] );
@@ -796,7 +811,7 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
 #pragma unroll
         for( int k = 0; k < TAILG; ++k )
             d[k] = (uint32_t)atlas[idx[k]];
-        vrc_f4 e[TAILG];
+        E e[TAILG];
 #pragma unroll
         for( int k = 0; k < TAILG; ++k )
             e[k] = lut[(uint32_t)k < cnt ? d[k] : 256u];
@@ -811,6 +826,27 @@ VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_se
         }
     }
     return done;
+}
+
+template < bool CLAMP, bool COUNT, bool FIXED, typename ATLAS_T, int GROUP = VRC_GROUP, bool GREY = false >
+VRC_HD bool vrc_march_segment( const vrc_frame& f, const vrc_dev_node& n, vrc_segment s,
+                               const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
+                               vrc_f4& color, uint32_t& nSamples, float levelStep = 0.0f )
+{
+    if constexpr( GREY )
+    {
+        /* lut holds two-float entries (the kernel fills it that way); the colour came in grey (a cleared pixel)
+         * and leaves grey */
+        vrc_f2 c = { color.x, color.w };
+        const bool done = vrc_march_segment_as< CLAMP, COUNT, FIXED, ATLAS_T, GROUP, vrc_f2 >(
+            f, n, s, atlas, reinterpret_cast< const vrc_f2* >( lut ), c, nSamples, levelStep );
+        color.x = color.y = color.z = c.x;
+        color.w = c.w;
+        return done;
+    }
+    else
+        return vrc_march_segment_as< CLAMP, COUNT, FIXED, ATLAS_T, GROUP, vrc_f4 >( f, n, s, atlas, lut, color,
+                                                                                  nSamples, levelStep );
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1021,6 +1057,8 @@ VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n,
  *                       the reference path;
  *   VRC_MODE_TRILINEAR  trilinear fetch, per-sample classification (lut = padded transfer function);
  *   VRC_MODE_POINT      point sample, per-sample classification (16-bit voxels). */
+#define VRC_MODE_GREY 3 /* VRC_MODE_TABLE with a grey transfer function (r == g == b in every entry): two-float table
+                         * entries and colours, bit-identical frames, half the table bytes and blend work */
 #define VRC_MODE_TABLE 0
 #define VRC_MODE_TRILINEAR 1
 #define VRC_MODE_POINT 2
@@ -1042,7 +1080,10 @@ VRC_HD bool vrc_march_brick( const vrc_frame& f, const vrc_dev_node& n, const vr
         return vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, false >( f, local, s, slot, lut, cls,
                                                                                 color, nSamples, levelStep );
     }
-    if( MODE != VRC_MODE_TABLE )
+    if constexpr( MODE == VRC_MODE_GREY )
+        return vrc_march_segment< CLAMP, COUNT, FIXED, ATLAS_T, GROUP, true >( f, n, s, atlas, lut, color, nSamples,
+                                                                             levelStep );
+    else if( MODE != VRC_MODE_TABLE )
         return vrc_march_segment_linear< CLAMP, COUNT, MODE == VRC_MODE_TRILINEAR, ATLAS_T >(
             f, n, s, atlas, lut, cls, color, nSamples, levelStep );
     return vrc_march_segment< CLAMP, COUNT, FIXED, ATLAS_T, GROUP >( f, n, s, atlas, lut, color, nSamples,

@@ -83,6 +83,8 @@ struct vrc_raycast_args
                          * transfer function whenever samples are classified one by one */
     vrc_classifier classifier;
     bool bigAtlas; /* more than 2^32 voxels: node slot bases are 64-bit (BIG kernel instances) */
+    bool greyTable;    /* the transfer function is grey and the frame starts from zero: the two-float table form
+                        * (VRC_MODE_GREY) of the point-sampling grid-walk kernel composites the same bits */
     int ertParts;      /* > 1: ray compaction, the march in this many launches (vrc_k_raycast_part); the host sets it
                         * only for the table-driven point-sampling walk kernel and frames below 65536 pixels a side */
     uint32_t* rayList; /* counts[VRC_MAX_ERT_PARTS] | two lists of width * height packed pixels */

@@ -415,7 +415,7 @@ template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLA
  * the float position chain, the clamped sampler and 64-bit slot bases need more registers than 5 waves leave (they
  * spilled at 5: the trilinear gather form ran 5.3 instead of 2.9 ms) */
 __global__ __launch_bounds__( VRC_WG_THREADS, GROUP > 8 ? 2
-                                              : ( MODE == VRC_MODE_TABLE && FIXED && !CLAMP && !BIG ? VRC_MIN_WAVES
+                                              : ( ( MODE == VRC_MODE_TABLE || MODE == VRC_MODE_GREY ) && FIXED && !CLAMP && !BIG ? VRC_MIN_WAVES
                                                                                                     : 4 ) ) void vrc_k_raycast(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ gridTable, const ATLAS_T* __restrict__ atlas,
@@ -428,12 +428,25 @@ __global__ __launch_bounds__( VRC_WG_THREADS, GROUP > 8 ? 2
     __shared__ vrc_f4 lut[VRC_TFP_ENTRIES];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
+    if( MODE == VRC_MODE_GREY )
+    {
+        /* grey table: (rgb * alpha', alpha') as two floats per entry, 257 entries */
+        vrc_f2* const lut2 = reinterpret_cast< vrc_f2* >( lut );
+        for( uint32_t i = tid; i < VRC_LUT_ENTRIES; i += VRC_WG_THREADS )
+        {
+            const vrc_f4 e = lutGlobal[i];
+            lut2[i] = vrc_f2{ e.x, e.w };
+        }
+    }
+    else
+    {
 #pragma unroll
-    for( uint32_t i = 0; i < ( 256u + VRC_WG_THREADS - 1u ) / VRC_WG_THREADS; ++i )
-        if( tid + i * VRC_WG_THREADS < 256u )
-            lut[tid + i * VRC_WG_THREADS] = lutGlobal[tid + i * VRC_WG_THREADS];
-    if( tid < VRC_TFP_ENTRIES - 256u )
-        lut[256u + tid] = lutGlobal[256u + tid];
+        for( uint32_t i = 0; i < ( 256u + VRC_WG_THREADS - 1u ) / VRC_WG_THREADS; ++i )
+            if( tid + i * VRC_WG_THREADS < 256u )
+                lut[tid + i * VRC_WG_THREADS] = lutGlobal[tid + i * VRC_WG_THREADS];
+        if( tid < VRC_TFP_ENTRIES - 256u )
+            lut[256u + tid] = lutGlobal[256u + tid];
+    }
 #if defined( VRC_ADDR_TABLES )
     if( FIXED )
     {
@@ -510,9 +523,13 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
     const uint32_t nTiles = tilesX * tilesY;
     if( nTiles == 0 )
         return hipSuccess;
+    /* The grey form needs 80 registers: a sixth wave per SIMD would fit, and six thrash the L1 (DESIGN.md section 4;
+     * frames in flight: 2180 -> 1730 frames/s).  20 KiB of LDS the kernel never touches keep it at five workgroups
+     * per CU (160 KiB / (7 + 20) KiB), the occupancy the four-float form has by its registers. */
+    const uint32_t ldsPad = ( MODE == VRC_MODE_GREY && GROUP <= 8 && VRC_WAVES_PER_WG == 4u ) ? 20u * 1024u : 0u;
     hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG > ),
                         dim3( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_WAVES_PER_WG - 1u ) / VRC_WAVES_PER_WG ),
-                        dim3( VRC_WG_THREADS ), 0, stream, a.frame, a.nodes, a.gridTable,
+                        dim3( VRC_WG_THREADS ), ldsPad, stream, a.frame, a.nodes, a.gridTable,
                         (const ATLAS_T*)a.atlas, a.lut, a.classifier, a.pixelBuffer,
                         a.sampleCounter, a.tileOrder, tilesX, nTiles );
     return hipGetLastError();
@@ -873,10 +890,16 @@ hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
     case 8: return launch_variant< false, false, false, true, VRC_MODE_TABLE, uint8_t >( a, stream );
     case 9: return launch_variant< false, false, true, true, VRC_MODE_TABLE, uint8_t >( a, stream );
     case 12:
+        if( a.greyTable )
+            return smallLaunch ? launch_variant< true, false, false, true, VRC_MODE_GREY, uint8_t, 16 >( a, stream )
+                               : launch_variant< true, false, false, true, VRC_MODE_GREY, uint8_t >( a, stream );
         if( smallLaunch )
             return launch_variant< true, false, false, true, VRC_MODE_TABLE, uint8_t, 16 >( a, stream );
         return launch_variant< true, false, false, true, VRC_MODE_TABLE, uint8_t >( a, stream );
     default:
+        if( a.greyTable )
+            return smallLaunch ? launch_variant< true, false, true, true, VRC_MODE_GREY, uint8_t, 16 >( a, stream )
+                               : launch_variant< true, false, true, true, VRC_MODE_GREY, uint8_t >( a, stream );
         if( smallLaunch )
             return launch_variant< true, false, true, true, VRC_MODE_TABLE, uint8_t, 16 >( a, stream );
         return launch_variant< true, false, true, true, VRC_MODE_TABLE, uint8_t >( a, stream );

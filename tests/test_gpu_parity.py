@@ -1038,3 +1038,40 @@ def test_ray_compaction_is_bit_identical(vrc):
         scenes.assert_parity(fb, want, "136^3 noise, 4 launches")
         ended, hits = int((plain[..., 3] > 0.999).sum()), int((plain[..., 3] > 0).sum())
         assert ended > 0 and counts[0] >= counts[2] and counts[2] <= hits - ended // 2, (counts, ended, hits)
+
+
+def test_grey_table_form_is_bit_identical(vrc):
+    # VRC_OPT_GREY_TABLE (default on): a transfer function with r == g == b in every entry lets the point-sampling
+    # grid-walk kernel keep (grey, alpha) instead of four floats per table entry and colour; the three colour
+    # channels of the reference's blend are then the same operations on the same numbers, so every bit of the frame
+    # is the four-float kernel's -- with early termination, clip planes, from inside the volume, in a multipass frame
+    # (first pass grey, later passes four floats), and at the judged 136^3-slot shape
+    cases = [scenes.get(n) for n in ("hash64_spin", "hash64_ert", "mem64_axis", "hash_clip", "mem_inside", "mem_ragged")]
+    cases.append(orc.build_scene(voxels=(256, 256, 256), block=128, viewport=(256, 256), volume="hash",
+                                 spin=(0.5236, 0.349), alpha=0.3))
+    for s in cases:
+        assert (s.tf[:, 0] == s.tf[:, 1]).all() and (s.tf[:, 0] == s.tf[:, 2]).all()  # the linear ramp is grey
+        with _gpu(s) as g:
+            vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 0))
+            four, n_four, _ = g.render()
+            h = s.n_nodes // 2
+            four2, n_four2, _ = g.render(passes=[(0, h), (h, s.n_nodes)])
+            vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 1))
+            grey, n_grey, st = g.render()
+            assert st.kernel_variant == vrc.KERNEL_GRID_DDA
+            assert (grey == four).all() and n_grey == n_four
+            assert (grey[..., 0] == grey[..., 1]).all() and (grey[..., 0] == grey[..., 2]).all()
+            grey2, n_grey2, _ = g.render(passes=[(0, h), (h, s.n_nodes)])
+            assert (grey2 == four2).all() and n_grey2 == n_four2
+    # a coloured transfer function: the option changes nothing, the frame is the oracle's
+    s = scenes.get("hash64_spin")
+    i = np.arange(256, dtype=np.float32) / np.float32(255.0)
+    s.tf = np.ascontiguousarray(np.stack([i, i * i, np.float32(1.0) - i, np.float32(0.3) * i], axis=1))
+    want, n_want = orc.oracle_render(s, threads=8)
+    with _gpu(s) as g:
+        got, n_got, _ = g.render()
+        scenes.assert_parity(got, want, "coloured transfer function")
+        assert n_got == n_want and not (got[..., 0] == got[..., 1]).all()
+        vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 0))
+        again, _, _ = g.render()
+        assert (again == got).all()
