@@ -402,6 +402,12 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t*
 /* ------------------------------------------------------------------------------------------
  * the raycast kernel
  * ---------------------------------------------------------------------------------------- */
+#ifndef VRC_GREY_GROUP
+/* samples a lane of the grey form keeps in flight: its two-float colours and table entries leave registers for 12 at
+ * five waves per SIMD (95 VGPRs); measured on C2 against 8: 0.509 -> 0.492 ms (mem://), 0.512 -> 0.493 ms (noise);
+ * 14 and 16 need 127 registers (four waves) */
+#define VRC_GREY_GROUP 12
+#endif
 #ifndef VRC_MIN_WAVES
 #define VRC_MIN_WAVES 5 /* measured on C2: 4 -> 5 waves per SIMD with four-wave workgroups: -2 % */
 #endif
@@ -414,9 +420,10 @@ template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLA
 /* waves per SIMD: 5 for the table-driven point-sampling instances (48 VGPRs); the per-sample classification modes,
  * the float position chain, the clamped sampler and 64-bit slot bases need more registers than 5 waves leave (they
  * spilled at 5: the trilinear gather form ran 5.3 instead of 2.9 ms) */
-__global__ __launch_bounds__( VRC_WG_THREADS, GROUP > 8 ? 2
-                                              : ( ( MODE == VRC_MODE_TABLE || MODE == VRC_MODE_GREY ) && FIXED && !CLAMP && !BIG ? VRC_MIN_WAVES
-                                                                                                    : 4 ) ) void vrc_k_raycast(
+__global__ __launch_bounds__( VRC_WG_THREADS, GROUP > VRC_GREY_GROUP ? 2
+                                              : ( ( ( MODE == VRC_MODE_TABLE && GROUP <= 8 ) || MODE == VRC_MODE_GREY ) && FIXED && !CLAMP && !BIG
+                                                      ? VRC_MIN_WAVES
+                                                      : ( GROUP > 8 ? 2 : 4 ) ) ) void vrc_k_raycast(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ gridTable, const ATLAS_T* __restrict__ atlas,
     const vrc_f4* __restrict__ lutGlobal, const vrc_classifier cls,
@@ -526,7 +533,7 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
     /* The grey form needs 80 registers: a sixth wave per SIMD would fit, and six thrash the L1 (DESIGN.md section 4;
      * frames in flight: 2180 -> 1730 frames/s).  20 KiB of LDS the kernel never touches keep it at five workgroups
      * per CU (160 KiB / (7 + 20) KiB), the occupancy the four-float form has by its registers. */
-    const uint32_t ldsPad = ( MODE == VRC_MODE_GREY && GROUP <= 8 && VRC_WAVES_PER_WG == 4u ) ? 20u * 1024u : 0u;
+    const uint32_t ldsPad = ( MODE == VRC_MODE_GREY && GROUP <= VRC_GREY_GROUP && VRC_WAVES_PER_WG == 4u ) ? 20u * 1024u : 0u;
     hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG > ),
                         dim3( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_WAVES_PER_WG - 1u ) / VRC_WAVES_PER_WG ),
                         dim3( VRC_WG_THREADS ), ldsPad, stream, a.frame, a.nodes, a.gridTable,
@@ -892,14 +899,14 @@ hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
     case 12:
         if( a.greyTable )
             return smallLaunch ? launch_variant< true, false, false, true, VRC_MODE_GREY, uint8_t, 16 >( a, stream )
-                               : launch_variant< true, false, false, true, VRC_MODE_GREY, uint8_t >( a, stream );
+                               : launch_variant< true, false, false, true, VRC_MODE_GREY, uint8_t, VRC_GREY_GROUP >( a, stream );
         if( smallLaunch )
             return launch_variant< true, false, false, true, VRC_MODE_TABLE, uint8_t, 16 >( a, stream );
         return launch_variant< true, false, false, true, VRC_MODE_TABLE, uint8_t >( a, stream );
     default:
         if( a.greyTable )
             return smallLaunch ? launch_variant< true, false, true, true, VRC_MODE_GREY, uint8_t, 16 >( a, stream )
-                               : launch_variant< true, false, true, true, VRC_MODE_GREY, uint8_t >( a, stream );
+                               : launch_variant< true, false, true, true, VRC_MODE_GREY, uint8_t, VRC_GREY_GROUP >( a, stream );
         if( smallLaunch )
             return launch_variant< true, false, true, true, VRC_MODE_TABLE, uint8_t, 16 >( a, stream );
         return launch_variant< true, false, true, true, VRC_MODE_TABLE, uint8_t >( a, stream );
