@@ -670,8 +670,9 @@ def main():
                          "kernel": ("vrc_k_raycast_raylod<false,false,true,0,unsigned char>" if ray_lod_on else
                                     # grey transfer function (the linear ramp is one): the two-float table form,
                                     # MODE 3 = VRC_MODE_GREY, bit-identical frames (VRC_OPT_GREY_TABLE)
-                                    "vrc_k_raycast<true,false,false,true,%d,unsigned char>"
-                                    % (0 if os.environ.get("VRC_GREY_TABLE", "1")[:1] == "0" else 3)),
+                                    ("vrc_k_raycast<true,false,false,true,0,unsigned char,8,false>"
+                                     if os.environ.get("VRC_GREY_TABLE", "1")[:1] == "0" else
+                                     "vrc_k_raycast<true,false,false,true,3,unsigned char,12,false>")),
                          "kernel_ms_per_frame": kernel_ms_per_frame,
                          "algorithmic_bytes_per_launch": per_rank_alg,
                          "algorithmic_bytes_per_frame_all_ranks": alg_bytes,
