@@ -149,6 +149,22 @@ class BatchedTileGather:
 
 
 
+def check_one_hip_runtime():
+    """PyTorch ships its own libamdhip64 / librccl (same sonames as ROCm's).  Imported FIRST, they satisfy
+    libvrc_hip.so's dependencies and the process has one HIP runtime and one RCCL, shared by both; the other way round
+    the process ends up with two runtimes, and a stream or an event of one is garbage to the other.  Raises if that
+    has happened (Linux: /proc/self/maps)."""
+    try:
+        maps = open("/proc/self/maps").read()
+    except OSError:
+        return
+    import re
+    found = sorted(set(re.findall(r"(/\S*libamdhip64\S*)", maps)))
+    if len(found) > 1:
+        raise RuntimeError("two HIP runtimes in one process (%s): import torch before loading libvrc_hip.so / "
+                           "libLivreHipRaycastPipeline.so" % ", ".join(found))
+
+
 class AbiTileGather:
     """The sort-first assembly through the C ABI: vrc_gather_tiles (include/vrc_hip.h) -- RCCL sends and
     receives, one per band, that land every band directly at its rows of the frame on the display rank; no
@@ -158,6 +174,7 @@ class AbiTileGather:
     (app.comm_create)."""
 
     def __init__(self, app, layout, width, rank, device, batch, dst=0):
+        check_one_hip_runtime()
         self.app, self.layout, self.width, self.rank, self.dst, self.batch = app, layout, width, rank, dst, batch
         self.world = len(layout)
         self.rows = sum(h for _, h in layout[rank])
