@@ -1148,6 +1148,7 @@ VRC_HD int vrc_part_dir( const vrc_frame& f )
  * only the bricks met in that one of `parts` equal slabs of the brick grid along axis partDir & 3, counted in the
  * direction the view looks along it (partDir & 4: towards smaller coordinates; vrc_part_dir).  The slab is a
  * property of the grid cell, the same for every ray: the lanes of a wave agree on which launch marches a brick.
+ * partDir < 0 (two parts): the halves of the ray's own interval inside the grid instead.
  * Every brick is marched whole in exactly one part, and a brick's part never falls below that of a brick met
  * before it, so marching the parts one after the other composites the reference's samples in the reference's
  * order.  Two users: the depth split (two waves march the two halves of a tile's rays at the same time and the
@@ -1239,10 +1240,20 @@ VRC_HD bool vrc_ray_grid_dda( const vrc_frame& f, const vrc_ray& r, const vrc_de
             {
                 if( part >= 0 )
                 {
-                    const int ax = partDir & 3;
-                    const int dim = f.gridDim[ax];
-                    const int c = ax == 0 ? cx : ( ax == 1 ? cy : cz );
-                    int sp = ( ( ( partDir & 4 ) ? dim - 1 - c : c ) * parts ) / dim;
+                    int sp;
+                    if( partDir < 0 )
+                        /* by ray parameter: the brick's segment starts in the near / far half of THIS ray's interval
+                         * inside the grid -- halves of equal length for every ray (what the depth split wants: the
+                         * longer half is the latency), at the price that the lanes of a wave disagree about the
+                         * brick the middle falls into */
+                        sp = s.tNear < 0.5f * ( t0 + t1 ) ? 0 : 1;
+                    else
+                    {
+                        const int ax = partDir & 3;
+                        const int dim = f.gridDim[ax];
+                        const int c = ax == 0 ? cx : ( ax == 1 ? cy : cz );
+                        sp = ( ( ( partDir & 4 ) ? dim - 1 - c : c ) * parts ) / dim;
+                    }
                     sp = sp > lastPart ? sp : lastPart;
                     lastPart = sp;
                     if( sp > part )

@@ -544,7 +544,8 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
 
 /* ------------------------------------------------------------------------------------------
  * Depth split (VRC_OPT_DEPTH_SPLIT): the same integrator with TWO waves per tile -- wave h of a tile marches the
- * bricks of the near (h = 0) or far (h = 1) half of the brick grid along the view axis (vrc_ray_grid_dda) -- composited with the
+ * bricks whose segments start in the near (h = 0) or far (h = 1) half of each ray's interval inside the brick grid
+ * (vrc_ray_grid_dda, partDir < 0) -- composited with the
  * `over` operator through LDS.  For launches that cannot fill the machine (a rank's share of a sort-first frame):
  * the time of such a launch is the longest ray's dependent chain of samples, and this halves it.  Every brick
  * is marched whole by exactly one of the two waves, so the samples are the reference's; compositing the far half
@@ -637,7 +638,8 @@ static hipError_t launch_split( const vrc_raycast_args& a, hipStream_t stream )
     hipLaunchKernelGGL( ( vrc_k_raycast_split< COUNT, GROUP > ), dim3( vrc_schedule_slots( tilesX, tilesY ) / 4u ),
                         dim3( 512 ), 0, stream, a.frame, a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut,
                         a.classifier, a.pixelBuffer, a.sampleCounter, a.tileOrder, tilesX, tilesX * tilesY,
-                        vrc_part_dir( a.frame ) );
+                        -1 /* halves of every ray's own interval: measured better balanced than grid slabs from 4 ranks
+                              down */ );
     return hipGetLastError();
 }
 
