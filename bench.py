@@ -677,9 +677,10 @@ def main():
                          "algorithmic_bytes_per_launch": per_rank_alg,
                          "algorithmic_bytes_per_frame_all_ranks": alg_bytes,
                          "launches_per_frame": 1,
-                         "note": "the kernel is bound by the vector L1's tag look-ups (one per cycle per CU; a "
-                                 "64-lane byte gather takes ~27 of them: TCP_TOTAL_CACHE_ACCESSES per CU = "
-                                 "kernel cycles), not by HBM (DESIGN.md section 4); traffic = FETCH_SIZE + WRITE_SIZE bytes per "
+                         "note": "not HBM-bound: the kernel sits on a plateau of vector issue (18.9 instructions per "
+                                 "64-sample step = 71 % of the issue slots) and gather latency that five waves per "
+                                 "SIMD do not cover; L1 look-ups, loads in flight and occupancy were each changed by "
+                                 "20-40 % without moving the time (DESIGN.md section 4); traffic = FETCH_SIZE + WRITE_SIZE bytes per "
                                  "launch from profiles/r2_traffic_c2.json"},
         }
         if world == 1 and not a.no_cpu_baseline and not ray_lod_on:

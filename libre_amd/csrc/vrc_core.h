@@ -142,7 +142,9 @@ struct vrc_layout
  *   1: micro-blocks 576 B apart and block rows padded to 3 mod 8 blocks: the 64-B lines of x/y
  *      neighbour blocks fall into different 64-B phases of a 512-B period
  *   2: row-major (x fastest), pitch slotDim.x + VRC_LAYOUT_PADX
- *   3: 64-B lines of 32 x 2 voxels      4: 64-B lines of 16 x 4 voxels */
+ *   3: 64-B lines of 32 x 2 voxels      4: 64-B lines of 16 x 4 voxels
+ *   5: 64-B lines of 4 x 4 x 4 voxels, z fastest (a dword = four voxels along z); with VRC_ZRUN the fast groups of
+ *      the march keep a lane's dword and reload it only when the voxel column or the 4-voxel block changes */
 #ifndef VRC_LAYOUT
 #define VRC_LAYOUT 0
 #endif
@@ -165,6 +167,8 @@ VRC_HD vrc_lay vrc_make_lay( uint32_t sbx, uint32_t sby )
     l.a = 1u; l.b = sbx * 8u + VRC_LAYOUT_PADX; l.c = l.b * sby * 8u;
 #elif VRC_LAYOUT == 3
     l.a = 64u; l.b = 64u * ( ( sbx * 8u + 31u ) / 32u ); l.c = l.b * sby * 4u;
+#elif VRC_LAYOUT == 5
+    l.a = 64u; l.b = 64u * sbx * 2u; l.c = l.b * sby * 2u;
 #else
     l.a = 64u; l.b = 64u * ( ( sbx * 8u + 15u ) / 16u ); l.c = l.b * sby * 2u;
 #endif
@@ -180,6 +184,8 @@ VRC_HD uint32_t vrc_lay_x( const vrc_lay& l, uint32_t u )
     return u;
 #elif VRC_LAYOUT == 3
     return ( u & 31u ) + l.a * ( u >> 5 );
+#elif VRC_LAYOUT == 5
+    return 16u * ( u & 3u ) + l.a * ( u >> 2 );
 #else
     return ( u & 15u ) + l.a * ( u >> 4 );
 #endif
@@ -194,6 +200,8 @@ VRC_HD uint32_t vrc_lay_y( const vrc_lay& l, uint32_t u )
     return l.b * u;
 #elif VRC_LAYOUT == 3
     return 32u * ( u & 1u ) + l.b * ( u >> 1 );
+#elif VRC_LAYOUT == 5
+    return 4u * ( u & 3u ) + l.b * ( u >> 2 );
 #else
     return 16u * ( u & 3u ) + l.b * ( u >> 2 );
 #endif
@@ -204,6 +212,8 @@ VRC_HD uint32_t vrc_lay_z( const vrc_lay& l, uint32_t u )
     return 64u * u + l.c * ( u >> 3 );
 #elif VRC_LAYOUT == 1
     return 64u * ( u & 7u ) + l.c * ( u >> 3 );
+#elif VRC_LAYOUT == 5
+    return ( u & 3u ) + l.c * ( u >> 2 );
 #else
     return l.c * u;
 #endif
@@ -215,6 +225,8 @@ VRC_HD uint64_t vrc_slot_elems( uint32_t sdx, uint32_t sdy, uint32_t sdz )
     return (uint64_t)sdx * sdy * sdz;
 #elif VRC_LAYOUT == 1
     return (uint64_t)vrc_make_lay( sdx >> 3, sdy >> 3 ).c * ( sdz >> 3 );
+#elif VRC_LAYOUT == 5
+    return (uint64_t)vrc_make_lay( sdx >> 3, sdy >> 3 ).c * ( sdz >> 2 );
 #else
     return (uint64_t)vrc_make_lay( sdx >> 3, sdy >> 3 ).c * sdz;
 #endif
@@ -736,6 +748,79 @@ VRC_HD bool vrc_march_segment_as( const vrc_frame& f, const vrc_dev_node& n, vrc
      * GROUP steps remain (the sequentially rounded travel differs from the exact one by
      * far less than one step) */
     const float guard = stepSize * (float)( GROUP + 1 );
+#if defined( VRC_PIPELINE ) && defined( __HIP_DEVICE_COMPILE__ )
+    /* Two groups in flight: the gathers of the NEXT group are issued before the table reads and blends of the
+     * current one.  Every wave's life is a chain of groups, each as long as its slowest gather (with every voxel
+     * line touched once per frame, some lane of every group goes all the way to HBM); with the next group's
+     * gathers already on their way that wait overlaps the current group's work instead of following it.  Same
+     * samples in the same order: only when the loads are issued changes. */
+    if( travel > guard )
+    {
+        uint32_t idx[GROUP], d[GROUP];
+        if( FIXED )
+            vrc_group_indices_fixed< GROUP >( sm, fp, idx );
+        else
+            vrc_group_indices< CLAMP, GROUP >( sm, pos, s.step, idx );
+#pragma unroll
+        for( int k = 0; k < GROUP; ++k )
+            d[k] = (uint32_t)atlas[idx[k]];
+        for( ;; )
+        {
+#pragma unroll
+            for( int k = 0; k < GROUP; ++k )
+                travel -= stepSize; /* same sequential subtraction as the reference */
+            const bool next = travel > guard; /* another whole group follows: fetch it now */
+            uint32_t dn[GROUP];
+#pragma unroll
+            for( int k = 0; k < GROUP; ++k )
+                dn[k] = 0u;
+            if( next )
+            {
+                if( FIXED )
+                    vrc_group_indices_fixed< GROUP >( sm, fp, idx );
+                else
+                    vrc_group_indices< CLAMP, GROUP >( sm, pos, s.step, idx );
+#pragma unroll
+                for( int k = 0; k < GROUP; ++k )
+                    dn[k] = (uint32_t)atlas[idx[k]];
+            }
+            E e[GROUP];
+#pragma unroll
+            for( int k = 0; k < GROUP; ++k )
+                e[k] = lut[d[k]];
+            const E saved = color;
+#pragma unroll
+            for( int k = 0; k < GROUP; ++k )
+                vrc_composite( color, e[k] );
+            if( COUNT )
+                nSamples += GROUP;
+            if( color.w > VRC_EARLY_EXIT )
+            {
+                /* crossed inside this group: replay it with the reference's per-sample exit */
+                color = saved;
+                if( COUNT )
+                    nSamples -= GROUP;
+#pragma unroll
+                for( int k = 0; k < GROUP; ++k )
+                {
+                    vrc_composite( color, e[k], done );
+                    if( COUNT )
+                        nSamples += done ? 0u : 1u;
+                    done = done || ( color.w > VRC_EARLY_EXIT );
+                }
+                return true;
+            }
+            if( !next )
+                break;
+#pragma unroll
+            for( int k = 0; k < GROUP; ++k )
+                d[k] = dn[k];
+        }
+    }
+#endif
+#if defined( VRC_ZRUN )
+    uint32_t zrunTag = 0xFFFFFFFFu, zrunWord = 0u;
+#endif
     while( travel > guard )
     {
         uint32_t idx[GROUP];
@@ -747,6 +832,35 @@ VRC_HD bool vrc_march_segment_as( const vrc_frame& f, const vrc_dev_node& n, vrc
         for( int k = 0; k < GROUP; ++k )
             travel -= stepSize; /* same sequential subtraction as the reference */
         E e[GROUP];
+#if defined( VRC_ZRUN ) && defined( __HIP_DEVICE_COMPILE__ ) && VRC_LAYOUT == 5
+        /* developer experiment (tools/dev_layouts.sh): a lane keeps the dword of its voxel
+         * column (four voxels along z) and loads a new one only when its dword address changes; the other lanes'
+         * loads are out of range of the buffer descriptor and touch nothing */
+        if( sizeof( ATLAS_T ) == 1 )
+        {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast< ATLAS_T* >( atlas ), (short)0, (int)0xFFFFFFFEu, 0x00020000 );
+            uint32_t w[GROUP];
+            uint32_t tag = zrunTag;
+#pragma unroll
+            for( int k = 0; k < GROUP; ++k )
+            {
+                const uint32_t t = idx[k] >> 2;
+                const bool need = t != tag;
+                tag = t;
+                w[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32( rsrc, need ? (int32_t)( idx[k] & ~3u ) : -1, 0, 0 );
+                idx[k] = ( idx[k] & 3u ) | ( need ? 4u : 0u );
+            }
+            zrunTag = tag;
+#pragma unroll
+            for( int k = 0; k < GROUP; ++k )
+            {
+                zrunWord = ( idx[k] & 4u ) ? w[k] : zrunWord;
+                e[k] = lut[( zrunWord >> ( ( idx[k] & 3u ) * 8u ) ) & 0xFFu];
+            }
+        }
+        else
+#endif
 #pragma unroll
         for( int k = 0; k < GROUP; ++k )
         {

@@ -230,7 +230,8 @@ hipError_t vrc_launch_repack_brick( const void* src, void* slot, uint32_t elemBy
             return hipErrorInvalidValue;
         return hipGetLastError();
     }
-    if( elemBytes == 1 && ( size[0] % 8u ) == 0 && ( ( (uintptr_t)src ) % 8u ) == 0 &&
+    /* (the experimental layout 5 has no 8-voxel runs along x: generic kernel) */
+    if( VRC_LAYOUT != 5 && elemBytes == 1 && ( size[0] % 8u ) == 0 && ( ( (uintptr_t)src ) % 8u ) == 0 &&
         ( ( (uintptr_t)slot ) % 8u ) == 0 && total / 8 < 0xFFFFFFFFull )
     {
         const uint32_t sx8 = size[0] / 8u;
@@ -533,7 +534,11 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
     /* The grey form needs 80 registers: a sixth wave per SIMD would fit, and six thrash the L1 (DESIGN.md section 4;
      * frames in flight: 2180 -> 1730 frames/s).  20 KiB of LDS the kernel never touches keep it at five workgroups
      * per CU (160 KiB / (7 + 20) KiB), the occupancy the four-float form has by its registers. */
-    const uint32_t ldsPad = ( MODE == VRC_MODE_GREY && GROUP <= VRC_GREY_GROUP && VRC_WAVES_PER_WG == 4u ) ? 20u * 1024u : 0u;
+#ifndef VRC_GREY_PAD_KB
+#define VRC_GREY_PAD_KB 20u
+#endif
+    const uint32_t ldsPad =
+        ( MODE == VRC_MODE_GREY && GROUP <= VRC_GREY_GROUP && VRC_WAVES_PER_WG == 4u ) ? VRC_GREY_PAD_KB * 1024u : 0u;
     hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG > ),
                         dim3( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_WAVES_PER_WG - 1u ) / VRC_WAVES_PER_WG ),
                         dim3( VRC_WG_THREADS ), ldsPad, stream, a.frame, a.nodes, a.gridTable,
