@@ -130,10 +130,21 @@ def self_launch(a):
     return rc
 
 
+def _json_channel():
+    """The contract is ONE JSON line on stdout.  Libraries print there too (gloo's "[Gloo] Rank 0 is connected to 1
+    peer ranks", RCCL's version banner on the first communicator -- from C++, past sys.stdout): keep a private
+    duplicate of the real stdout for the line and point file descriptor 1 at stderr for everybody else."""
+    sys.stdout.flush()
+    out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return out
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(self_launch(a))
+    json_out = _json_channel()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -163,7 +174,7 @@ def main():
         else:
             ok = True
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ok": ok}), flush=True)
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ok": ok}), file=json_out, flush=True)
         sys.exit(0 if ok else 1)
 
     from libre_amd import driver, sortfirst, vrc
@@ -690,7 +701,7 @@ def main():
                 sys.stderr.write("bench.py: cpu_baseline failed: %r\n" % (e,))
                 out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
 
     app.close()
     if world > 1:
