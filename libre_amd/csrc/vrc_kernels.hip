@@ -901,8 +901,14 @@ hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
     case 5: return launch_variant< true, false, true, false, VRC_MODE_TABLE, uint8_t >( a, stream );
     case 6: return launch_variant< true, true, false, false, VRC_MODE_TABLE, uint8_t >( a, stream );
     case 7: return launch_variant< true, true, true, false, VRC_MODE_TABLE, uint8_t >( a, stream );
-    case 8: return launch_variant< false, false, false, true, VRC_MODE_TABLE, uint8_t >( a, stream );
-    case 9: return launch_variant< false, false, true, true, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 8:
+        if( a.greyTable )
+            return launch_variant< false, false, false, true, VRC_MODE_GREY, uint8_t, VRC_GREY_GROUP >( a, stream );
+        return launch_variant< false, false, false, true, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 9:
+        if( a.greyTable )
+            return launch_variant< false, false, true, true, VRC_MODE_GREY, uint8_t, VRC_GREY_GROUP >( a, stream );
+        return launch_variant< false, false, true, true, VRC_MODE_TABLE, uint8_t >( a, stream );
     case 12:
         if( a.greyTable )
             return smallLaunch ? launch_variant< true, false, false, true, VRC_MODE_GREY, uint8_t, 16 >( a, stream )

@@ -1063,6 +1063,12 @@ def test_grey_table_form_is_bit_identical(vrc):
             assert (grey[..., 0] == grey[..., 1]).all() and (grey[..., 0] == grey[..., 2]).all()
             grey2, n_grey2, _ = g.render(passes=[(0, h), (h, s.n_nodes)])
             assert (grey2 == four2).all() and n_grey2 == n_four2
+            # the reference-order kernel has the grey form too
+            ref_grey, n_ref_grey, st = g.render(kernel=vrc.KERNEL_REFERENCE_ORDER)
+            assert st.kernel_variant == vrc.KERNEL_REFERENCE_ORDER
+            vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 0))
+            ref_four, n_ref_four, _ = g.render(kernel=vrc.KERNEL_REFERENCE_ORDER)
+            assert (ref_grey == ref_four).all() and n_ref_grey == n_ref_four
     # a coloured transfer function: the option changes nothing, the frame is the oracle's
     s = scenes.get("hash64_spin")
     i = np.arange(256, dtype=np.float32) / np.float32(255.0)
