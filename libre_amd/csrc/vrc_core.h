@@ -1204,12 +1204,85 @@ VRC_HD bool vrc_march_brick( const vrc_frame& f, const vrc_dev_node& n, const vr
                                                                    levelStep );
 }
 
+/* ---- tile culling for the reference-order loop -------------------------------------------------------------
+ * The reference tests every brick of the list against every ray (Renderer.cu:172-181).  A wave is an 8x8 pixel
+ * tile: the bricks none of its rays can hit are found once per wave -- 64 bricks per step against the pyramid
+ * through the tile's corner pixels (one pixel of margin) -- and the lanes then run the reference's loop over the
+ * remaining bricks, in the list's order, with the reference's own slab test per ray.  A brick that is not hit is a
+ * `continue` in the reference (the hit test comes before the `break` test, :181-186), so leaving it out changes
+ * nothing: same bricks marched, same order, same samples. */
+struct vrc_tile_pyramid
+{
+    vrc_f3 eye;
+    vrc_f3 n[4]; /* inward normals of the four side planes through the eye */
+};
+VRC_HD vrc_f3 vrc_pixel_direction( const vrc_frame& f, float wx, float wy )
+{
+    const float nx = 2.0f * ( wx + f.pixelOffX - f.vpX - ( f.vpW / 2.0f ) ) / f.vpW;
+    const float ny = 2.0f * ( wy + f.pixelOffY - f.vpY - ( f.vpH / 2.0f ) ) / f.vpH;
+    const vrc_f4 ndc = { nx, ny, 1.0f, 1.0f };
+    const vrc_f4 e = vrc_mul44( f.invProj, ndc );
+    const vrc_f4 eyeSpace = { e.x / e.w, e.y / e.w, e.z / e.w, 1.0f };
+    const vrc_f4 world = vrc_mul44( f.invView, eyeSpace );
+    const vrc_f3 d = { world.x - f.eye[0], world.y - f.eye[1], world.z - f.eye[2] };
+    return d;
+}
+VRC_HD vrc_f3 vrc_cross( vrc_f3 a, vrc_f3 b )
+{
+    const vrc_f3 c = { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
+    return c;
+}
+/* pixels [x0, x1] x [y0, y1] (window coordinates of pixel corners, frame rows) */
+VRC_HD vrc_tile_pyramid vrc_make_tile_pyramid( const vrc_frame& f, float x0, float y0, float x1, float y1 )
+{
+    vrc_tile_pyramid p;
+    p.eye.x = f.eye[0];
+    p.eye.y = f.eye[1];
+    p.eye.z = f.eye[2];
+    const vrc_f3 d[4] = { vrc_pixel_direction( f, x0, y0 ), vrc_pixel_direction( f, x1, y0 ),
+                          vrc_pixel_direction( f, x1, y1 ), vrc_pixel_direction( f, x0, y1 ) };
+    for( int k = 0; k < 4; ++k )
+    {
+        vrc_f3 n = vrc_cross( d[k], d[( k + 1 ) & 3] );
+        if( vrc_dot( n, d[( k + 2 ) & 3] ) < 0.0f ) /* whichever way the projection winds the corners */
+        {
+            n.x = -n.x;
+            n.y = -n.y;
+            n.z = -n.z;
+        }
+        p.n[k] = n;
+    }
+    return p;
+}
+/* false: the box lies entirely outside one side plane, no ray of the tile can hit it */
+VRC_HD bool vrc_pyramid_may_hit( const vrc_tile_pyramid& p, const float bmin[3], const float bsize[3] )
+{
+    const float lo[3] = { bmin[0] - p.eye.x, bmin[1] - p.eye.y, bmin[2] - p.eye.z };
+    const float hi[3] = { lo[0] + bsize[0], lo[1] + bsize[1], lo[2] + bsize[2] };
+    for( int k = 0; k < 4; ++k )
+    {
+        const float nn[3] = { p.n[k].x, p.n[k].y, p.n[k].z };
+        float s = 0.0f, mag = 0.0f;
+        for( int a = 0; a < 3; ++a )
+        {
+            const float u = nn[a] * lo[a], v = nn[a] * hi[a];
+            s += u > v ? u : v;
+            mag += ( u < 0.f ? -u : u ) + ( v < 0.f ? -v : v );
+        }
+        if( s < -1e-5f * mag ) /* the vertex furthest inside is outside, by more than rounding */
+            return false;
+    }
+    return true;
+}
+#define VRC_TILE_CANDIDATES 1024u /* per wave; a tile that could hit more runs the plain loop */
+
 template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP, bool BIG = false >
 VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
                                        const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
                                        const vrc_classifier& cls,
                                        vrc_f4* __restrict__ pixelBuffer, uint32_t px, uint32_t py,
-                                       uint32_t& nSamples )
+                                       uint32_t& nSamples, const uint16_t* candidates = nullptr,
+                                       uint32_t nCandidates = 0 )
 {
     const vrc_ray r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
     const uint32_t pixelPos = py * f.width + px;
@@ -1223,8 +1296,11 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
     vrc_f4 color = f.clearFirst ? zero : pixelBuffer[pixelPos];
     if( color.w > VRC_EARLY_EXIT ) /* Renderer.cu:152-155 */
         return;
-    for( uint32_t i = 0; i < f.nodeCount; ++i )
+    /* candidates: the bricks of the list a ray of this wave's tile can hit, in list order (tile culling, above) */
+    const uint32_t nLoop = candidates ? nCandidates : f.nodeCount;
+    for( uint32_t c = 0; c < nLoop; ++c )
     {
+        const uint32_t i = candidates ? (uint32_t)candidates[c] : c;
         const vrc_dev_node n = nodes[i];
         vrc_segment s;
         bool stop;

@@ -434,6 +434,7 @@ __global__ __launch_bounds__( VRC_WG_THREADS, GROUP > VRC_GREY_GROUP ? 2
     /* classified table (257 entries) or, for the per-sample classification modes, the padded
      * transfer function (258) */
     __shared__ vrc_f4 lut[VRC_TFP_ENTRIES];
+    __shared__ uint16_t vrc_tile_cand[DDA ? 1u : VRC_WAVES_PER_WG * VRC_TILE_CANDIDATES];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     if( MODE == VRC_MODE_GREY )
@@ -501,6 +502,45 @@ __global__ __launch_bounds__( VRC_WG_THREADS, GROUP > VRC_GREY_GROUP ? 2
     const uint32_t py = ty * VRC_TILE_H + ly;
 
     uint32_t nSamples = 0;
+    /* reference-order loop: the bricks this tile's rays can hit at all, found once per wave (vrc_core.h, "tile
+     * culling"): 64 bricks per step against the pyramid through the tile's corners */
+    const uint16_t* cand = nullptr;
+    uint32_t nCand = 0;
+    if( !DDA && f.nodeCount > 8u && f.nodeCount <= 65535u )
+    {
+        uint16_t* const mine = vrc_tile_cand + ( tid >> 6 ) * VRC_TILE_CANDIDATES;
+        /* frame rows of the tile (row bands: local rows map to frame rows, not always consecutive ones) */
+        float r0 = 1e30f, r1 = -1e30f;
+        for( uint32_t j = 0; j < VRC_TILE_H; ++j )
+        {
+            const uint32_t ly = ty * VRC_TILE_H + j;
+            if( ly < f.height )
+            {
+                const float fr = (float)( f.rowMap ? f.rowMap[ly] : ly );
+                r0 = fminf( r0, fr );
+                r1 = fmaxf( r1, fr );
+            }
+        }
+        const vrc_tile_pyramid pyr = vrc_make_tile_pyramid( f, (float)( tx * VRC_TILE_W ) - 1.0f, r0 - 1.0f,
+                                                           (float)( tx * VRC_TILE_W + VRC_TILE_W ), r1 + 1.0f );
+        for( uint32_t base = 0; base < f.nodeCount; base += 64u )
+        {
+            const uint32_t i = base + lane;
+            bool in = false;
+            if( i < f.nodeCount )
+                in = vrc_pyramid_may_hit( pyr, nodes[i].aabbMin, nodes[i].aabbSize );
+            const uint64_t m = __builtin_amdgcn_ballot_w64( in );
+            const uint32_t at = nCand + __builtin_amdgcn_mbcnt_hi( (uint32_t)( m >> 32 ),
+                                                                   __builtin_amdgcn_mbcnt_lo( (uint32_t)m, 0u ) );
+            if( in && at < VRC_TILE_CANDIDATES )
+                mine[at] = (uint16_t)i;
+            nCand += (uint32_t)__builtin_popcountll( m );
+        }
+        __builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+        __builtin_amdgcn_wave_barrier();
+        if( nCand <= VRC_TILE_CANDIDATES )
+            cand = mine;
+    }
     if( px < f.width && py < f.height )
     {
         if( DDA )
@@ -508,7 +548,7 @@ __global__ __launch_bounds__( VRC_WG_THREADS, GROUP > VRC_GREY_GROUP ? 2
                 f, nodes, gridTable, atlas, lut, cls, pixelBuffer, px, py, nSamples );
         else
             vrc_pixel_reference_order< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >(
-                f, nodes, atlas, lut, cls, pixelBuffer, px, py, nSamples );
+                f, nodes, atlas, lut, cls, pixelBuffer, px, py, nSamples, cand, nCand );
     }
     if( COUNT )
     {
