@@ -804,3 +804,36 @@ def test_abi_gather_with_several_ranks_on_one_gpu(drv, world, bands, batch):
     r = subprocess.run([sys.executable, script, str(world), str(bands), str(batch)], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "ok:" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_reference_order_tile_culling_with_row_bands_and_mixed_levels(drv):
+    # the reference-order kernel first culls the brick list per 8x8 tile (vrc_core.h, "tile culling").  Row bands
+    # whose heights are not multiples of 8 put rows of two bands -- frame rows far apart -- into one tile: the tile's
+    # pyramid must span them.  Mixed brick sizes (an LOD cut) make AUTO take that kernel; the stacked bands equal
+    # the rows of the full frame bit for bit, and the full frame matches the oracle
+    from libre_amd import vrc
+    W, H = 56, 72
+    kw = dict(synchronous=True, sse=2.0, gpu_cache_mb=16)
+    eye, spin = (0.15, -0.1, 0.9), (0.7, -0.4)
+    with drv.App("hash://#128,128,128,16", W, H, **kw) as app:
+        app.set_camera(position=eye, spin=spin)
+        app.set_colormap(orc.linear_ramp_tf(0.3))
+        ids = app.visible_set()
+        assert len({i & 0xF for i in ids}) > 1 and len(ids) > 64  # several levels, more bricks than one culling step
+        auto, _ = app.render_frame()  # AUTO: the reference-order kernel for a list of mixed brick sizes
+        app.set_option(vrc.OPT_KERNEL, vrc.KERNEL_REFERENCE_ORDER)
+        full, st = app.render_frame()
+        assert (auto == full).all()
+        s = orc.build_scene(voxels=(128, 128, 128), block=16, viewport=(W, H), ids=ids, spin=spin, eye=eye,
+                            volume="hash", alpha=0.3, order=app.node_order())
+        want, _ = orc.oracle_render(s, threads=8)
+        scenes.assert_parity(full, want, "LOD cut, reference order with tile culling")
+        bands = [(3, 5), (50, 13), (21, 7), (64, 8)]
+        app.set_bands(bands)
+        fb, _ = app.render_frame()
+        stacked = np.concatenate([full[y0:y0 + h] for (y0, h) in bands], axis=0)
+        assert fb.shape == stacked.shape and (fb == stacked).all()
+        app.set_bands([])
+        app.height = H
+        again, _ = app.render_frame()
+        assert (again == full).all()
