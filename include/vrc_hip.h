@@ -148,7 +148,7 @@ typedef struct
                                       * VRC_REFERENCE_ORDER_MAX_NODES bricks -- the reference composites in the host's
                                       * centre-distance order, which is not a visibility order for every ray once
                                       * brick sizes differ (cuda/Renderer.cu:172-199) -- above that GRID_DDA */
-#define VRC_REFERENCE_ORDER_MAX_NODES 1024
+#define VRC_REFERENCE_ORDER_MAX_NODES 4096
 #define VRC_KERNEL_REFERENCE_ORDER 1 /* O(nodes) loop per ray in host order, cuda/Renderer.cu:172-227 */
 #define VRC_KERNEL_GRID_DDA 2        /* 3-D DDA over the brick grid; needs a grid-aligned node set */
 #define VRC_KERNEL_LDS 3             /* grid DDA + voxels staged through LDS per wave and round (needs
