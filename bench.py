@@ -533,10 +533,24 @@ def main():
                          "note": "three renderers on three streams over one atlas; kernels of consecutive "
                                  "frames overlap"}
 
+            # read-back leg: six frames in flight (measured, tools/dev_readback.py: the 16 MiB copy behind each
+            # kernel hides completely from four to six on: 1 / 2 / 3 / 4 / 6 in flight = 1231 / 1340 / 1623 / 2108 / 2154
+            # frames/s)
+            KR = 6
+            while len(r_streams) < KR:
+                r_streams.append(torch.cuda.Stream())
+                r_fbs.append(torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda"))
+                r_host.append(torch.zeros((rows, W, 4), dtype=torch.float32).pin_memory())
+            torch.cuda.synchronize()
+            app.set_frames_in_flight(KR)
+            for k in range(KR):
+                app.select_slot(k)
+                app.set_stream(r_streams[k].cuda_stream)
+                app.set_framebuffer(r_fbs[k].data_ptr())
             for i in range(2 * KR):
                 rb_frame(i)
             torch.cuda.synchronize()
-            n_rb = 100
+            n_rb = 240
             t0 = time.perf_counter()
             for i in range(n_rb):
                 rb_frame(i)
@@ -545,7 +559,7 @@ def main():
             readback = {"frames_per_s": n_rb / dt_rb, "frames": n_rb, "frames_in_flight": KR,
                         "bytes_per_frame": rows * W * 16,
                         "d2h_GBps": n_rb * rows * W * 16 / dt_rb / 1e9,
-                        "note": "kernel + RGBA32F frame copied to pinned host memory, 3 frames in flight"}
+                        "note": "kernel + RGBA32F frame copied to pinned host memory, 6 frames in flight"}
             ok = bool(torch.isfinite(r_host[0]).all()) and float(r_host[0][..., 3].max()) > 0.0
             readback["frame_ok"] = ok
         return (pipelined, readback)
