@@ -315,8 +315,6 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
                     {
                         const uint32_t slot = (uint32_t)__builtin_ctz( walk );
                         walk &= walk - 1u;
-                        const uint32_t tied = ( walk >> 16 ) & 7u;
-                        (void)tied;
                         const uint32_t sub = slot < 7u ? ( 0x4216537u >> ( slot * 4u ) ) & 7u
                                                        : ( 0x653421u >> ( ( slot - 8u ) * 4u ) ) & 7u;
                         const int sgn = slot < 7u ? -1 : 1;
