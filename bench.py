@@ -697,7 +697,7 @@ def main():
                                     # MODE 3 = VRC_MODE_GREY, bit-identical frames (VRC_OPT_GREY_TABLE)
                                     ("vrc_k_raycast<true,false,false,true,0,unsigned char,8,false>"
                                      if os.environ.get("VRC_GREY_TABLE", "1")[:1] == "0" else
-                                     "vrc_k_raycast<true,false,false,true,3,unsigned char,12,false>")),
+                                     "vrc_k_raycast<true,false,false,true,3,unsigned char,14,false>")),
                          "kernel_ms_per_frame": kernel_ms_per_frame,
                          "algorithmic_bytes_per_launch": per_rank_alg,
                          "algorithmic_bytes_per_frame_all_ranks": alg_bytes,

@@ -662,6 +662,12 @@ VRC_HD void vrc_group_indices_fixed( const vrc_sampler& s, vrc_fixpos& p, uint32
         p.x += p.dx;
         p.y += p.dy;
         p.z += p.dz;
+#if !defined( VRC_NO_SERIAL_STEPS )
+        /* keep the three additions per step: left alone, hipcc rewrites the chain as p + k * d with a
+         * v_mul_lo_u32 or a shift-add per step and axis (the slow integer classes, profiles/r1_ubench_valu_issue_costs.txt)
+         * to shorten a dependency that the other waves hide anyway */
+        asm( "" : "+v"( p.x ), "+v"( p.y ), "+v"( p.z ) );
+#endif
     }
 #pragma unroll
     for( int k = 0; k < N; ++k )

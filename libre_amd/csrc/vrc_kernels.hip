@@ -404,10 +404,10 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t*
  * the raycast kernel
  * ---------------------------------------------------------------------------------------- */
 #ifndef VRC_GREY_GROUP
-/* samples a lane of the grey form keeps in flight: its two-float colours and table entries leave registers for 12 at
- * five waves per SIMD (95 VGPRs); measured on C2 against 8: 0.509 -> 0.492 ms (mem://), 0.512 -> 0.493 ms (noise);
- * 14 and 16 need 127 registers (four waves) */
-#define VRC_GREY_GROUP 12
+/* samples a lane of the grey form keeps in flight: its two-float colours and table entries leave registers for 14 at
+ * five waves per SIMD (93 VGPRs with the sample counter, 82 without); measured on C2 against 8: 0.509 -> 0.481 ms
+ * (mem://), 0.512 -> 0.482 ms (noise); 12: 0.491 / 0.484; 16 (96 VGPRs): 0.487 */
+#define VRC_GREY_GROUP 14
 #endif
 #ifndef VRC_MIN_WAVES
 #define VRC_MIN_WAVES 5 /* measured on C2: 4 -> 5 waves per SIMD with four-wave workgroups: -2 % */
