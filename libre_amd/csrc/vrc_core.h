@@ -911,6 +911,8 @@ VRC_HD bool vrc_march_segment_as( const vrc_frame& f, const vrc_dev_node& n, vrc
     /* measured on C2 (groups of 8): tail groups of 8 / 4 / 2 / 1: 0.500 / 0.491 / 0.484 / 0.502 ms relative:
      * fewer gather slots spent on steps no lane takes, until the dependent round trips of a short group
      * cost more than the slots did */
+    /* (whole groups of GROUP / 2 between the full groups and this tail were tried for GROUP = 14: the second unrolled
+     * body costs the registers of a fifth wave -- spills, 0.488 -> 0.539 ms) */
     constexpr int TAILG = GROUP >= 8 ? GROUP / 4 : ( GROUP >= 2 ? GROUP / 2 : 1 );
 #endif
     while( travel > 0.0f && !done )
