@@ -702,8 +702,8 @@ def main():
                          "algorithmic_bytes_per_launch": per_rank_alg,
                          "algorithmic_bytes_per_frame_all_ranks": alg_bytes,
                          "launches_per_frame": 1,
-                         "note": "not HBM-bound: the kernel sits on a plateau of vector issue (18.9 instructions per "
-                                 "64-sample step = 71 % of the issue slots) and gather latency that five waves per "
+                         "note": "not HBM-bound: the kernel sits on a plateau of vector issue (16.3 instructions per "
+                                 "64-sample step = 61 % of the issue slots) and gather latency that five waves per "
                                  "SIMD do not cover; L1 look-ups, loads in flight and occupancy were each changed by "
                                  "20-40 % without moving the time (DESIGN.md section 4); traffic = FETCH_SIZE + WRITE_SIZE bytes per "
                                  "launch from profiles/r2_traffic_c2.json"},
