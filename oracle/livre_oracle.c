@@ -720,7 +720,8 @@ static float sliver_budget( const job_t* j, const orc_node_data* nodeData, f3 or
         ( ( pos.x - nodeData->aabbMin[0] ) / nodeData->aabbSize[0] ) * nodeData->textureSize[0] + nodeData->textureMin[0],
         ( ( pos.y - nodeData->aabbMin[1] ) / nodeData->aabbSize[1] ) * nodeData->textureSize[1] + nodeData->textureMin[1],
         ( ( pos.z - nodeData->aabbMin[2] ) / nodeData->aabbSize[2] ) * nodeData->textureSize[2] + nodeData->textureMin[2] };
-    const float density = fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
+    const float density = j->opt.filter ? fetch_trilinear( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos )
+                                        : fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
     float tfn[4], here[4] = { 0, 0, 0, 0 };
     orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, tfn );
     orc_composite( tfn, here, alphaCorrection );
@@ -734,7 +735,8 @@ static float sliver_budget( const job_t* j, const orc_node_data* nodeData, f3 or
 static float sample_weight( const job_t* j, f3 texPos, float multiplyer, float addedValue, float alphaCorrection,
                             float transmittance )
 {
-    const float density = fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
+    const float density = j->opt.filter ? fetch_trilinear( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos )
+                                        : fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
     float tfn[4], here[4] = { 0, 0, 0, 0 };
     orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, tfn );
     orc_composite( tfn, here, alphaCorrection );
@@ -822,7 +824,7 @@ static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
 
         float tNear = 0.0f, tFar = 0.0f;
         const int hitBox = intersect_box( origin, dir, boxMin, boxMax, &tNear, &tFar );
-        if( j->opt.tieBudget && !j->opt.filter && !shadowMode && tFar >= tNearGlobal && tNear <= tFarGlobal &&
+        if( j->opt.tieBudget && !shadowMode && tFar >= tNearGlobal && tNear <= tFarGlobal &&
             tFar >= tNearPlane ) /* test instrument, see orc_options */
             j->opt.tieBudget[pixelPos] += sliver_budget( j, nodeData, origin, dir, tNear, tFar, multiplyer,
                                                          addedValue, alphaCorrection, 1.0f - color[3] );
@@ -867,10 +869,11 @@ static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
                                       ? fetch_trilinear( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos )
                                       : fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
             float transferFn[4];
-            if( j->opt.tieBudget && !j->opt.filter && !shadowMode ) /* test instrument, see orc_options */
+            if( j->opt.tieBudget && !shadowMode ) /* test instrument, see orc_options */
             {
-                j->opt.tieBudget[pixelPos] += tie_budget( j, texPos, density, multiplyer, addedValue,
-                                                          alphaCorrection, 1.0f - color[3], kStep, vpw );
+                if( !j->opt.filter ) /* a voxel flip is a point-sampling matter; whether a sample exists is not */
+                    j->opt.tieBudget[pixelPos] += tie_budget( j, texPos, density, multiplyer, addedValue,
+                                                              alphaCorrection, 1.0f - color[3], kStep, vpw );
                 if( travel <= endEps && kStep > 0 ) /* the sample at the far face barely made it */
                     j->opt.tieBudget[pixelPos] += sample_weight( j, texPos, multiplyer, addedValue, alphaCorrection,
                                                                  1.0f - color[3] );
@@ -913,7 +916,7 @@ static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
             break;
         if( isEarlyExit && !shadowMode )
             break;
-        if( j->opt.tieBudget && !j->opt.filter && !shadowMode && travel > -endEps && kStep > 0 ) /* ... or barely did not */
+        if( j->opt.tieBudget && !shadowMode && travel > -endEps && kStep > 0 ) /* ... or barely did not */
         {
             const f3 texPos = { ( ( pos.x - boxMin.x ) / boxSize.x ) * texSize.x + texMin.x,
                                 ( ( pos.y - boxMin.y ) / boxSize.y ) * texSize.y + texMin.y,
@@ -986,9 +989,29 @@ static uint64_t raycast_pixel_gl( const job_t* j, uint32_t x, uint32_t y )
         (float)renderData->maxSamplesPerRay / (float)renderData->samplesPerRay;
     const float stepSize = 1.0f / (float)renderData->samplesPerRay;
 
+    /* test instrument, parts three and four as in raycast_pixel: the last sample of a segment and the early-exit test */
+    float shadow[4] = { 0, 0, 0, 0 }, *acc = color, ertLo = -1.0f, ertEps = 0.0f;
+    int shadowMode = 0;
+
     for( uint32_t i = 0; i < j->nodeCount; ++i )
     {
-        if( color[3] > EARLY_EXIT ) /* :115-117 */
+        if( !shadowMode && color[3] > EARLY_EXIT ) /* :115-117 */
+        {
+            if( j->opt.tieBudget && color[3] <= EARLY_EXIT + 5e-5f + 2.0f * j->opt.tieBudget[pixelPos] )
+            {
+                if( ertLo < 0.0f )
+                {
+                    ertEps = 5e-5f + 2.0f * j->opt.tieBudget[pixelPos];
+                    ertLo = color[3];
+                }
+                shadowMode = 1;
+                shadow[0] = color[0], shadow[1] = color[1], shadow[2] = color[2], shadow[3] = color[3];
+                acc = shadow;
+            }
+            else
+                break;
+        }
+        if( shadowMode && shadow[3] > EARLY_EXIT + ertEps )
             break;
         const orc_node_data* nodeData = &j->nodes[i];
         const f3 boxMin = { nodeData->aabbMin[0], nodeData->aabbMin[1], nodeData->aabbMin[2] };
@@ -1038,7 +1061,10 @@ static uint64_t raycast_pixel_gl( const job_t* j, uint32_t x, uint32_t y )
         uint32_t kStep = 0; /* test instrument only (tie budget) */
         const f3 vpw = { texSize.x * (float)j->atlasDim[0] / boxSize.x, texSize.y * (float)j->atlasDim[1] / boxSize.y,
                          texSize.z * (float)j->atlasDim[2] / boxSize.z };
-        for( float travel = dist; travel > 0.0f;
+        const float endEps = 4e-6f * fmaxf( 1.0f, fabsf( tfar ) );
+        int stopHere = 0;
+        float travel;
+        for( travel = dist; travel > 0.0f;
              pos.x += step.x, pos.y += step.y, pos.z += step.z, travel -= stepSize, ++kStep )
         {
             const f3 texPos = { ( ( pos.x - boxMin.x ) / boxSize.x ) * texSize.x + texMin.x,
@@ -1048,16 +1074,63 @@ static uint64_t raycast_pixel_gl( const job_t* j, uint32_t x, uint32_t y )
                                       ? fetch_trilinear( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos )
                                       : fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
             float transferFn[4];
-            if( j->opt.tieBudget && !j->opt.filter ) /* test instrument, see orc_options */
-                j->opt.tieBudget[pixelPos] += tie_budget( j, texPos, density, multiplyer, addedValue,
-                                                          alphaCorrection, 1.0f - color[3], kStep, vpw );
+            if( j->opt.tieBudget && !shadowMode ) /* test instrument, see orc_options */
+            {
+                if( !j->opt.filter )
+                    j->opt.tieBudget[pixelPos] += tie_budget( j, texPos, density, multiplyer, addedValue,
+                                                              alphaCorrection, 1.0f - color[3], kStep, vpw );
+                if( travel <= endEps && kStep > 0 )
+                    j->opt.tieBudget[pixelPos] += sample_weight( j, texPos, multiplyer, addedValue, alphaCorrection,
+                                                                 1.0f - color[3] );
+            }
             orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, transferFn );
-            orc_composite( transferFn, color, alphaCorrection );
-            ++nSamples;
+            orc_composite( transferFn, acc, alphaCorrection );
+            if( !shadowMode )
+                ++nSamples;
+            if( j->opt.tieBudget )
+            {
+                if( ertLo < 0.0f )
+                {
+                    ertEps = 5e-5f + 2.0f * j->opt.tieBudget[pixelPos];
+                    if( acc[3] > EARLY_EXIT - ertEps )
+                        ertLo = acc[3];
+                }
+                if( shadowMode )
+                {
+                    if( acc[3] > EARLY_EXIT + ertEps )
+                    {
+                        stopHere = 1;
+                        break;
+                    }
+                    continue;
+                }
+                if( color[3] > EARLY_EXIT && color[3] <= EARLY_EXIT + ertEps )
+                {
+                    shadowMode = 1;
+                    shadow[0] = color[0], shadow[1] = color[1], shadow[2] = color[2], shadow[3] = color[3];
+                    acc = shadow;
+                    continue;
+                }
+            }
             if( color[3] > EARLY_EXIT )
+            {
+                stopHere = 1;
                 break;
+            }
+        }
+        if( stopHere )
+            continue; /* the test at the top of the brick loop ends the ray */
+        if( j->opt.tieBudget && !shadowMode && travel > -endEps && kStep > 0 )
+        {
+            const f3 texPos = { ( ( pos.x - boxMin.x ) / boxSize.x ) * texSize.x + texMin.x,
+                                ( ( pos.y - boxMin.y ) / boxSize.y ) * texSize.y + texMin.y,
+                                ( ( pos.z - boxMin.z ) / boxSize.z ) * texSize.z + texMin.z };
+            j->opt.tieBudget[pixelPos] += sample_weight( j, texPos, multiplyer, addedValue, alphaCorrection,
+                                                         1.0f - color[3] );
         }
     }
+    if( j->opt.tieBudget && ertLo >= 0.0f )
+        j->opt.tieBudget[pixelPos] += fmaxf( 0.0f, acc[3] - ertLo );
     px[0] = color[0];
     px[1] = color[1];
     px[2] = color[2];
