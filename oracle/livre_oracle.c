@@ -1297,9 +1297,16 @@ static lod_grid* lod_grid_build( const orc_node_data* nodes, uint32_t n, const u
     return g;
 }
 
-/* integrate one run [tA, tB] of the ray through one brick; returns 1 on early exit */
+/* test instrument (orc_options.tieBudget), part four for the per-ray LOD march: see raycast_pixel */
+typedef struct
+{
+    float shadow[4], lo, eps;
+    int on;
+} ert_probe;
+
+/* integrate one run [tA, tB] of the ray through one brick; returns 1 when the march is over (early exit) */
 static int integrate_run( const job_t* j, const orc_node_data* nodeData, int level, f3 origin, f3 dir,
-                          float tA, float tB, float color[4], uint64_t* nSamples, size_t pixelPos )
+                          float tA, float tB, float color[4], uint64_t* nSamples, size_t pixelPos, ert_probe* ep )
 {
     const orc_render_data* renderData = j->render;
     const float r0 = renderData->dataSourceRange[0], r1 = renderData->dataSourceRange[1];
@@ -1337,12 +1344,35 @@ static int integrate_run( const job_t* j, const orc_node_data* nodeData, int lev
                                   ? fetch_trilinear( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos )
                                   : fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
         float transferFn[4];
-        if( j->opt.tieBudget && !j->opt.filter ) /* test instrument, see orc_options */
+        float* const acc = ep->on ? ep->shadow : color;
+        if( j->opt.tieBudget && !j->opt.filter && !ep->on ) /* test instrument, see orc_options */
             j->opt.tieBudget[pixelPos] += tie_budget( j, texPos, density, multiplyer, addedValue,
                                                       alphaCorrection, 1.0f - color[3], kStep, vpw );
         orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, transferFn );
-        orc_composite( transferFn, color, alphaCorrection );
-        ++*nSamples;
+        orc_composite( transferFn, acc, alphaCorrection );
+        if( !ep->on )
+            ++*nSamples;
+        if( j->opt.tieBudget )
+        {
+            if( ep->lo < 0.0f )
+            {
+                ep->eps = 5e-5f + 2.0f * j->opt.tieBudget[pixelPos];
+                if( acc[3] > EARLY_EXIT - ep->eps )
+                    ep->lo = acc[3];
+            }
+            if( ep->on )
+            {
+                if( acc[3] > EARLY_EXIT + ep->eps )
+                    return 1;
+                continue;
+            }
+            if( color[3] > EARLY_EXIT && color[3] <= EARLY_EXIT + ep->eps )
+            {
+                ep->on = 1; /* the march's own exit; an evaluation ep->eps lower goes on: follow it on a copy */
+                ep->shadow[0] = color[0], ep->shadow[1] = color[1], ep->shadow[2] = color[2], ep->shadow[3] = color[3];
+                continue;
+            }
+        }
         if( color[3] > EARLY_EXIT )
             return 1;
     }
@@ -1354,6 +1384,7 @@ static uint64_t raycast_pixel_ray_lod( const job_t* j, uint32_t x, uint32_t y )
     const orc_view_data* viewData = j->view;
     const lod_grid* g = j->lod;
     uint64_t nSamples = 0;
+    ert_probe probe = { { 0, 0, 0, 0 }, -1.0f, 0.0f, 0 }; /* test instrument only */
 
     /* ray, global interval, clip planes, near plane: Renderer.cu:106-160 as in raycast_pixel */
     const f4 pixelEyeSpacePos =
@@ -1457,11 +1488,13 @@ static uint64_t raycast_pixel_ray_lod( const job_t* j, uint32_t x, uint32_t y )
             const float tB = fminf( fmaxf( tX, tp ), t1 ); /* always forward */
             if( node >= 0 &&
                 integrate_run( j, &j->nodes[node], g->level[node], origin, dir, tp, tB, color, &nSamples,
-                               (size_t)y * j->width + x ) )
+                               (size_t)y * j->width + x, &probe ) )
                 break;
             te = tB;
         }
     }
+    if( j->opt.tieBudget && probe.lo >= 0.0f )
+        j->opt.tieBudget[(size_t)y * j->width + x] += fmaxf( 0.0f, ( probe.on ? probe.shadow[3] : color[3] ) - probe.lo );
     px[0] = color[0];
     px[1] = color[1];
     px[2] = color[2];
