@@ -918,6 +918,9 @@ hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
      * measured 0.153 -> 0.130 ms for an eighth of the C2 frame, 0.538 -> 0.562 ms for the whole */
     const uint32_t nTilesLaunch = ( ( a.frame.width + VRC_TILE_W - 1 ) / VRC_TILE_W ) *
                                   ( ( a.frame.height + VRC_TILE_H - 1 ) / VRC_TILE_H );
+#ifndef VRC_SMALL_GROUP
+#define VRC_SMALL_GROUP 24 /* samples in flight per lane in launches too small to fill the GPU (latency-bound: 16 -> 24: -5 % on a rank's share of an 8-rank frame, -4 % of a 4-rank frame; 32: -7 % / -3 %) */
+#endif
 #ifndef VRC_SMALL_LAUNCH_TILES
 #define VRC_SMALL_LAUNCH_TILES 6144u
 #endif
@@ -951,17 +954,17 @@ hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
         return launch_variant< false, false, true, true, VRC_MODE_TABLE, uint8_t >( a, stream );
     case 12:
         if( a.greyTable )
-            return smallLaunch ? launch_variant< true, false, false, true, VRC_MODE_GREY, uint8_t, 16 >( a, stream )
+            return smallLaunch ? launch_variant< true, false, false, true, VRC_MODE_GREY, uint8_t, VRC_SMALL_GROUP >( a, stream )
                                : launch_variant< true, false, false, true, VRC_MODE_GREY, uint8_t, VRC_GREY_GROUP >( a, stream );
         if( smallLaunch )
-            return launch_variant< true, false, false, true, VRC_MODE_TABLE, uint8_t, 16 >( a, stream );
+            return launch_variant< true, false, false, true, VRC_MODE_TABLE, uint8_t, VRC_SMALL_GROUP >( a, stream );
         return launch_variant< true, false, false, true, VRC_MODE_TABLE, uint8_t >( a, stream );
     default:
         if( a.greyTable )
-            return smallLaunch ? launch_variant< true, false, true, true, VRC_MODE_GREY, uint8_t, 16 >( a, stream )
+            return smallLaunch ? launch_variant< true, false, true, true, VRC_MODE_GREY, uint8_t, VRC_SMALL_GROUP >( a, stream )
                                : launch_variant< true, false, true, true, VRC_MODE_GREY, uint8_t, VRC_GREY_GROUP >( a, stream );
         if( smallLaunch )
-            return launch_variant< true, false, true, true, VRC_MODE_TABLE, uint8_t, 16 >( a, stream );
+            return launch_variant< true, false, true, true, VRC_MODE_TABLE, uint8_t, VRC_SMALL_GROUP >( a, stream );
         return launch_variant< true, false, true, true, VRC_MODE_TABLE, uint8_t >( a, stream );
     }
 }
