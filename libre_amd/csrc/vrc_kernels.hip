@@ -922,7 +922,7 @@ hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
 #define VRC_SMALL_GROUP 24 /* samples in flight per lane in launches too small to fill the GPU (latency-bound: 16 -> 24: -5 % on a rank's share of an 8-rank frame, -4 % of a 4-rank frame; 32: -7 % / -3 %) */
 #endif
 #ifndef VRC_SMALL_LAUNCH_TILES
-#define VRC_SMALL_LAUNCH_TILES 6144u
+#define VRC_SMALL_LAUNCH_TILES 6144u /* (8192 = half a 1024^2 frame: one frame alone 0.303 -> 0.287 ms, three in flight 4428 -> 4365 frames/s: not taken) */
 #endif
     const bool smallLaunch = nTilesLaunch <= VRC_SMALL_LAUNCH_TILES;
     if( a.ertParts > 1 && ( key == 12 || key == 13 ) && VRC_TILE_W == 8u )
