@@ -733,10 +733,27 @@ VRC_HD void vrc_composite( vrc_f2& c, const vrc_f2& e, bool frozen = false )
 #define VRC_GROUP 8
 #endif
 
-template < bool CLAMP, bool COUNT, bool FIXED, typename ATLAS_T, int GROUP, typename E >
+struct vrc_classifier;
+VRC_HD vrc_f4 vrc_classify( const vrc_f4* tfp, float d, const vrc_classifier& k );
+VRC_HD vrc_f2 vrc_classify( const vrc_f2* tfp, float d, const vrc_classifier& k );
+
+/* table entry of a fetched voxel: lut[d] -- or, PERSAMPLE (volumes the 257-entry table cannot index: 16-bit
+ * voxels), the transfer function and the opacity correction evaluated on the value (vrc_classify; lut is then the
+ * padded transfer function and the entries are four floats) */
+template < bool PERSAMPLE, typename E >
+VRC_HD E vrc_entry( const E* lut, uint32_t d, const vrc_classifier* cls )
+{
+    if constexpr( PERSAMPLE )
+        return vrc_classify( lut, (float)d, *cls );
+    else
+        return lut[d];
+}
+
+template < bool CLAMP, bool COUNT, bool FIXED, typename ATLAS_T, int GROUP, typename E, bool PERSAMPLE = false >
 VRC_HD bool vrc_march_segment_as( const vrc_frame& f, const vrc_dev_node& n, vrc_segment s,
                                   const ATLAS_T* __restrict__ atlas, const E* lut,
-                                  E& color, uint32_t& nSamples, float levelStep )
+                                  E& color, uint32_t& nSamples, float levelStep,
+                                  const vrc_classifier* cls = nullptr )
 {
     /* levelStep: step of a coarser brick under per-ray LOD (vrc_pixel_ray_lod); 0 = the frame's */
     const float stepSize = levelStep > 0.0f ? levelStep : f.stepSize;
@@ -877,7 +894,7 @@ VRC_HD bool vrc_march_segment_as( const vrc_frame& f, const vrc_dev_node& n, vrc
 #elif defined( VRC_ABLATE_QUARTER_FETCH ) /* timing experiment only */
             e[k] = lut[(uint32_t)atlas[idx[k & ~3]] + ( idx[k] >> 31 )];
 #else
-            e[k] = lut[(uint32_t)atlas[idx[k]]];
+            e[k] = vrc_entry< PERSAMPLE, E >( lut, (uint32_t)atlas[idx[k]], cls );
 #endif
         }
         const E saved = color;
@@ -936,7 +953,16 @@ VRC_HD bool vrc_march_segment_as( const vrc_frame& f, const vrc_dev_node& n, vrc
         E e[TAILG];
 #pragma unroll
         for( int k = 0; k < TAILG; ++k )
-            e[k] = lut[(uint32_t)k < cnt ? d[k] : 256u];
+        {
+            if constexpr( PERSAMPLE )
+            {
+                /* a step the reference does not take blends nothing */
+                const E z = {};
+                e[k] = (uint32_t)k < cnt ? vrc_entry< true, E >( lut, d[k], cls ) : z;
+            }
+            else
+                e[k] = lut[(uint32_t)k < cnt ? d[k] : 256u];
+        }
 #pragma unroll
         for( int k = 0; k < TAILG; ++k )
         {
@@ -1028,6 +1054,33 @@ VRC_HD vrc_f4 vrc_classify( const vrc_f4* tfp, float d, const vrc_classifier& k 
     e.x = ( b * t0.x + a * t1.x ) * alpha;
     e.y = ( b * t0.y + a * t1.y ) * alpha;
     e.z = ( b * t0.z + a * t1.z ) * alpha;
+    e.w = alpha;
+    return e;
+}
+
+/* the same for a grey transfer function kept as (grey, alpha) pairs: the colour channels of vrc_classify are one
+ * expression evaluated three times on equal numbers */
+VRC_HD vrc_f2 vrc_classify( const vrc_f2* tfp, float d, const vrc_classifier& k )
+{
+    VRC_FAST_FP
+    float xB = d * k.mult + k.add;
+    xB = fminf( fmaxf( xB, -1.0f ), 255.99998f );
+    const float fl = floorf( xB );
+    float a = xB - fl;
+    if( k.q > 0.0f )
+        a = floorf( a * k.q + 0.5f ) * k.invq;
+    const int j = (int)fl + 1;
+    const vrc_f2 t0 = tfp[j], t1 = tfp[j + 1];
+    const float b = 1.0f - a;
+    const float cw = b * t0.w + a * t1.w;
+    const float corr = 1.0f - fminf( cw, 1.0f - 1.0f / 256.0f );
+#if defined( __HIP_DEVICE_COMPILE__ )
+    const float alpha = 1.0f - __builtin_amdgcn_exp2f( k.alphaCorrection * __builtin_amdgcn_logf( corr ) );
+#else
+    const float alpha = 1.0f - powf( corr, k.alphaCorrection );
+#endif
+    vrc_f2 e;
+    e.x = ( b * t0.x + a * t1.x ) * alpha;
     e.w = alpha;
     return e;
 }
@@ -1181,6 +1234,7 @@ VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n,
  *   VRC_MODE_POINT      point sample, per-sample classification (16-bit voxels). */
 #define VRC_MODE_GREY 3 /* VRC_MODE_TABLE with a grey transfer function (r == g == b in every entry): two-float table
                          * entries and colours, bit-identical frames, half the table bytes and blend work */
+#define VRC_MODE_POINT_GREY 4 /* VRC_MODE_POINT with a grey transfer function, as VRC_MODE_GREY is to VRC_MODE_TABLE */
 #define VRC_MODE_TABLE 0
 #define VRC_MODE_TRILINEAR 1
 #define VRC_MODE_POINT 2
@@ -1205,6 +1259,22 @@ VRC_HD bool vrc_march_brick( const vrc_frame& f, const vrc_dev_node& n, const vr
     if constexpr( MODE == VRC_MODE_GREY )
         return vrc_march_segment< CLAMP, COUNT, FIXED, ATLAS_T, GROUP, true >( f, n, s, atlas, lut, color, nSamples,
                                                                              levelStep );
+    else if constexpr( MODE == VRC_MODE_POINT_GREY )
+    {
+        /* lut holds the padded transfer function as (grey, alpha) pairs; the pixel came in grey and leaves grey */
+        vrc_f2 c = { color.x, color.w };
+        const bool done = vrc_march_segment_as< CLAMP, COUNT, true, ATLAS_T, GROUP, vrc_f2, true >(
+            f, n, s, atlas, reinterpret_cast< const vrc_f2* >( lut ), c, nSamples, levelStep, &cls );
+        color.x = color.y = color.z = c.x;
+        color.w = c.w;
+        return done;
+    }
+    else if constexpr( MODE == VRC_MODE_POINT && FIXED )
+        /* point sampling with per-sample classification (16-bit voxels) through the grouped march of the table
+         * form: whole groups without per-sample masks, fixed-point stepping, address tables; only the table read
+         * is replaced by vrc_classify */
+        return vrc_march_segment_as< CLAMP, COUNT, true, ATLAS_T, GROUP, vrc_f4, true >( f, n, s, atlas, lut, color,
+                                                                                       nSamples, levelStep, &cls );
     else if( MODE != VRC_MODE_TABLE )
         return vrc_march_segment_linear< CLAMP, COUNT, MODE == VRC_MODE_TRILINEAR, ATLAS_T >(
             f, n, s, atlas, lut, cls, color, nSamples, levelStep );

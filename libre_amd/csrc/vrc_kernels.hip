@@ -437,11 +437,12 @@ __global__ __launch_bounds__( VRC_WG_THREADS, GROUP > VRC_GREY_GROUP ? 2
     __shared__ uint16_t vrc_tile_cand[DDA ? 1u : VRC_WAVES_PER_WG * VRC_TILE_CANDIDATES];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
-    if( MODE == VRC_MODE_GREY )
+    if( MODE == VRC_MODE_GREY || MODE == VRC_MODE_POINT_GREY )
     {
-        /* grey table: (rgb * alpha', alpha') as two floats per entry, 257 entries */
+        /* grey table: (rgb * alpha', alpha') as two floats per entry, 257 entries -- or, for the per-sample
+         * classification of 16-bit voxels, the 258 entries of the padded transfer function as (grey, alpha) */
         vrc_f2* const lut2 = reinterpret_cast< vrc_f2* >( lut );
-        for( uint32_t i = tid; i < VRC_LUT_ENTRIES; i += VRC_WG_THREADS )
+        for( uint32_t i = tid; i < ( MODE == VRC_MODE_GREY ? VRC_LUT_ENTRIES : VRC_TFP_ENTRIES ); i += VRC_WG_THREADS )
         {
             const vrc_f4 e = lutGlobal[i];
             lut2[i] = vrc_f2{ e.x, e.w };
@@ -855,10 +856,28 @@ static hipError_t launch_parts( const vrc_raycast_args& a, hipStream_t stream )
     return hipGetLastError();
 }
 
-/* per-sample classification modes (float stepping): trilinear or point, u8 or u16 voxels */
+/* per-sample classification modes: trilinear or point, u8 or u16 voxels.  Point sampling of 16-bit voxels with
+ * overlap (no clamped sampler) takes the fixed-point grouped march (vrc_march_brick) */
 template < int MODE, typename ATLAS_T >
 static hipError_t launch_classify( const vrc_raycast_args& a, bool count, hipStream_t stream )
 {
+    if constexpr( MODE == VRC_MODE_POINT && sizeof( ATLAS_T ) == 2 )
+        if( a.fixedStepping && !a.clamp )
+        {
+            if( a.greyTable )
+            {
+                if( a.gridDda )
+                    return count ? launch_variant< true, false, true, true, VRC_MODE_POINT_GREY, ATLAS_T >( a, stream )
+                                 : launch_variant< true, false, false, true, VRC_MODE_POINT_GREY, ATLAS_T >( a, stream );
+                return count ? launch_variant< false, false, true, true, VRC_MODE_POINT_GREY, ATLAS_T >( a, stream )
+                             : launch_variant< false, false, false, true, VRC_MODE_POINT_GREY, ATLAS_T >( a, stream );
+            }
+            if( a.gridDda )
+                return count ? launch_variant< true, false, true, true, MODE, ATLAS_T >( a, stream )
+                             : launch_variant< true, false, false, true, MODE, ATLAS_T >( a, stream );
+            return count ? launch_variant< false, false, true, true, MODE, ATLAS_T >( a, stream )
+                         : launch_variant< false, false, false, true, MODE, ATLAS_T >( a, stream );
+        }
     const int key = ( a.gridDda ? 4 : 0 ) | ( a.clamp ? 2 : 0 ) | ( count ? 1 : 0 );
     switch( key )
     {
@@ -873,10 +892,22 @@ static hipError_t launch_classify( const vrc_raycast_args& a, bool count, hipStr
     }
 }
 
-/* atlases of more than 2^32 voxels: 64-bit slot bases (BIG), float stepping, groups of 8 */
+/* atlases of more than 2^32 voxels: 64-bit slot bases (BIG), groups of 8; float stepping except for point sampling of
+ * 16-bit voxels with overlap, which takes the fixed-point grouped march as in launch_classify */
 template < int MODE, typename ATLAS_T >
 static hipError_t launch_big( const vrc_raycast_args& a, bool count, hipStream_t stream )
 {
+    if constexpr( MODE == VRC_MODE_POINT && sizeof( ATLAS_T ) == 2 )
+        if( a.fixedStepping && !a.clamp )
+        {
+#define VRC_BIG_FIXED( M )                                                                                         \
+    ( a.gridDda ? ( count ? launch_variant< true, false, true, true, M, ATLAS_T, VRC_GROUP, true >( a, stream )     \
+                          : launch_variant< true, false, false, true, M, ATLAS_T, VRC_GROUP, true >( a, stream ) )  \
+                : ( count ? launch_variant< false, false, true, true, M, ATLAS_T, VRC_GROUP, true >( a, stream )    \
+                          : launch_variant< false, false, false, true, M, ATLAS_T, VRC_GROUP, true >( a, stream ) ) )
+            return a.greyTable ? VRC_BIG_FIXED( VRC_MODE_POINT_GREY ) : VRC_BIG_FIXED( VRC_MODE_POINT );
+#undef VRC_BIG_FIXED
+        }
     const int key = ( a.gridDda ? 4 : 0 ) | ( a.clamp ? 2 : 0 ) | ( count ? 1 : 0 );
     switch( key )
     {

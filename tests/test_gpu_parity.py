@@ -1081,3 +1081,30 @@ def test_grey_table_form_is_bit_identical(vrc):
         vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 0))
         again, _, _ = g.render()
         assert (again == got).all()
+
+
+def test_uint16_point_sampling_grouped_march_and_its_grey_form(vrc):
+    # 16-bit voxels cannot index the 257-entry classified table: every sample is classified on its own.  With overlap
+    # (no clamped sampler) and fixed-point stepping the march is the table form's (whole groups, address tables) with
+    # the table read replaced by the classification; a grey transfer function takes (grey, alpha) pairs.  The frame
+    # matches the oracle, the grey form equals the four-float form bit for bit, and the float-stepping form (the
+    # general per-sample march) composites the same samples
+    for kw in (dict(voxels=(64, 64, 64), block=16, viewport=(48, 40), volume="hash", spin=(0.5, 0.35), dtype="u16"),
+               dict(voxels=(64, 64, 64), block=16, viewport=(40, 40), volume="hash", spin=(0.3, -0.2), alpha=1.0,
+                    dtype="u16"),
+               dict(voxels=(256, 256, 256), block=128, viewport=(160, 160), volume="hash", spin=(0.5236, 0.349),
+                    alpha=0.3, dtype="u16")):
+        s = orc.build_scene(**kw)
+        want, n_want = orc.oracle_render(s, threads=16)
+        with _gpu(s) as g:
+            for k in (vrc.KERNEL_GRID_DDA, vrc.KERNEL_REFERENCE_ORDER):
+                grey, n_grey, _ = g.render(kernel=k)
+                scenes.assert_parity(grey, want, "u16 %r kernel %d" % (kw, k))
+                assert abs(n_grey - n_want) <= 3e-4 * n_want + 16
+                vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 0))
+                four, n_four, _ = g.render(kernel=k)
+                vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 1))
+                assert (four == grey).all() and n_four == n_grey
+                flt, n_flt, _ = g.render(kernel=k, stepping=0)
+                scenes.assert_parity(flt, want, "u16 %r kernel %d, float stepping" % (kw, k))
+                assert n_flt == n_grey
