@@ -1031,6 +1031,11 @@ VRC_HD vrc_classifier vrc_make_classifier( vrc_lut_params p )
     return k;
 }
 
+#if defined( __HIP_DEVICE_COMPILE__ )
+#define VRC_LERP2( B, X, A, Y ) __builtin_fmaf( ( A ), ( Y ), ( B ) * ( X ) )
+#else
+#define VRC_LERP2( B, X, A, Y ) ( ( B ) * ( X ) + ( A ) * ( Y ) )
+#endif
 VRC_HD vrc_f4 vrc_classify( const vrc_f4* tfp, float d, const vrc_classifier& k )
 {
     VRC_FAST_FP
@@ -1043,7 +1048,10 @@ VRC_HD vrc_f4 vrc_classify( const vrc_f4* tfp, float d, const vrc_classifier& k 
     const int j = (int)fl + 1;
     const vrc_f4 t0 = tfp[j], t1 = tfp[j + 1];
     const float b = 1.0f - a;
-    const float cw = b * t0.w + a * t1.w;
+    /* on the device the interpolation is spelled as one product and one fused multiply-add: which of the two
+     * products hipcc fuses otherwise depends on the code around it, and the grey form (below) has to produce the
+     * same bits as this one */
+    const float cw = VRC_LERP2( b, t0.w, a, t1.w );
     const float corr = 1.0f - fminf( cw, 1.0f - 1.0f / 256.0f );
 #if defined( __HIP_DEVICE_COMPILE__ )
     const float alpha = 1.0f - __builtin_amdgcn_exp2f( k.alphaCorrection * __builtin_amdgcn_logf( corr ) );
@@ -1051,9 +1059,9 @@ VRC_HD vrc_f4 vrc_classify( const vrc_f4* tfp, float d, const vrc_classifier& k 
     const float alpha = 1.0f - powf( corr, k.alphaCorrection );
 #endif
     vrc_f4 e;
-    e.x = ( b * t0.x + a * t1.x ) * alpha;
-    e.y = ( b * t0.y + a * t1.y ) * alpha;
-    e.z = ( b * t0.z + a * t1.z ) * alpha;
+    e.x = VRC_LERP2( b, t0.x, a, t1.x ) * alpha;
+    e.y = VRC_LERP2( b, t0.y, a, t1.y ) * alpha;
+    e.z = VRC_LERP2( b, t0.z, a, t1.z ) * alpha;
     e.w = alpha;
     return e;
 }
@@ -1072,7 +1080,7 @@ VRC_HD vrc_f2 vrc_classify( const vrc_f2* tfp, float d, const vrc_classifier& k 
     const int j = (int)fl + 1;
     const vrc_f2 t0 = tfp[j], t1 = tfp[j + 1];
     const float b = 1.0f - a;
-    const float cw = b * t0.w + a * t1.w;
+    const float cw = VRC_LERP2( b, t0.w, a, t1.w );
     const float corr = 1.0f - fminf( cw, 1.0f - 1.0f / 256.0f );
 #if defined( __HIP_DEVICE_COMPILE__ )
     const float alpha = 1.0f - __builtin_amdgcn_exp2f( k.alphaCorrection * __builtin_amdgcn_logf( corr ) );
@@ -1080,7 +1088,7 @@ VRC_HD vrc_f2 vrc_classify( const vrc_f2* tfp, float d, const vrc_classifier& k 
     const float alpha = 1.0f - powf( corr, k.alphaCorrection );
 #endif
     vrc_f2 e;
-    e.x = ( b * t0.x + a * t1.x ) * alpha;
+    e.x = VRC_LERP2( b, t0.x, a, t1.x ) * alpha;
     e.w = alpha;
     return e;
 }

@@ -139,7 +139,9 @@ struct lds_box
 };
 }
 
-template < bool COUNT, bool LINEAR, typename S >
+/* GREY: the transfer function is grey and the frame starts from zero (vrc_raycast_args.greyTable): colours and table
+ * entries are (grey, alpha) pairs, bit-identical to the four-float form (vrc_core.h, VRC_MODE_GREY) */
+template < bool COUNT, bool LINEAR, typename S, bool GREY = false >
 /* the deep region leaves LDS for three workgroups per CU (3 waves per SIMD), the flat one for four */
 #ifndef VRC_LDS_LINEAR_WAVES
 #define VRC_LDS_LINEAR_WAVES 4 /* measured: 4 waves with 11 spilled dwords (2.52 ms) beat 3 waves without (2.71 ms) */
@@ -151,11 +153,18 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
     vrc_f4* __restrict__ pixelBuffer, unsigned long long* __restrict__ sampleCounter,
     const uint32_t* __restrict__ tileOrder, const uint32_t tilesX, const uint32_t nTiles )
 {
-    __shared__ vrc_f4 lut[VRC_TFP_ENTRIES];
+    using C = std::conditional_t< GREY, vrc_f2, vrc_f4 >; /* a colour / a table entry */
+    __shared__ C lut[VRC_TFP_ENTRIES];
     __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t regions[VRC_LDS_WAVES][S::REGION];
 
     for( uint32_t i = threadIdx.x; i < VRC_TFP_ENTRIES; i += 64u * VRC_LDS_WAVES )
-        lut[i] = lutGlobal[i];
+    {
+        const vrc_f4 e = lutGlobal[i];
+        if constexpr( GREY )
+            lut[i] = vrc_f2{ e.x, e.w };
+        else
+            lut[i] = e;
+    }
     __syncthreads();
     /* from here on the waves of the workgroup are independent: no further barrier */
 
@@ -179,7 +188,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
 
     /* ---- ray set-up: vrc_pixel_grid_dda ------------------------------------------------ */
     vrc_ray r;
-    vrc_f4 color = { 0.f, 0.f, 0.f, 0.f };
+    C color = {};
     bool done = true; /* nothing (more) to do for this lane */
     bool store = false;
     if( inFrame )
@@ -187,8 +196,9 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
         r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
         if( r.hit )
         {
-            if( !f.clearFirst )
-                color = pixelBuffer[pixelPos];
+            if constexpr( !GREY ) /* the grey form is only taken for frames that start from zero */
+                if( !f.clearFirst )
+                    color = pixelBuffer[pixelPos];
             if( !( color.w > VRC_EARLY_EXIT ) )
             {
                 store = true;
@@ -564,7 +574,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
                             fz += take ? fdz : 0u;
                             travel -= take ? stepSize : 0.0f;
                         }
-                        vrc_f4 e[BATCH];
+                        C e[BATCH];
                         if( LINEAR )
                         {
                             float t[BATCH][8];
@@ -638,7 +648,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
                     if( b0 < g )
                     {
                         bool act[BATCH];
-                        vrc_f4 e[BATCH];
+                        C e[BATCH];
                         if( LINEAR )
                         {
                             uint32_t ax[BATCH][2], ay[BATCH][2], az[BATCH][2], wfx[BATCH], wfy[BATCH], wfz[BATCH];
@@ -724,7 +734,12 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
     }
 
     if( store )
-        pixelBuffer[pixelPos] = color;
+    {
+        if constexpr( GREY )
+            pixelBuffer[pixelPos] = vrc_f4{ color.x, color.x, color.x, color.w };
+        else
+            pixelBuffer[pixelPos] = color;
+    }
     if( COUNT )
     {
         unsigned long long s = nSamples;
@@ -753,14 +768,19 @@ hipError_t vrc_launch_raycast_lds( const vrc_raycast_args& a, hipStream_t stream
     if( const char* force = getenv( "VRC_LDS_SHAPE" ) )
         flat = force[0] == 'f';
 #endif
-#define VRC_LDS_LAUNCH( COUNT, LINEAR, SHAPE )                                                        \
-    hipLaunchKernelGGL( ( vrc_k_raycast_lds< COUNT, LINEAR, SHAPE > ), grid, block, 0, stream, a.frame, \
-                        a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut, a.classifier,            \
+#define VRC_LDS_LAUNCH( COUNT, LINEAR, SHAPE, GREY )                                                         \
+    hipLaunchKernelGGL( ( vrc_k_raycast_lds< COUNT, LINEAR, SHAPE, GREY > ), grid, block, 0, stream, a.frame, \
+                        a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut, a.classifier,                  \
                         a.pixelBuffer, a.sampleCounter, a.tileOrder, tilesX, nTiles )
-#define VRC_LDS_LAUNCH_SHAPE( COUNT, LINEAR )                         \
-    {                                                                 \
-        if( flat ) VRC_LDS_LAUNCH( COUNT, LINEAR, vrc_lds_shape_flat ); \
-        else VRC_LDS_LAUNCH( COUNT, LINEAR, vrc_lds_shape_deep );       \
+#define VRC_LDS_LAUNCH_SHAPE( COUNT, LINEAR )                                         \
+    {                                                                                 \
+        if( a.greyTable )                                                             \
+        {                                                                             \
+            if( flat ) VRC_LDS_LAUNCH( COUNT, LINEAR, vrc_lds_shape_flat, true );       \
+            else VRC_LDS_LAUNCH( COUNT, LINEAR, vrc_lds_shape_deep, true );             \
+        }                                                                             \
+        else if( flat ) VRC_LDS_LAUNCH( COUNT, LINEAR, vrc_lds_shape_flat, false );     \
+        else VRC_LDS_LAUNCH( COUNT, LINEAR, vrc_lds_shape_deep, false );                \
     }
     if( a.linear )
     {

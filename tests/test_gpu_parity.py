@@ -1108,3 +1108,22 @@ def test_uint16_point_sampling_grouped_march_and_its_grey_form(vrc):
                 flt, n_flt, _ = g.render(kernel=k, stepping=0)
                 scenes.assert_parity(flt, want, "u16 %r kernel %d, float stepping" % (kw, k))
                 assert n_flt == n_grey
+
+
+def test_lds_kernel_grey_form_is_bit_identical(vrc):
+    # the LDS-staged kernel (the fast path of the trilinear filter) with (grey, alpha) pairs for a grey transfer
+    # function: the same bits as its four-float form, point-sampled and trilinear, first pass only
+    for name in ("hash64_spin", "hash64_ert", "mem_inside", "hash_clip"):
+        s = scenes.get(name)
+        with _gpu(s) as g:
+            for flt in (0, 1):
+                vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 0))
+                four, n_four, st = g.render(kernel=vrc.KERNEL_LDS, filter_mode=flt)
+                assert st.kernel_variant == vrc.KERNEL_LDS
+                h = s.n_nodes // 2
+                four2, n_four2, _ = g.render(kernel=vrc.KERNEL_LDS, filter_mode=flt, passes=[(0, h), (h, s.n_nodes)])
+                vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 1))
+                grey, n_grey, _ = g.render(kernel=vrc.KERNEL_LDS, filter_mode=flt)
+                assert (grey == four).all() and n_grey == n_four, (name, flt)
+                grey2, n_grey2, _ = g.render(kernel=vrc.KERNEL_LDS, filter_mode=flt, passes=[(0, h), (h, s.n_nodes)])
+                assert (grey2 == four2).all() and n_grey2 == n_four2, (name, flt)
