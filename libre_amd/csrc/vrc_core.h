@@ -1808,7 +1808,12 @@ VRC_HD void vrc_pixel_ray_lod( const vrc_frame& f, const vrc_dev_node* __restric
                 const vrc_segment s = vrc_run_segment( r, tp, tB, levelStep ); /* first sample eps inside */
                 vrc_classifier lc = cls;
                 lc.alphaCorrection = cls.alphaCorrection * scale;
-                const vrc_f4* ll = MODE == VRC_MODE_TABLE ? lut + n.level * VRC_LUT_ENTRIES : lut;
+                /* the level's classified table (257 entries of four floats, or of two in the grey form) */
+                const vrc_f4* ll = MODE == VRC_MODE_TABLE ? lut + n.level * VRC_LUT_ENTRIES
+                                   : MODE == VRC_MODE_GREY
+                                       ? reinterpret_cast< const vrc_f4* >( reinterpret_cast< const vrc_f2* >( lut ) +
+                                                                            n.level * VRC_LUT_ENTRIES )
+                                       : lut;
                 if( vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >( f, n, s, atlas, ll, lc, color,
                                                                              nSamples, levelStep ) )
                     break;

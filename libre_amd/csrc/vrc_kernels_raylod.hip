@@ -34,8 +34,19 @@ __global__ __launch_bounds__( VRC_RL_THREADS, VRC_RL_MIN_BLOCKS ) void vrc_k_ray
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) vrc_f4 lutLevels[]; /* 16: ds_read_b128 per entry */
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
-    for( uint32_t i = tid; i < lutEntries; i += VRC_RL_THREADS )
-        lutLevels[i] = lutGlobal[i];
+    if( MODE == VRC_MODE_GREY )
+    {
+        /* grey transfer function: (grey, alpha) pairs, half the table bytes (vrc_core.h, VRC_MODE_GREY) */
+        vrc_f2* const lut2 = reinterpret_cast< vrc_f2* >( lutLevels );
+        for( uint32_t i = tid; i < lutEntries; i += VRC_RL_THREADS )
+        {
+            const vrc_f4 e = lutGlobal[i];
+            lut2[i] = vrc_f2{ e.x, e.w };
+        }
+    }
+    else
+        for( uint32_t i = tid; i < lutEntries; i += VRC_RL_THREADS )
+            lutLevels[i] = lutGlobal[i];
 #if defined( VRC_ADDR_TABLES )
     if( FIXED )
     {
@@ -85,12 +96,14 @@ static hipError_t launch_raylod( const vrc_raycast_args& a, hipStream_t stream )
     const uint32_t nTiles = tilesX * tilesY;
     if( nTiles == 0 )
         return hipSuccess;
-    const uint32_t lutEntries =
-        MODE == VRC_MODE_TABLE ? a.frame.lodLevels * VRC_LUT_ENTRIES : VRC_TFP_ENTRIES;
+    const uint32_t lutEntries = ( MODE == VRC_MODE_TABLE || MODE == VRC_MODE_GREY )
+                                    ? a.frame.lodLevels * VRC_LUT_ENTRIES
+                                    : VRC_TFP_ENTRIES;
     hipLaunchKernelGGL( ( vrc_k_raycast_raylod< CLAMP, COUNT, FIXED, MODE, ATLAS_T > ),
                         dim3( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_RL_WAVES - 1u ) / VRC_RL_WAVES ),
                         dim3( VRC_RL_THREADS ),
-                        lutEntries * sizeof( vrc_f4 ), stream, a.frame, a.nodes, a.gridTable,
+                        lutEntries * ( MODE == VRC_MODE_GREY ? sizeof( vrc_f2 ) : sizeof( vrc_f4 ) ), stream, a.frame,
+                        a.nodes, a.gridTable,
                         (const ATLAS_T*)a.atlas, a.lut, lutEntries, a.classifier, a.pixelBuffer,
                         a.sampleCounter, a.tileOrder, tilesX, nTiles );
     return hipGetLastError();
@@ -130,7 +143,11 @@ hipError_t vrc_launch_raycast_raylod( const vrc_raycast_args& a, hipStream_t str
     case 1: return launch_raylod< false, true, false, VRC_MODE_TABLE, uint8_t >( a, stream );
     case 2: return launch_raylod< true, false, false, VRC_MODE_TABLE, uint8_t >( a, stream );
     case 3: return launch_raylod< true, true, false, VRC_MODE_TABLE, uint8_t >( a, stream );
-    case 4: return launch_raylod< false, false, true, VRC_MODE_TABLE, uint8_t >( a, stream );
-    default: return launch_raylod< false, true, true, VRC_MODE_TABLE, uint8_t >( a, stream );
+    case 4:
+        return a.greyTable ? launch_raylod< false, false, true, VRC_MODE_GREY, uint8_t >( a, stream )
+                           : launch_raylod< false, false, true, VRC_MODE_TABLE, uint8_t >( a, stream );
+    default:
+        return a.greyTable ? launch_raylod< false, true, true, VRC_MODE_GREY, uint8_t >( a, stream )
+                           : launch_raylod< false, true, true, VRC_MODE_TABLE, uint8_t >( a, stream );
     }
 }

@@ -1127,3 +1127,21 @@ def test_lds_kernel_grey_form_is_bit_identical(vrc):
                 assert (grey == four).all() and n_grey == n_four, (name, flt)
                 grey2, n_grey2, _ = g.render(kernel=vrc.KERNEL_LDS, filter_mode=flt, passes=[(0, h), (h, s.n_nodes)])
                 assert (grey2 == four2).all() and n_grey2 == n_four2, (name, flt)
+
+
+def test_per_ray_lod_grey_form_is_bit_identical(vrc):
+    # the per-ray LOD kernel with (grey, alpha) level tables: the same bits as its four-float form
+    from test_ray_lod import _hierarchy
+    for kw, sse in ((dict(voxels=(64, 64, 64), block=16, viewport=(48, 48), volume="hash", spin=(0.5, 0.35)), 2.0),
+                    (dict(voxels=(96, 64, 64), block=16, viewport=(40, 44), volume="hash", spin=(-0.4, 0.6), alpha=1.0),
+                     1.0)):
+        s = _hierarchy(**kw)
+        lod = (sse, orc.world_space_per_pixel(s))
+        with _gpu(s) as g:
+            vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 0))
+            four, n_four, st = g.render(ray_lod=lod)
+            assert st.kernel_variant == vrc.KERNEL_RAY_LOD
+            vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 1))
+            grey, n_grey, st = g.render(ray_lod=lod)
+            assert st.kernel_variant == vrc.KERNEL_RAY_LOD
+            assert (grey == four).all() and n_grey == n_four
