@@ -125,7 +125,7 @@ typedef struct
                                    * vrc_get_ray_counts */
 
 #define VRC_OPT_GREY_TABLE 12      /* 1 (default) | 0.  A transfer function whose red, green and blue are equal in every
-                                   * entry (bit for bit) lets the point-sampling grid-walk kernel keep (grey, alpha)
+                                   * entry (bit for bit) lets the kernels keep (grey, alpha)
                                    * instead of four floats per classified-table entry and per colour: half the
                                    * table bytes in LDS and three fused multiply-adds less per sample.  The three colour
                                    * channels of the reference's blend (cuda/Renderer.cu:83-93) are then the same
