@@ -144,7 +144,7 @@ struct lds_box
 template < bool COUNT, bool LINEAR, typename S, bool GREY = false >
 /* the deep region leaves LDS for three workgroups per CU (3 waves per SIMD), the flat one for four */
 #ifndef VRC_LDS_LINEAR_WAVES
-#define VRC_LDS_LINEAR_WAVES 4 /* measured: 4 waves with 11 spilled dwords (2.52 ms) beat 3 waves without (2.71 ms) */
+#define VRC_LDS_LINEAR_WAVES 4 /* measured: 4 waves beat 3 (2.52 against 2.71 ms, when 4 still spilled 11 dwords) */
 #endif
 __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINEAR ? VRC_LDS_LINEAR_WAVES : 4 ) ) void vrc_k_raycast_lds(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
@@ -545,7 +545,10 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
 
             /* ---- march g steps from LDS ---------------------------------------------------- */
             const uint32_t bias = box.z0 * S::PZ + box.y0 * S::PY + box.x0;
-            constexpr int BATCH = LINEAR ? 4 : VRC_LDS_G;
+#ifndef VRC_LDS_LBATCH
+#define VRC_LDS_LBATCH 2 /* trilinear samples whose 8 taps are read before the first is used: 4 spills at four waves per SIMD (2.39 -> 2.35 ms with 2; 8: 4.3 ms) */
+#endif
+            constexpr int BATCH = LINEAR ? VRC_LDS_LBATCH : VRC_LDS_G;
             /* FASTR: a full round (g = VRC_LDS_G) in which every participating lane has more than
              * g steps left: no per-step "does this lane take this step" selects */
             auto marchLds = [&]( auto fastTag ) {
