@@ -930,7 +930,9 @@ VRC_HD bool vrc_march_segment_as( const vrc_frame& f, const vrc_dev_node& n, vrc
      * cost more than the slots did */
     /* (whole groups of GROUP / 2 between the full groups and this tail were tried for GROUP = 14: the second unrolled
      * body costs the registers of a fifth wave -- spills, 0.488 -> 0.539 ms) */
-    constexpr int TAILG = GROUP >= 8 ? GROUP / 4 : ( GROUP >= 2 ? GROUP / 2 : 1 );
+    /* groups of 14: tails of 2 / 3 / 4 / 5 / 7: 0.492 / 0.489 / 0.479 / 0.485 / 0.485 ms (C2), 0.622 / 0.615 / 0.587 / 0.580 /
+     * 0.582 ms (noise, 30/20 degrees) */
+    constexpr int TAILG = GROUP >= 8 ? ( GROUP + 2 ) / 4 : ( GROUP >= 2 ? GROUP / 2 : 1 );
 #endif
     while( travel > 0.0f && !done )
     {
