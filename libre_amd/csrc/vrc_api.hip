@@ -1082,9 +1082,12 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         return fail( VRC_EINVAL, "vrc_render: node set is not grid-aligned; GRID_DDA unavailable" );
     /* LDS-staged kernel: brick-grid DDA + unclamped sampler (overlap >= 1).  AUTO takes it for
      * the trilinear filter (eight taps per sample), the gather kernel for point sampling. */
-    const bool ldsEligible = c->cachedGridOk && !c->cachedClamp && pool->elemBytes == 1 && !pool->bigAtlas;
+    /* its trilinear form takes the transfer-function texel and CUDA's 1.8 fixed-point lerp weight out of one
+     * float -> integer conversion (vrc_kernels_lds.hip: lds_classify): other weight widths use the gather form */
+    const bool ldsEligible = c->cachedGridOk && !c->cachedClamp && pool->elemBytes == 1 && !pool->bigAtlas &&
+                             ( !linear || c->optTfFracBits == 8 );
     if( c->optKernel == VRC_KERNEL_LDS && !ldsEligible )
-        return fail( VRC_EINVAL, "vrc_render: the LDS kernel needs a grid-aligned node set of 8-bit bricks with overlap >= 1" );
+        return fail( VRC_EINVAL, "vrc_render: the LDS kernel needs a grid-aligned node set of 8-bit bricks with overlap >= 1 (trilinear: VRC_OPT_TF_FRAC_BITS = 8)" );
     const bool useLds = !c->rayLod && ( c->optKernel == VRC_KERNEL_LDS ||
                                         ( c->optKernel == VRC_KERNEL_AUTO && linear && ldsEligible ) );
 

@@ -6,46 +6,64 @@
  * coalesced loads and the march then reads LDS instead of issuing byte gathers:
  *
  *   - one wave64 = one 8x8 pixel tile (as before); a workgroup is VRC_LDS_WAVES independent
- *     waves that only share the 4 KiB transfer-function table;
- *   - the wave works on ONE brick at a time: lanes whose current brick is another one wait
- *     (a tile covers at most 2x2 bricks across, usually one);
- *   - a round = up to VRC_LDS_G steps of every participating lane.  The slot-local bounding
- *     box of all the voxels those samples touch is found with six DPP wave reductions, the
- *     box is copied atlas -> LDS as 16-byte pieces (two 8-voxel rows of a micro-block slice,
- *     one global_load_dwordx4 + one ds_write2_b64 per lane and z-slice), and the samples are
- *     taken from LDS with a linear address (z*PZ + y*PY + x, compile-time pitches, so the
- *     eight trilinear taps are immediate offsets of one address);
- *   - the region comes in two shapes (flat 32x24x11; deeper 32x20x16 for views along y);
- *   - a box that does not fit the LDS region halves the round (8,4,2,1 steps) and then the
- *     lane set (half tile, quarter tile, 2x2 quad, single lane), so any view is handled.
+ *     waves that only share the transfer-function table;
+ *   - a round = up to VRC_LDS_G steps of every lane that has a brick segment, served in up to
+ *     VRC_LDS_PASSES passes.  A pass picks a lead lane (the tile centre if it still has steps to
+ *     take), puts a region-sized window around the voxels the lead's next steps touch, and takes
+ *     every lane of the lead's brick whose own steps stay inside that window.  ONE wave-wide OR
+ *     (six DPP steps) of a packed bit mask -- slices | row pairs | 8-voxel pieces each lane
+ *     touches, relative to the window -- gives the part of the window that is needed; that box is
+ *     copied atlas -> LDS as 16-byte pieces (two 8-voxel rows of a micro-block slice, one
+ *     global_load_dwordx4 + one ds_write2_b64 per lane and z-slice) and the samples are taken
+ *     from LDS with a linear address (z*PZ + y*PY + x, compile-time pitches, so the eight
+ *     trilinear taps are immediate offsets of one address);
+ *   - lanes the first pass left out (the other brick of a tile that straddles a brick border,
+ *     rays at another depth) get a pass of their own; only what is left after the last pass
+ *     takes its steps by byte gathers.  Round 2 sent every such lane to the gathers: 8 gathers
+ *     per trilinear sample for the whole wave whenever one lane was outside the box -- 29 % of
+ *     the rounds on BASELINE C2, and the larger part of the texture addresser's time;
+ *   - early ray termination is tested once per pass (opacity never decreases); a lane that
+ *     crossed the threshold replays its steps of the pass one by one from the saved colour,
+ *     which reproduces the reference's exit sample exactly (cuda/Renderer.cu:219-226);
+ *   - the box of a pass has any shape of up to 264 rows of 32 voxels (rows per slice x slices);
+ *   - a lead whose own steps do not fit the region halves the pass (8, 4, 2, 1 steps).
  *
- * Why: a 64-lane byte gather occupies the CU's texture addresser for ~23 cycles whatever it
- * returns.  Point sampling needs one gather per sample and the staging
- * overhead (reductions + copies, ~100 VALU per round) does not pay; the trilinear filter
- * needs eight taps per sample and does: this kernel is the fast path of VRC_OPT_FILTER = 1
- * and a measured alternative (VRC_OPT_KERNEL = VRC_KERNEL_LDS) for point sampling.
+ * Trilinear samples (VRC_OPT_FILTER = 1) are the reason this kernel exists: eight taps per
+ * sample cost eight gathers in the gather form.  What a sample costs here was counted
+ * instruction by instruction against profiles/r3_ubench_valu_lds_issue_costs.txt (wave64
+ * fma/mul/add/and/lshr issue in ~1.15 ns per SIMD, conversions, min/max, 24-bit multiplies,
+ * SDWA and DPP forms in ~1.85, log/exp in ~3.45; an LDS read at an odd address is 15 x slower
+ * than an aligned one, so x0/x1 pair loads are out):
+ *   - the fixed-point fractions are used as weights without the 2^-24 scale (W and 2^24 - W
+ *     are exact floats; the scale of the three lerps, 2^-72, is folded into the classifier's
+ *     multiplier -- same bits as scaled weights, three multiplies and nothing else less);
+ *   - the transfer-function texel and its 1.8 fixed-point lerp weight come out of ONE float ->
+ *     integer conversion (u = xB*256 + 256.5: texel = u >> 8, weight = u & 255), and for a grey
+ *     transfer function both texels arrive in one ds_read_b128 of (g0, 1-a0, g1, 1-a1)/256.
  *
- * Requires overlap >= 1 (no clamped sampler), slot dims <= 248 and a grid-aligned node set;
- * vrc_api.hip falls back to the gather kernels otherwise.
+ * Requires overlap >= 1 (no clamped sampler), slot dims <= 248, a grid-aligned node set and
+ * the CUDA lerp-weight width (VRC_OPT_TF_FRAC_BITS = 8) for the trilinear form;
+ * vrc_api.hip / the launcher fall back to the gather kernels otherwise.
  */
 #include "vrc_internal.h"
 
 #include <cstdlib>
 #include <type_traits>
 
-/* LDS region of one wave: PY = row pitch = max x extent (a multiple of 8), RY / RZ = max y / z
- * extent, bytes = PY*RY*RZ.  Two shapes, picked per frame from the view direction in volume space
- * (vrc_launch_raycast_lds): the flat one by default, the deeper one for views within ~20 degrees
- * of the y axis, the only ones it helps (measured, C2 trilinear, ms per frame flat / deep: along z
- * 2.46 / 2.71, along y 3.36 / 3.07, along x 3.59 / 3.72, 30/20 degrees off axis 3.59 / 4.17). */
-struct vrc_lds_shape_flat
-{
-    static constexpr uint32_t PY = 32u, RY = 24u, RZ = 11u, PZ = PY * RY, REGION = PZ * RZ;
-};
-struct vrc_lds_shape_deep
-{
-    static constexpr uint32_t PY = 32u, RY = 20u, RZ = 16u, PZ = PY * RY, REGION = PZ * RZ;
-};
+/* LDS region of one wave: VRC_LDS_REGION bytes = VRC_LDS_ROWS rows of VRC_LDS_PY voxels.  The row pitch is fixed
+ * (an 8x8-pixel tile at up to 2 voxels per pixel spans 16 + 2 voxels, + 7 for the 8-voxel alignment of the pieces);
+ * how the rows are split into rows per slice x slices is decided per pass from the box the lanes need: BASELINE C2's
+ * tiles go from 10 x 10 voxels across at the front of the volume to 18 x 18 at its back (the pixel pitch doubles
+ * with the distance from the eye) and march ~1 voxel per step along z, another view marches along y.  Round 2 had two
+ * compile-time shapes (32x24x11, 32x20x16): on C2, 8 of a tile's 58 marching lanes did not fit the 11 slices of the
+ * first in the average round (they are a voxel apart in depth) and took their steps by gathers; 16 slices in a
+ * third shape with 16 rows lost as many at the back of the volume.  The price of the run-time slice pitch is one
+ * address addition per trilinear sample (the second tap plane). */
+#define VRC_LDS_PY 32u
+#define VRC_LDS_ROWS 264u
+#define VRC_LDS_REGION ( VRC_LDS_PY * VRC_LDS_ROWS )
+#define VRC_LDS_MAX_DY 32u /* 16 row pairs: one per staging lane group */
+#define VRC_LDS_MAX_DZ 22u /* two staging halves of 11 slice loads in flight */
 #ifndef VRC_LDS_WAVES
 #define VRC_LDS_WAVES 4u
 #endif
@@ -55,15 +73,12 @@ struct vrc_lds_shape_deep
 #ifndef VRC_LDS_REFILL
 #define VRC_LDS_REFILL 8
 #endif
+#ifndef VRC_LDS_PASSES
+#define VRC_LDS_PASSES 1 /* boxes per round before the remaining lanes fall back to gathers (measured on C2, round 3: 1: 2.38 ms, 2: 2.61, 3: 2.81) */
+#endif
 
 #if defined( VRC_LDS_STATS ) /* developer build only (tools/build_variants.sh) */
 __device__ unsigned long long vrc_lds_stats[8];
-__device__ unsigned int vrc_lds_log[64 * 16];
-__device__ unsigned int vrc_lds_log_n;
-extern "C" int vrc_debug_lds_log( unsigned int out[64 * 16] )
-{
-    return hipMemcpyFromSymbol( out, HIP_SYMBOL( vrc_lds_log ), sizeof( unsigned int ) * 64 * 16 ) == hipSuccess ? 0 : 1;
-}
 extern "C" int vrc_debug_lds_stats( unsigned long long out[8], int reset )
 {
     if( hipMemcpyFromSymbol( out, HIP_SYMBOL( vrc_lds_stats ), sizeof( unsigned long long ) * 8 ) != hipSuccess )
@@ -78,22 +93,16 @@ extern "C" int vrc_debug_lds_stats( unsigned long long out[8], int reset )
 }
 #define VRC_LDS_STAT( I, V ) { if( lane == 0 ) atomicAdd( &vrc_lds_stats[I], (unsigned long long)( V ) ); }
 #else
-#define VRC_LDS_STAT( I, V )
+#define VRC_LDS_STAT( I, V ) {} /* a statement in both builds: `if( c ) VRC_LDS_STAT(..)` must not swallow what follows */
 #endif
 
 namespace
 {
-/* wave64 min / max: four DPP steps inside each row of 16 lanes, two row broadcasts, result
- * read from lane 63 */
-template < bool MAX >
-__device__ __forceinline__ uint32_t wave_reduce( uint32_t v )
+/* wave64 OR: four DPP steps inside each row of 16 lanes, two row broadcasts, result read from lane 63 */
+__device__ __forceinline__ uint32_t wave_or( uint32_t v )
 {
-#define VRC_DPP_STEP( CTRL, ROWMASK )                                                          \
-    {                                                                                          \
-        const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp( (int)v, (int)v, CTRL,        \
-                                                                  ROWMASK, 0xF, false );       \
-        v = MAX ? ( t > v ? t : v ) : ( t < v ? t : v );                                       \
-    }
+#define VRC_DPP_STEP( CTRL, ROWMASK ) \
+    v |= (uint32_t)__builtin_amdgcn_update_dpp( (int)v, (int)v, CTRL, ROWMASK, 0xF, false );
     VRC_DPP_STEP( 0xB1, 0xF )  /* quad_perm [1,0,3,2] */
     VRC_DPP_STEP( 0x4E, 0xF )  /* quad_perm [2,3,0,1] */
     VRC_DPP_STEP( 0x141, 0xF ) /* row_half_mirror */
@@ -105,10 +114,10 @@ __device__ __forceinline__ uint32_t wave_reduce( uint32_t v )
 }
 
 /* copy N z-slices of the box: per lane one 16-byte piece (two 8-voxel rows) per slice */
-template < typename S, int N >
+template < int N >
 __device__ __forceinline__ void lds_stage( const uint8_t* __restrict__ slotPtr, uint32_t partial,
                                            uint32_t sliceStride, uint32_t z0, uint32_t dz, bool on,
-                                           uint8_t* dst )
+                                           uint8_t* dst, uint32_t pz )
 {
     if( !on )
         return;
@@ -126,8 +135,8 @@ __device__ __forceinline__ void lds_stage( const uint8_t* __restrict__ slotPtr, 
     {
         if( (uint32_t)z < dz ) /* wave-uniform; never write past the box (the region ends with it) */
         {
-            *reinterpret_cast< uint2* >( dst + z * S::PZ ) = make_uint2( v[z].x, v[z].y );
-            *reinterpret_cast< uint2* >( dst + z * S::PZ + S::PY ) = make_uint2( v[z].z, v[z].w );
+            *reinterpret_cast< uint2* >( dst + z * pz ) = make_uint2( v[z].x, v[z].y );
+            *reinterpret_cast< uint2* >( dst + z * pz + VRC_LDS_PY ) = make_uint2( v[z].z, v[z].w );
         }
     }
 }
@@ -137,16 +146,91 @@ struct lds_box
     uint32_t x0, y0, z0; /* origin: x0 multiple of 8, y0 even */
     uint32_t dx, dy, dz; /* extents */
 };
+
+/* Transfer function and opacity correction of one trilinear sample (the oracle's orc_tf_fetch +
+ * composite, cuda/ColorMap.cu:40-45, cuda/Renderer.cu:83-93; vrc_classify in vrc_core.h is the same
+ * function in float form).  tq = xB*256 + 256.5 with xB = u*256 - 0.5 the CUDA texel coordinate
+ * (already clamped to [0.5, 65792.25]): texel pair (tq >> 8, +1) of the padded table, lerp weight
+ * (tq & 255)/256 = CUDA's 1.8 fixed-point weight, rounded to nearest as there.  tab holds, per
+ * texel j, (colour_j, 1 - alpha_j) / 256: the weights are used as integers 0..256.
+ * GREY: (g_j, 1-a_j, g_j+1, 1-a_j+1)/256 in one 16-byte entry. */
+struct lds_cls
+{
+    float mult, add, kexp;
+};
+__device__ __forceinline__ float lds_alpha( float corr, float kexp )
+{
+    /* 1 - min(a, 255/256) = max(1 - a, 1/256) (Renderer.cu:88); pow as exp2(k log2 x) */
+    corr = fmaxf( corr, 1.0f / 256.0f );
+    return 1.0f - __builtin_amdgcn_exp2f( kexp * __builtin_amdgcn_logf( corr ) );
+}
+__device__ __forceinline__ vrc_f2 lds_classify( const vrc_f2*, const float4* tab, float d, const lds_cls& k )
+{
+    float tq = __builtin_fmaf( d, k.mult, k.add );
+    tq = __builtin_amdgcn_fmed3f( tq, 0.5f, 65792.25f );
+    const uint32_t u = (uint32_t)tq;
+    const float a = (float)( u & 255u ), b = 256.0f - a;
+    const float4 t = *reinterpret_cast< const float4* >( reinterpret_cast< const char* >( tab ) +
+                                                        ( ( u >> 4 ) & 0xFFFF0u ) );
+    const float alpha = lds_alpha( __builtin_fmaf( a, t.w, b * t.y ), k.kexp );
+    vrc_f2 e;
+    e.x = __builtin_fmaf( a, t.z, b * t.x ) * alpha;
+    e.w = alpha;
+    return e;
+}
+__device__ __forceinline__ vrc_f4 lds_classify( const vrc_f4*, const float4* tab, float d, const lds_cls& k )
+{
+    float tq = __builtin_fmaf( d, k.mult, k.add );
+    tq = __builtin_amdgcn_fmed3f( tq, 0.5f, 65792.25f );
+    const uint32_t u = (uint32_t)tq;
+    const float a = (float)( u & 255u ), b = 256.0f - a;
+    const float4* const p = reinterpret_cast< const float4* >( reinterpret_cast< const char* >( tab ) +
+                                                               ( ( u >> 4 ) & 0xFFFF0u ) );
+    const float4 t0 = p[0], t1 = p[1];
+    const float alpha = lds_alpha( __builtin_fmaf( a, t1.w, b * t0.w ), k.kexp );
+    vrc_f4 e;
+    e.x = __builtin_fmaf( a, t1.x, b * t0.x ) * alpha;
+    e.y = __builtin_fmaf( a, t1.y, b * t0.y ) * alpha;
+    e.z = __builtin_fmaf( a, t1.z, b * t0.z ) * alpha;
+    e.w = alpha;
+    return e;
+}
+
+/* the eight taps at p, weights = the 24 fraction bits of the sample's coordinates, NOT scaled by 2^-24:
+ * W and 2^24 - W are exact, so every product and sum is 2^24 (2^48, 2^72) times the one with scaled
+ * weights, bit for bit; lds_cls.mult carries the 2^-72 */
+/* p: the sample's voxel in the box, q: the same voxel one slice further */
+__device__ __forceinline__ void lds_taps( const uint8_t* p, const uint8_t* q, float t[8] )
+{
+    t[0] = (float)p[0];
+    t[1] = (float)p[1];
+    t[2] = (float)p[VRC_LDS_PY];
+    t[3] = (float)p[VRC_LDS_PY + 1u];
+    t[4] = (float)q[0];
+    t[5] = (float)q[1];
+    t[6] = (float)q[VRC_LDS_PY];
+    t[7] = (float)q[VRC_LDS_PY + 1u];
+}
+__device__ __forceinline__ float lds_trilerp( const float v[8], uint32_t fx, uint32_t fy, uint32_t fz )
+{
+    const float wx = (float)( fx & 0xFFFFFFu ), wy = (float)( fy & 0xFFFFFFu ), wz = (float)( fz & 0xFFFFFFu );
+    const float ux = 16777216.0f - wx, uy = 16777216.0f - wy, uz = 16777216.0f - wz;
+    /* the oracle's order: x, then y, then z; a*(1-w) + b*w */
+    const float c00 = __builtin_fmaf( v[1], wx, v[0] * ux );
+    const float c10 = __builtin_fmaf( v[3], wx, v[2] * ux );
+    const float c01 = __builtin_fmaf( v[5], wx, v[4] * ux );
+    const float c11 = __builtin_fmaf( v[7], wx, v[6] * ux );
+    const float c0 = __builtin_fmaf( c10, wy, c00 * uy );
+    const float c1 = __builtin_fmaf( c11, wy, c01 * uy );
+    return __builtin_fmaf( c1, wz, c0 * uz );
+}
 }
 
 /* GREY: the transfer function is grey and the frame starts from zero (vrc_raycast_args.greyTable): colours and table
  * entries are (grey, alpha) pairs, bit-identical to the four-float form (vrc_core.h, VRC_MODE_GREY) */
-template < bool COUNT, bool LINEAR, typename S, bool GREY = false >
-/* the deep region leaves LDS for three workgroups per CU (3 waves per SIMD), the flat one for four */
-#ifndef VRC_LDS_LINEAR_WAVES
-#define VRC_LDS_LINEAR_WAVES 4 /* measured: 4 waves beat 3 (2.52 against 2.71 ms, when 4 still spilled 11 dwords) */
-#endif
-__global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINEAR ? VRC_LDS_LINEAR_WAVES : 4 ) ) void vrc_k_raycast_lds(
+template < bool COUNT, bool LINEAR, bool GREY = false >
+/* four workgroups per CU: 4 x (4 regions of 8.25 KiB + the table) = 152 of the CU's 160 KiB */
+__global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ gridTable, const uint8_t* __restrict__ atlas,
     const vrc_f4* __restrict__ lutGlobal, const vrc_classifier cls,
@@ -154,16 +238,38 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
     const uint32_t* __restrict__ tileOrder, const uint32_t tilesX, const uint32_t nTiles )
 {
     using C = std::conditional_t< GREY, vrc_f2, vrc_f4 >; /* a colour / a table entry */
-    __shared__ C lut[VRC_TFP_ENTRIES];
-    __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t regions[VRC_LDS_WAVES][S::REGION];
+    /* point sampling: the classified table (257 entries of C).  Trilinear: the padded transfer function
+     * tfp[j] = tf[clamp(j-1)] as (colour, 1 - alpha) / 256 per texel (lds_classify); grey: texels j and j+1
+     * side by side in one 16-byte entry.  One texel more than the 258 of the float form: a sample at the
+     * upper clamp reads texel pair (257, 258) with weights (256, 0). */
+    constexpr uint32_t TAB_ENTRIES = LINEAR ? ( GREY ? VRC_TFP_ENTRIES : VRC_TFP_ENTRIES + 1u ) : 1u;
+    __shared__ C lut[LINEAR ? 1u : VRC_TFP_ENTRIES];
+    __shared__ __attribute__( ( aligned( 16 ) ) ) float4 tab[TAB_ENTRIES];
+    __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t regions[VRC_LDS_WAVES][VRC_LDS_REGION];
 
-    for( uint32_t i = threadIdx.x; i < VRC_TFP_ENTRIES; i += 64u * VRC_LDS_WAVES )
+    if constexpr( LINEAR )
     {
-        const vrc_f4 e = lutGlobal[i];
-        if constexpr( GREY )
-            lut[i] = vrc_f2{ e.x, e.w };
-        else
-            lut[i] = e;
+        for( uint32_t i = threadIdx.x; i < TAB_ENTRIES; i += 64u * VRC_LDS_WAVES )
+        {
+            const float sc = 1.0f / 256.0f;
+            const vrc_f4 e0 = lutGlobal[i < VRC_TFP_ENTRIES - 1u ? i : VRC_TFP_ENTRIES - 1u];
+            const vrc_f4 e1 = lutGlobal[i + 1u < VRC_TFP_ENTRIES - 1u ? i + 1u : VRC_TFP_ENTRIES - 1u];
+            if constexpr( GREY )
+                tab[i] = float4{ e0.x * sc, ( 1.0f - e0.w ) * sc, e1.x * sc, ( 1.0f - e1.w ) * sc };
+            else
+                tab[i] = float4{ e0.x * sc, e0.y * sc, e0.z * sc, ( 1.0f - e0.w ) * sc };
+        }
+    }
+    else
+    {
+        for( uint32_t i = threadIdx.x; i < VRC_TFP_ENTRIES; i += 64u * VRC_LDS_WAVES )
+        {
+            const vrc_f4 e = lutGlobal[i];
+            if constexpr( GREY )
+                lut[i] = vrc_f2{ e.x, e.w };
+            else
+                lut[i] = e;
+        }
     }
     __syncthreads();
     /* from here on the waves of the workgroup are independent: no further barrier */
@@ -281,16 +387,22 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
     uint32_t laneSlotBase = 0;
     uint32_t nSamples = 0;
     const float stepSize = f.stepSize;
-    const float invStep = 1.0f / stepSize;
     int budget = 8 * ( f.gridDim[0] + f.gridDim[1] + f.gridDim[2] + 3 ); /* exit guarantee */
 
     /* staging role of the lane: 4 row-pairs across (x), 16 down (y) per z-slice */
     const uint32_t sxr = lane & 3u, syp = lane >> 2;
-    const uint32_t ldsLane = syp * 2u * S::PY + sxr * 8u;
+    const uint32_t ldsLane = syp * 2u * VRC_LDS_PY + sxr * 8u;
     const uint32_t sliceStride = f.sbx * f.sby * VRC_MB_VOXELS;
+    /* classifier of the trilinear form (lds_classify): texel coordinate * 256 + 256.5 from the density * 2^72 */
+    [[maybe_unused]] const lds_cls lcls = { cls.mult * 256.0f * 0x1p-72f, cls.add * 256.0f + 256.5f, cls.alphaCorrection };
 
+    /* exit guarantee of the round loop, whatever the state: every round advances at least one lane by a step or a
+     * brick, so 64 lanes x (steps of the longest ray + cells it can cross) rounds are never reached */
+    uint32_t roundBudget = 64u * ( (uint32_t)( 3.5f / stepSize ) + 8u * (uint32_t)( f.gridDim[0] + f.gridDim[1] + f.gridDim[2] ) + 64u );
     for( ;; )
     {
+        if( roundBudget-- == 0u )
+            break;
         /* A: live lanes without a segment walk their DDA to the next brick they sample.  The
          * walk (ray/box set-up, ~200 instructions) is shared by the wave, so lanes that
          * finish a brick early wait for company (VRC_LDS_REFILL lanes) or for the others to
@@ -309,7 +421,6 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
         }
         while( refill && __builtin_amdgcn_ballot_w64( !done && !hasSeg ) != 0ull )
         {
-            VRC_LDS_STAT( 4, 1 )
             if( !done && !hasSeg )
             {
                 if( ddaEnd || --budget < 0 )
@@ -418,30 +529,31 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
             }
         }
 
-        /* B: the round's LDS box is built around one lane (the tile centre if it has a
-         * segment): its brick, and the lanes of that brick that are near it */
-        const uint64_t segMask = __builtin_amdgcn_ballot_w64( hasSeg );
-        if( segMask == 0ull )
+        /* B: one round: up to VRC_LDS_G steps of every lane that has a segment, in up to VRC_LDS_PASSES
+         * passes through an LDS box each; what is left after the last pass takes its steps by gathers */
+        if( __builtin_amdgcn_ballot_w64( hasSeg ) == 0ull )
             break;
-        const uint32_t lead = ( segMask >> 15 ) & 1ull ? 15u
-                              : ( ( segMask >> 48 ) & 1ull ? 48u : (uint32_t)__builtin_ctzll( segMask ) );
-        const int32_t brick = __builtin_amdgcn_readlane( curNode, lead );
-        const uint8_t* const slotPtr = atlas + (uint32_t)__builtin_amdgcn_readlane( (int)laneSlotBase, lead );
-
-        /* C: one round: up to g steps of every lane that has a segment -- from LDS for the
-         * lanes in the box, by byte gathers from the atlas for the others */
+        bool inTodo = hasSeg;
+        for( int pass = 0; pass < VRC_LDS_PASSES; ++pass )
         {
-            bool part = hasSeg && curNode == brick;
-            int g = VRC_LDS_G;
+            const uint64_t todoMask = __builtin_amdgcn_ballot_w64( inTodo );
+            if( todoMask == 0ull )
+                break;
+            /* the lead: the tile centre if it still has steps to take in this round */
+            const uint32_t lead = ( todoMask >> 15 ) & 1ull ? 15u
+                                  : ( ( todoMask >> 48 ) & 1ull ? 48u : (uint32_t)__builtin_ctzll( todoMask ) );
+            const int32_t brick = __builtin_amdgcn_readlane( curNode, lead );
+            const uint8_t* const slotPtr = atlas + (uint32_t)__builtin_amdgcn_readlane( (int)laneSlotBase, lead );
+
+            /* voxels touched by the lane's next g samples -- all g of them, whether or not the lane's segment
+             * ends earlier (the march then reads inside the box for every lane and step and needs no address
+             * select); g is halved until the lead's own footprint fits the region */
+            uint32_t g = VRC_LDS_G;
             uint32_t lox, hix, loy, hiy, loz, hiz;
-            /* voxels touched by the lane's next (up to) g samples; the step count is
-             * over-estimated by at most 2 (the exact per-sample test is travel > 0).  g is
-             * halved until the first participating lane's own footprint fits the region. */
+            uint32_t llx, lhx, lly, lhy, llz, lhz;
             for( ;; )
             {
-                int m = (int)( travel * invStep ) + 2;
-                m = m < g ? m : g;
-                const uint32_t k = (uint32_t)( m - 1 );
+                const uint32_t k = g - 1u;
                 const uint32_t ex = fx + k * fdx, ey = fy + k * fdy, ez = fz + k * fdz;
                 const uint32_t ax = fx >> 24, ay = fy >> 24, az = fz >> 24;
                 const uint32_t bx = ex >> 24, by = ey >> 24, bz = ez >> 24;
@@ -449,74 +561,96 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
                 lox = ax < bx ? ax : bx; hix = ( ax < bx ? bx : ax ) + ext;
                 loy = ay < by ? ay : by; hiy = ( ay < by ? by : ay ) + ext;
                 loz = az < bz ? az : bz; hiz = ( az < bz ? bz : az ) + ext;
-                /* the over-estimate may leave the slot: keep the copy inside it */
+                /* steps past the end of a segment may leave the slot: keep the copy inside it */
                 hix = hix < f.slotDim[0] - 1u ? hix : f.slotDim[0] - 1u;
                 hiy = hiy < f.slotDim[1] - 1u ? hiy : f.slotDim[1] - 1u;
                 hiz = hiz < f.slotDim[2] - 1u ? hiz : f.slotDim[2] - 1u;
                 lox = lox < hix ? lox : hix;
                 loy = loy < hiy ? loy : hiy;
                 loz = loz < hiz ? loz : hiz;
-                /* x origin is aligned down to 8, y origin to 2 */
-                const bool ownFit = hix - ( lox & ~7u ) < S::PY && hiy - ( loy & ~1u ) < S::RY &&
-                                    hiz - loz < S::RZ;
-                const bool leadFit = ( __builtin_amdgcn_ballot_w64( ownFit ) >> lead ) & 1ull;
-                if( leadFit || g == 1 )
+                llx = (uint32_t)__builtin_amdgcn_readlane( (int)lox, lead );
+                lhx = (uint32_t)__builtin_amdgcn_readlane( (int)hix, lead );
+                lly = (uint32_t)__builtin_amdgcn_readlane( (int)loy, lead );
+                lhy = (uint32_t)__builtin_amdgcn_readlane( (int)hiy, lead );
+                llz = (uint32_t)__builtin_amdgcn_readlane( (int)loz, lead );
+                lhz = (uint32_t)__builtin_amdgcn_readlane( (int)hiz, lead );
+                /* the lead's own steps must fit: pieces are aligned to 8 in x, row pairs to 2 in y */
                 {
-                    part = part && ownFit;
-                    break;
+                    const uint32_t ey2 = ( ( lhy | 1u ) - ( lly & ~1u ) + 1u ), ez1 = lhz - llz + 1u;
+                    if( ( lhx - llx + 8u <= VRC_LDS_PY && ey2 <= VRC_LDS_MAX_DY && ez1 <= VRC_LDS_MAX_DZ &&
+                          ey2 * ez1 <= VRC_LDS_ROWS ) || g == 1u )
+                        break;
                 }
                 g >>= 1;
             }
+            /* Candidates: the lanes of the lead's brick whose steps lie within 32 voxels / 32 rows / 32 slices around
+             * the lead's (all scalar).  Two wave-wide ORs (six DPP steps each) of bit masks relative to that
+             * neighbourhood -- the slices; the row pairs and 8-voxel pieces each lane touches -- give the box of
+             * all of them. */
+            const uint32_t ex_ = lhx - llx + 1u, ey_ = lhy - lly + 1u, ez_ = lhz - llz + 1u;
+            const uint32_t sx = ex_ < VRC_LDS_PY - 7u ? ( VRC_LDS_PY - 7u - ex_ ) / 2u : 0u;
+            const uint32_t sy = ey_ < 31u ? ( 31u - ey_ ) / 2u : 0u;
+            const uint32_t sz = ez_ < 32u ? ( 32u - ez_ ) / 2u : 0u;
+            const uint32_t wx0 = ( llx - ( llx < sx ? llx : sx ) ) & ~7u;
+            const uint32_t wy0 = ( lly - ( lly < sy ? lly : sy ) ) & ~1u;
+            const uint32_t wz0 = llz - ( llz < sz ? llz : sz );
+            const bool cand = inTodo && curNode == brick && lox >= wx0 && hix < wx0 + VRC_LDS_PY && loy >= wy0 &&
+                              hiy < wy0 + 32u && loz >= wz0 && hiz < wz0 + 32u;
             lds_box box;
-            bool windowed = false;
-            for( ;; )
             {
-                const uint32_t mnx = wave_reduce< false >( part ? lox : 0xFFFFFFFFu );
-                const uint32_t mny = wave_reduce< false >( part ? loy : 0xFFFFFFFFu );
-                const uint32_t mnz = wave_reduce< false >( part ? loz : 0xFFFFFFFFu );
-                const uint32_t mxx = wave_reduce< true >( part ? hix : 0u );
-                const uint32_t mxy = wave_reduce< true >( part ? hiy : 0u );
-                const uint32_t mxz = wave_reduce< true >( part ? hiz : 0u );
-                box.x0 = mnx & ~7u;
-                box.y0 = mny & ~1u;
-                box.z0 = mnz;
-                box.dx = mxx - box.x0 + 1u;
-                box.dy = mxy - box.y0 + 1u;
-                box.dz = mxz - box.z0 + 1u;
-                VRC_LDS_STAT( 3, 1 )
-                if( ( box.dx <= S::PY && box.dy <= S::RY && box.dz <= S::RZ ) || windowed )
-                    break;
-                /* The lanes of the brick are too far apart (rays that entered it through
-                 * different faces are at different depths): keep the lanes whose footprint
-                 * lies in a region-sized window centred on the first lane's footprint; the
-                 * others are served by later rounds. */
-                const uint32_t llx = (uint32_t)__builtin_amdgcn_readlane( (int)lox, lead );
-                const uint32_t lhx = (uint32_t)__builtin_amdgcn_readlane( (int)hix, lead );
-                const uint32_t lly = (uint32_t)__builtin_amdgcn_readlane( (int)loy, lead );
-                const uint32_t lhy = (uint32_t)__builtin_amdgcn_readlane( (int)hiy, lead );
-                const uint32_t llz = (uint32_t)__builtin_amdgcn_readlane( (int)loz, lead );
-                const uint32_t lhz = (uint32_t)__builtin_amdgcn_readlane( (int)hiz, lead );
-                const uint32_t ex_ = lhx - llx + 1u, ey_ = lhy - lly + 1u, ez_ = lhz - llz + 1u;
-                const uint32_t sx = ex_ < S::PY - 7u ? ( S::PY - 7u - ex_ ) / 2u : 0u;
-                const uint32_t sy = ey_ < S::RY - 1u ? ( S::RY - 1u - ey_ ) / 2u : 0u;
-                const uint32_t sz = ez_ < S::RZ ? ( S::RZ - ez_ ) / 2u : 0u;
-                const uint32_t wx0 = ( llx - ( llx < sx ? llx : sx ) ) & ~7u;
-                const uint32_t wy0 = ( lly - ( lly < sy ? lly : sy ) ) & ~1u;
-                const uint32_t wz0 = llz - ( llz < sz ? llz : sz );
-                part = part && lox >= wx0 && hix < wx0 + S::PY && loy >= wy0 &&
-                       hiy < wy0 + S::RY && loz >= wz0 && hiz < wz0 + S::RZ;
-                windowed = true;
+                const uint32_t zb = ( ( 2u << ( hiz - loz ) ) - 1u ) << ( loz - wz0 );
+                const uint32_t p0 = ( loy - wy0 ) >> 1, p1 = ( hiy - wy0 ) >> 1;
+                const uint32_t yb = ( ( 2u << ( p1 - p0 ) ) - 1u ) << p0;
+                const uint32_t q0 = ( lox - wx0 ) >> 3, q1 = ( hix - wx0 ) >> 3;
+                const uint32_t xb = ( ( 2u << ( q1 - q0 ) ) - 1u ) << ( q0 + 16u );
+                const uint32_t zm = wave_or( cand ? zb : 0u );
+                const uint32_t yx = wave_or( cand ? ( yb | xb ) : 0u );
+                const uint32_t ym = yx & 0xFFFFu, xm = yx >> 16;
+                uint32_t zlo = (uint32_t)__builtin_ctz( zm ), zhi = 31u - (uint32_t)__builtin_clz( zm );
+                uint32_t ylo = (uint32_t)__builtin_ctz( ym ), yhi = 31u - (uint32_t)__builtin_clz( ym );
+                const uint32_t xlo = (uint32_t)__builtin_ctz( xm ), xhi = 31u - (uint32_t)__builtin_clz( xm );
+                /* More rows x slices than the region holds (or more slices than the staging loop loads): take
+                 * slices / row pairs off the side that reaches furthest beyond the lead's own; the lanes that
+                 * needed them get the next pass.  Scalar, and it ends at the lead's own box, which fits. */
+                const uint32_t lz0 = llz - wz0, lz1 = lhz - wz0, lp0 = ( lly - wy0 ) >> 1, lp1 = ( lhy - wy0 ) >> 1;
+                for( ;; )
+                {
+                    const uint32_t dz = zhi - zlo + 1u, dy = 2u * ( yhi - ylo + 1u );
+                    if( dz <= VRC_LDS_MAX_DZ && dy * dz <= VRC_LDS_ROWS )
+                        break;
+                    const uint32_t sz0 = lz0 - zlo, sz1 = zhi - lz1, sy0 = 2u * ( lp0 - ylo ), sy1 = 2u * ( yhi - lp1 );
+                    const uint32_t mz = sz0 > sz1 ? sz0 : sz1, my = sy0 > sy1 ? sy0 : sy1;
+                    if( dz > VRC_LDS_MAX_DZ || ( mz >= my && mz > 0u ) )
+                    {
+                        if( sz0 > sz1 ) ++zlo; else --zhi;
+                    }
+                    else
+                    {
+                        if( sy0 > sy1 ) ++ylo; else --yhi;
+                    }
+                }
+                box.x0 = wx0 + 8u * xlo;
+                box.dx = 8u * ( xhi - xlo + 1u );
+                box.y0 = wy0 + 2u * ylo;
+                box.dy = 2u * ( yhi - ylo + 1u );
+                box.z0 = wz0 + zlo;
+                box.dz = zhi - zlo + 1u;
             }
-
+            const bool part = cand && loy >= box.y0 && hiy < box.y0 + box.dy && loz >= box.z0 && hiz < box.z0 + box.dz;
+            const uint32_t pz = VRC_LDS_PY * box.dy; /* slice pitch of this pass */
             VRC_LDS_STAT( 0, 1 )
-            VRC_LDS_STAT( 1, g )
             {
-                const uint64_t pm_ = __builtin_amdgcn_ballot_w64( part );
-                (void)pm_;
+                [[maybe_unused]] const uint64_t cm_ = __builtin_amdgcn_ballot_w64( inTodo && curNode == brick );
+                VRC_LDS_STAT( 1, pass == 0 ? __builtin_popcountll( todoMask ) : 0 )
+                VRC_LDS_STAT( 4, pass == 0 ? __builtin_popcountll( cm_ ) : 0 )
+                [[maybe_unused]] const uint64_t p0_ = __builtin_amdgcn_ballot_w64( part );
+                VRC_LDS_STAT( 7, pass == 0 ? __builtin_popcountll( p0_ ) : 0 )
+            }
+            {
+                [[maybe_unused]] const uint64_t pm_ = __builtin_amdgcn_ballot_w64( part );
                 VRC_LDS_STAT( 5, __builtin_popcountll( pm_ ) )
             }
-            VRC_LDS_STAT( 6, box.dx * box.dy * box.dz )
-            VRC_LDS_STAT( 7, box.dz )
+            VRC_LDS_STAT( 6, pass == 0 ? 1 : 0 )
             /* ---- stage the box: atlas (micro-blocked) -> LDS (linear) --------------------- */
             {
                 const uint32_t x = box.x0 + sxr * 8u, y = box.y0 + syp * 2u;
@@ -525,18 +659,21 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
                     ( ( y >> VRC_MB_SHIFT ) * f.sbx + ( x >> VRC_MB_SHIFT ) ) * VRC_MB_VOXELS +
                     ( ( y & 7u ) << 3 );
                 uint8_t* const dst = region + ldsLane;
-                /* every slice load of the round is issued before the first LDS write; slices
+                /* every slice load of the pass is issued before the first LDS write; slices
                  * past the box repeat its last slice (branch-free, same cache lines) */
+#if defined( VRC_LDS_ABLATE_STAGE ) /* developer timing build: no copies (wrong pixels) */
+                if( box.dz > 1000u )
+#endif
                 if( box.dz <= 8u )
-                    lds_stage< S, 8 >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst );
+                    lds_stage< 8 >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst, pz );
                 else if( box.dz <= 11u )
-                    lds_stage< S, 11 >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst );
+                    lds_stage< 11 >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst, pz );
                 else
                 {
-                    /* deep boxes (S::RZ > 11) in two halves: at most 11 loads in flight */
+                    /* deeper boxes in two halves: at most 11 loads in flight */
                     const uint32_t h = ( box.dz + 1u ) / 2u;
-                    lds_stage< S, 11 >( slotPtr, partial, sliceStride, box.z0, h, on, dst );
-                    lds_stage< S, 11 >( slotPtr, partial, sliceStride, box.z0 + h, box.dz - h, on, dst + h * S::PZ );
+                    lds_stage< 11 >( slotPtr, partial, sliceStride, box.z0, h, on, dst, pz );
+                    lds_stage< 11 >( slotPtr, partial, sliceStride, box.z0 + h, box.dz - h, on, dst + h * pz, pz );
                 }
             }
             /* a wave's LDS accesses complete in issue order, so its own region needs no
@@ -544,30 +681,43 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
             __builtin_amdgcn_wave_barrier();
 
             /* ---- march g steps from LDS ---------------------------------------------------- */
-            const uint32_t bias = box.z0 * S::PZ + box.y0 * S::PY + box.x0;
+            const uint32_t bias = box.z0 * pz + box.y0 * VRC_LDS_PY + box.x0;
+            /* one sample from the box: the entry (rgb*alpha', alpha') it composites */
+            auto sampleLds = [&]( uint32_t a, uint32_t sx_, uint32_t sy_, uint32_t sz_ ) -> C {
+                if constexpr( LINEAR )
+                {
+                    float t[8];
+                    lds_taps( region + a, region + a + pz, t );
+                    return lds_classify( (const C*)nullptr, tab, lds_trilerp( t, sx_, sy_, sz_ ), lcls );
+                }
+                else
+                    return lut[(uint32_t)region[a]];
+            };
 #ifndef VRC_LDS_LBATCH
-#define VRC_LDS_LBATCH 2 /* trilinear samples whose 8 taps are read before the first is used: 4 spills at four waves per SIMD (2.39 -> 2.35 ms with 2; 8: 4.3 ms) */
+#define VRC_LDS_LBATCH 2 /* trilinear samples whose 8 taps are read before the first is used */
 #endif
             constexpr int BATCH = LINEAR ? VRC_LDS_LBATCH : VRC_LDS_G;
-            /* FASTR: a full round (g = VRC_LDS_G) in which every participating lane has more than
+            const C colorIn = color; /* for the replay of a lane that crosses the early-exit threshold */
+            uint32_t cnt = 0;        /* samples the lane took in this pass */
+            /* FASTR: a full pass (g = VRC_LDS_G) in which every participating lane has more than
              * g steps left: no per-step "does this lane take this step" selects */
             auto marchLds = [&]( auto fastTag ) {
                 constexpr bool FASTR = decltype( fastTag )::value;
 #pragma unroll
                 for( int b0 = 0; b0 < VRC_LDS_G; b0 += BATCH )
                 {
-                    if( FASTR || b0 < g ) /* wave-uniform */
+                    if( FASTR || (uint32_t)b0 < g ) /* wave-uniform */
                     {
-                        /* addresses of the batch; a step the lane does not take reads offset 0 */
                         uint32_t a[BATCH], wfx[BATCH], wfy[BATCH], wfz[BATCH];
                         bool act[BATCH];
 #pragma unroll
                         for( int s = 0; s < BATCH; ++s )
                         {
-                            const bool take = FASTR ? true : ( part && ( b0 + s < g ) );
+                            const bool take = FASTR ? true : ( (uint32_t)( b0 + s ) < g ); /* wave-uniform */
                             act[s] = FASTR ? true : ( take && travel > 0.0f );
-                            const uint32_t av = ( fz >> 24 ) * S::PZ + ( fy >> 24 ) * S::PY +
-                                                ( fx >> 24 ) - bias;
+                            /* a step past the end of the lane's segment may lie outside the slot, where the box
+                             * does not follow: it reads offset 0 */
+                            const uint32_t av = ( fz >> 24 ) * pz + ( fy >> 24 ) * VRC_LDS_PY + ( fx >> 24 ) - bias;
                             a[s] = act[s] ? av : 0u;
                             wfx[s] = fx;
                             wfy[s] = fy;
@@ -578,31 +728,16 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
                             travel -= take ? stepSize : 0.0f;
                         }
                         C e[BATCH];
-                        if( LINEAR )
+                        if constexpr( LINEAR )
                         {
                             float t[BATCH][8];
 #pragma unroll
                             for( int s = 0; s < BATCH; ++s )
-                            {
-                                const uint8_t* const p = region + a[s];
-                                t[s][0] = (float)p[0];
-                                t[s][1] = (float)p[1];
-                                t[s][2] = (float)p[S::PY];
-                                t[s][3] = (float)p[S::PY + 1u];
-                                t[s][4] = (float)p[S::PZ];
-                                t[s][5] = (float)p[S::PZ + 1u];
-                                t[s][6] = (float)p[S::PZ + S::PY];
-                                t[s][7] = (float)p[S::PZ + S::PY + 1u];
-                            }
+                                lds_taps( region + a[s], region + a[s] + pz, t[s] );
 #pragma unroll
                             for( int s = 0; s < BATCH; ++s )
-                            {
-                                const float sc = 1.0f / 16777216.0f;
-                                const float wx = (float)( wfx[s] & 0xFFFFFFu ) * sc;
-                                const float wy = (float)( wfy[s] & 0xFFFFFFu ) * sc;
-                                const float wz = (float)( wfz[s] & 0xFFFFFFu ) * sc;
-                                e[s] = vrc_classify( lut, vrc_trilerp( t[s], wx, wy, wz ), cls );
-                            }
+                                e[s] = lds_classify( (const C*)nullptr, tab,
+                                                     lds_trilerp( t[s], wfx[s], wfy[s], wfz[s] ), lcls );
                         }
                         else
                         {
@@ -612,128 +747,137 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, S::REGION > 8448u ? 3 : ( LINE
                                 d[s] = (uint32_t)region[a[s]];
 #pragma unroll
                             for( int s = 0; s < BATCH; ++s )
-                                e[s] = lut[act[s] ? d[s] : 256u];
+                                e[s] = lut[d[s]];
                         }
 #pragma unroll
                         for( int s = 0; s < BATCH; ++s )
                         {
-                            const bool on = act[s] && !done;
-                            vrc_composite( color, e[s], !on );
-                            if( COUNT )
-                                nSamples += on ? 1u : 0u;
-                            done = done || ( on && color.w > VRC_EARLY_EXIT );
+                            vrc_composite( color, e[s], !act[s] );
+                            if( !FASTR )
+                                cnt += act[s] ? 1u : 0u;
                         }
                     }
                 }
             };
-            const bool fastRound =
+            const bool fastPass =
                 g == VRC_LDS_G &&
                 __builtin_amdgcn_ballot_w64( part && !( travel > stepSize * (float)( VRC_LDS_G + 1 ) ) ) == 0ull;
-            if( fastRound )
+            if( fastPass )
             {
-                if( part ) /* the lanes outside the box keep their state */
-                    marchLds( std::true_type() );
+                VRC_LDS_STAT( 3, 1 )
             }
-            else
-                marchLds( std::false_type() );
-            /* ---- the other lanes with a segment: same steps by gathers from the atlas ------ */
-            const bool strag = hasSeg && !part;
-            if( __builtin_amdgcn_ballot_w64( strag ) != 0ull )
+            if( part ) /* the other lanes keep their state */
             {
-                VRC_LDS_STAT( 2, 1 )
-                vrc_sampler sm; /* only the address constants are used */
-                sm.slotBase = laneSlotBase;
-                sm.cyy = f.sbx * VRC_MB_VOXELS - 64u;
-                sm.czz = f.sbx * f.sby * VRC_MB_VOXELS - 512u;
-#pragma unroll
-                for( int b0 = 0; b0 < VRC_LDS_G; b0 += BATCH )
+                if( fastPass )
                 {
-                    if( b0 < g )
+                    marchLds( std::true_type() );
+                    cnt = g;
+                }
+                else
+                    marchLds( std::false_type() );
+                if( COUNT )
+                    nSamples += cnt;
+            }
+            /* early ray termination (Renderer.cu:219-226), tested once per pass: the opacity never decreases, so
+             * a lane is over the threshold now iff one of its samples of this pass took it there; such a lane
+             * takes its samples again one by one from the colour it came with and stops after the one that
+             * crosses -- the reference's exit */
+            const bool crossed = part && color.w > VRC_EARLY_EXIT;
+            if( __builtin_amdgcn_ballot_w64( crossed ) != 0ull )
+            {
+                if( crossed )
+                {
+                    color = colorIn;
+                    if( COUNT )
+                        nSamples -= cnt;
+                    uint32_t rx = fx - g * fdx, ry = fy - g * fdy, rz = fz - g * fdz;
+                    bool fin = false;
+#pragma unroll 1
+                    for( uint32_t s = 0; s < g; ++s )
                     {
-                        bool act[BATCH];
-                        C e[BATCH];
-                        if( LINEAR )
+                        if( !fin && s < cnt )
                         {
-                            uint32_t ax[BATCH][2], ay[BATCH][2], az[BATCH][2], wfx[BATCH], wfy[BATCH], wfz[BATCH];
-#pragma unroll
-                            for( int s = 0; s < BATCH; ++s )
-                            {
-                                const bool take = strag && ( b0 + s < g );
-                                act[s] = take && travel > 0.0f;
-                                const uint32_t ux = fx >> 24, uy = fy >> 24, uz = fz >> 24;
-#pragma unroll
-                                for( int i = 0; i < 2; ++i )
-                                {
-                                    const uint32_t cx = ux + (uint32_t)i, cy = uy + (uint32_t)i, cz = uz + (uint32_t)i;
-                                    ax[s][i] = vrc_mul24( cx >> VRC_MB_SHIFT, 504u ) + cx;
-                                    ay[s][i] = vrc_mul24( cy >> VRC_MB_SHIFT, sm.cyy ) + ( cy << 3 );
-                                    az[s][i] = vrc_mul24( cz >> VRC_MB_SHIFT, sm.czz ) + ( cz << 6 ) + sm.slotBase;
-                                }
-                                wfx[s] = fx;
-                                wfy[s] = fy;
-                                wfz[s] = fz;
-                                fx += take ? fdx : 0u;
-                                fy += take ? fdy : 0u;
-                                fz += take ? fdz : 0u;
-                                travel -= take ? stepSize : 0.0f;
-                            }
-                            float t[BATCH][8];
-#pragma unroll
-                            for( int s = 0; s < BATCH; ++s )
-#pragma unroll
-                                for( int c = 0; c < 8; ++c )
-                                {
-                                    const uint32_t idx = ax[s][c & 1] + ay[s][( c >> 1 ) & 1] + az[s][c >> 2];
-                                    t[s][c] = (float)atlas[act[s] ? idx : 0u];
-                                }
-#pragma unroll
-                            for( int s = 0; s < BATCH; ++s )
-                            {
-                                const float sc = 1.0f / 16777216.0f;
-                                const float wx = (float)( wfx[s] & 0xFFFFFFu ) * sc;
-                                const float wy = (float)( wfy[s] & 0xFFFFFFu ) * sc;
-                                const float wz = (float)( wfz[s] & 0xFFFFFFu ) * sc;
-                                e[s] = vrc_classify( lut, vrc_trilerp( t[s], wx, wy, wz ), cls );
-                            }
-                        }
-                        else
-                        {
-                            uint32_t idx[BATCH], d[BATCH];
-#pragma unroll
-                            for( int s = 0; s < BATCH; ++s )
-                            {
-                                const bool take = strag && ( b0 + s < g );
-                                act[s] = take && travel > 0.0f;
-                                const uint32_t iv = vrc_voxel_address( sm, fx >> 24, fy >> 24, fz >> 24 );
-                                idx[s] = act[s] ? iv : 0u;
-                                fx += take ? fdx : 0u;
-                                fy += take ? fdy : 0u;
-                                fz += take ? fdz : 0u;
-                                travel -= take ? stepSize : 0.0f;
-                            }
-#pragma unroll
-                            for( int s = 0; s < BATCH; ++s )
-                                d[s] = (uint32_t)atlas[idx[s]];
-#pragma unroll
-                            for( int s = 0; s < BATCH; ++s )
-                                e[s] = lut[act[s] ? d[s] : 256u];
-                        }
-#pragma unroll
-                        for( int s = 0; s < BATCH; ++s )
-                        {
-                            const bool on = act[s] && !done;
-                            vrc_composite( color, e[s], !on );
+                            const uint32_t a = ( rz >> 24 ) * pz + ( ry >> 24 ) * VRC_LDS_PY + ( rx >> 24 ) - bias;
+                            vrc_composite( color, sampleLds( a, rx, ry, rz ) );
                             if( COUNT )
-                                nSamples += on ? 1u : 0u;
-                            done = done || ( on && color.w > VRC_EARLY_EXIT );
+                                nSamples += 1u;
+                            fin = color.w > VRC_EARLY_EXIT;
                         }
+                        rx += fdx;
+                        ry += fdy;
+                        rz += fdz;
                     }
+                    done = true;
                 }
             }
-            if( hasSeg && ( done || !( travel > 0.0f ) ) )
-                hasSeg = false;
-            __builtin_amdgcn_wave_barrier(); /* the next round overwrites the region */
+            inTodo = inTodo && !part;
+            __builtin_amdgcn_wave_barrier(); /* the next pass overwrites the region */
         }
+
+        /* C: lanes no box of this round served: the same steps by byte gathers from the atlas */
+#if defined( VRC_LDS_ABLATE_GATHER ) /* developer timing build: the left-over lanes skip their steps (wrong pixels) */
+        if( inTodo )
+        {
+            fx += 8u * fdx; fy += 8u * fdy; fz += 8u * fdz;
+            travel -= 8.0f * stepSize;
+            inTodo = false;
+        }
+#endif
+        if( __builtin_amdgcn_ballot_w64( inTodo ) != 0ull )
+        {
+            VRC_LDS_STAT( 2, 1 )
+            if( inTodo )
+            {
+                const uint32_t cyy = f.sbx * VRC_MB_VOXELS - 64u;
+                const uint32_t czz = f.sbx * f.sby * VRC_MB_VOXELS - 512u;
+#pragma unroll 1
+                for( int s = 0; s < VRC_LDS_G; ++s )
+                {
+                    const bool act = travel > 0.0f && !done;
+                    C e;
+                    if constexpr( LINEAR )
+                    {
+                        const uint32_t ux = fx >> 24, uy = fy >> 24, uz = fz >> 24;
+                        uint32_t ax[2], ay[2], az[2];
+#pragma unroll
+                        for( int i = 0; i < 2; ++i )
+                        {
+                            const uint32_t cx = ux + (uint32_t)i, cy = uy + (uint32_t)i, cz = uz + (uint32_t)i;
+                            ax[i] = vrc_mul24( cx >> VRC_MB_SHIFT, 504u ) + cx;
+                            ay[i] = vrc_mul24( cy >> VRC_MB_SHIFT, cyy ) + ( cy << 3 );
+                            az[i] = vrc_mul24( cz >> VRC_MB_SHIFT, czz ) + ( cz << 6 ) + laneSlotBase;
+                        }
+                        float t[8];
+#pragma unroll
+                        for( int c = 0; c < 8; ++c )
+                        {
+                            const uint32_t idx = ax[c & 1] + ay[( c >> 1 ) & 1] + az[c >> 2];
+                            t[c] = (float)atlas[act ? idx : 0u];
+                        }
+                        e = lds_classify( (const C*)nullptr, tab, lds_trilerp( t, fx, fy, fz ), lcls );
+                    }
+                    else
+                    {
+                        vrc_sampler sm; /* only the address constants are used */
+                        sm.slotBase = laneSlotBase;
+                        sm.cyy = cyy;
+                        sm.czz = czz;
+                        const uint32_t iv = vrc_voxel_address( sm, fx >> 24, fy >> 24, fz >> 24 );
+                        e = lut[act ? (uint32_t)atlas[iv] : 256u];
+                    }
+                    vrc_composite( color, e, !act );
+                    if( COUNT )
+                        nSamples += act ? 1u : 0u;
+                    done = done || ( act && color.w > VRC_EARLY_EXIT );
+                    fx += fdx;
+                    fy += fdy;
+                    fz += fdz;
+                    travel -= stepSize;
+                }
+            }
+        }
+        if( hasSeg && ( done || !( travel > 0.0f ) ) )
+            hasSeg = false;
     }
 
     if( store )
@@ -764,36 +908,24 @@ hipError_t vrc_launch_raycast_lds( const vrc_raycast_args& a, hipStream_t stream
     const dim3 grid( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_LDS_WAVES - 1u ) / VRC_LDS_WAVES ),
         block( 64u * VRC_LDS_WAVES );
     const bool count = a.sampleCounter != nullptr;
-    /* region shape from the view direction in volume space (the ray through the frame centre) */
-    const vrc_ray centre = vrc_setup_ray( a.frame, a.frame.width / 2u, (uint32_t)( a.frame.vpH * 0.5f ) );
-    bool flat = fabsf( centre.dir.y ) <= 0.94f;
-#if defined( VRC_DEV_KNOBS ) /* A/B builds only (tools/build_variants.sh): VRC_LDS_SHAPE=flat|deep */
-    if( const char* force = getenv( "VRC_LDS_SHAPE" ) )
-        flat = force[0] == 'f';
-#endif
-#define VRC_LDS_LAUNCH( COUNT, LINEAR, SHAPE, GREY )                                                         \
-    hipLaunchKernelGGL( ( vrc_k_raycast_lds< COUNT, LINEAR, SHAPE, GREY > ), grid, block, 0, stream, a.frame, \
-                        a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut, a.classifier,                  \
+#define VRC_LDS_LAUNCH( COUNT, LINEAR, GREY )                                                         \
+    hipLaunchKernelGGL( ( vrc_k_raycast_lds< COUNT, LINEAR, GREY > ), grid, block, 0, stream, a.frame, \
+                        a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut, a.classifier,           \
                         a.pixelBuffer, a.sampleCounter, a.tileOrder, tilesX, nTiles )
-#define VRC_LDS_LAUNCH_SHAPE( COUNT, LINEAR )                                         \
-    {                                                                                 \
-        if( a.greyTable )                                                             \
-        {                                                                             \
-            if( flat ) VRC_LDS_LAUNCH( COUNT, LINEAR, vrc_lds_shape_flat, true );       \
-            else VRC_LDS_LAUNCH( COUNT, LINEAR, vrc_lds_shape_deep, true );             \
-        }                                                                             \
-        else if( flat ) VRC_LDS_LAUNCH( COUNT, LINEAR, vrc_lds_shape_flat, false );     \
-        else VRC_LDS_LAUNCH( COUNT, LINEAR, vrc_lds_shape_deep, false );                \
+#define VRC_LDS_LAUNCH_GREY( COUNT, LINEAR )                        \
+    {                                                               \
+        if( a.greyTable ) VRC_LDS_LAUNCH( COUNT, LINEAR, true );    \
+        else VRC_LDS_LAUNCH( COUNT, LINEAR, false );                \
     }
     if( a.linear )
     {
-        if( count ) VRC_LDS_LAUNCH_SHAPE( true, true ) else VRC_LDS_LAUNCH_SHAPE( false, true )
+        if( count ) VRC_LDS_LAUNCH_GREY( true, true ) else VRC_LDS_LAUNCH_GREY( false, true )
     }
     else
     {
-        if( count ) VRC_LDS_LAUNCH_SHAPE( true, false ) else VRC_LDS_LAUNCH_SHAPE( false, false )
+        if( count ) VRC_LDS_LAUNCH_GREY( true, false ) else VRC_LDS_LAUNCH_GREY( false, false )
     }
-#undef VRC_LDS_LAUNCH_SHAPE
+#undef VRC_LDS_LAUNCH_GREY
 #undef VRC_LDS_LAUNCH
     return hipGetLastError();
 }

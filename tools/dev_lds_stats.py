@@ -27,15 +27,11 @@ with GpuScene(s) as g:
     fn(out, 1)
     fb, n, st = g.render(kernel=vrc.KERNEL_LDS, filter_mode=a.filter, count=True)
     fn(out, 1)
-    rounds, sumg, shrunk, fits, aloop, lanes, vol, dz = list(out)
+    passes, todo0, gathers, fast, cand0, lanes, rounds, part0 = list(out)
     print("samples %d kernel_ms %.3f" % (n, st.kernel_ms))
-    print("rounds %d  mean g %.2f  rounds with shrunk lane set %d  fit iterations/round %.2f" %
-          (rounds, sumg / max(rounds, 1), shrunk, fits / max(rounds, 1)))
-    print("A-loop iterations %d  mean participating lanes %.1f  samples/round %.1f" %
-          (aloop, lanes / max(rounds, 1), n / max(rounds, 1)))
-    print("mean box volume %.0f B  mean dz %.2f" % (vol / max(rounds, 1), dz / max(rounds, 1)))
-    lg = g.L.vrc_debug_lds_log
-    buf = (C.c_uint * (64 * 16))()
-    lg(buf)
-    for i in range(40):
-        print("fit %2d:" % i, list(buf[i * 16:(i + 1) * 16]))
+    print("rounds %d  box passes %d (%.2f per round, %d of them fast)  rounds that ended in the gather path %d" %
+          (rounds, passes, passes / max(rounds, 1), fast, gathers))
+    print("first pass of a round, lanes: with steps to take %.1f, of them in the lead's brick %.1f, of them in the window %.1f"
+          % (todo0 / max(rounds, 1), cand0 / max(rounds, 1), part0 / max(rounds, 1)))
+    print("mean participating lanes per pass %.1f  samples/pass %.1f  samples/round %.1f" %
+          (lanes / max(passes, 1), n / max(passes, 1), n / max(rounds, 1)))
