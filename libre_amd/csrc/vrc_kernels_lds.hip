@@ -63,7 +63,15 @@
 #define VRC_LDS_ROWS 264u
 #define VRC_LDS_REGION ( VRC_LDS_PY * VRC_LDS_ROWS )
 #define VRC_LDS_MAX_DY 32u /* 16 row pairs: one per staging lane group */
+#ifndef VRC_LDS_MAX_DZ
 #define VRC_LDS_MAX_DZ 22u /* two staging halves of 11 slice loads in flight */
+#endif
+#ifndef VRC_LDS_KMAX
+#define VRC_LDS_KMAX 8u /* steps of the lead a box is extended by at most (measured on C2, ms per frame: 4: 2.78, 6: 2.29,
+                          * 7: 2.16, 8: 2.05, 12: 2.37, 15: 2.61, 20: 2.60 -- deep boxes are staged in two halves, one
+                          * after the other, and the lanes of another brick take 8 steps per round whatever the box does) */
+#endif
+#define VRC_LDS_NMAX 30u /* steps a lane takes in one pass at most (one-hot in 32 bits) */
 #ifndef VRC_LDS_WAVES
 #define VRC_LDS_WAVES 4u
 #endif
@@ -95,6 +103,25 @@ extern "C" int vrc_debug_lds_stats( unsigned long long out[8], int reset )
 #else
 #define VRC_LDS_STAT( I, V ) {} /* a statement in both builds: `if( c ) VRC_LDS_STAT(..)` must not swallow what follows */
 #endif
+#if defined( VRC_LDS_TIMING ) /* developer build only */
+/* wave cycles per phase (s_memtime; a wave's stalls are charged to the phase it stalls in) */
+__device__ unsigned long long vrc_lds_phase[8];
+extern "C" int vrc_debug_lds_phases( unsigned long long out[8], int reset )
+{
+    if( hipMemcpyFromSymbol( out, HIP_SYMBOL( vrc_lds_phase ), sizeof( unsigned long long ) * 8 ) != hipSuccess )
+        return 1;
+    if( reset )
+    {
+        const unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        if( hipMemcpyToSymbol( HIP_SYMBOL( vrc_lds_phase ), z, sizeof( z ) ) != hipSuccess )
+            return 1;
+    }
+    return 0;
+}
+#define VRC_LDS_PHASE( I ) { const unsigned long long now_ = __builtin_readcyclecounter(); phaseAcc[phaseCur] += now_ - phaseT0; phaseT0 = now_; phaseCur = I; }
+#else
+#define VRC_LDS_PHASE( I ) {}
+#endif
 
 namespace
 {
@@ -114,22 +141,27 @@ __device__ __forceinline__ uint32_t wave_or( uint32_t v )
 }
 
 /* copy N z-slices of the box: per lane one 16-byte piece (two 8-voxel rows) per slice */
-template < int N >
+/* between: work that does not depend on the box's voxels, done while the loads are on their way */
+template < int N, typename F >
 __device__ __forceinline__ void lds_stage( const uint8_t* __restrict__ slotPtr, uint32_t partial,
                                            uint32_t sliceStride, uint32_t z0, uint32_t dz, bool on,
-                                           uint8_t* dst, uint32_t pz )
+                                           uint8_t* dst, uint32_t pz, F between )
 {
+    uint4 v[N];
+    if( on )
+    {
+#pragma unroll
+        for( int z = 0; z < N; ++z )
+        {
+            const uint32_t zc = (uint32_t)z < dz ? (uint32_t)z : dz - 1u;
+            const uint32_t zz = z0 + zc;
+            const uint8_t* const zb = slotPtr + ( ( zz >> VRC_MB_SHIFT ) * sliceStride + ( ( zz & 7u ) << 6 ) );
+            v[z] = *reinterpret_cast< const uint4* >( zb + partial );
+        }
+    }
+    between();
     if( !on )
         return;
-    uint4 v[N];
-#pragma unroll
-    for( int z = 0; z < N; ++z )
-    {
-        const uint32_t zc = (uint32_t)z < dz ? (uint32_t)z : dz - 1u;
-        const uint32_t zz = z0 + zc;
-        const uint8_t* const zb = slotPtr + ( ( zz >> VRC_MB_SHIFT ) * sliceStride + ( ( zz & 7u ) << 6 ) );
-        v[z] = *reinterpret_cast< const uint4* >( zb + partial );
-    }
 #pragma unroll
     for( int z = 0; z < N; ++z )
     {
@@ -281,6 +313,10 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
     if( slot >= vrc_schedule_slots( tilesX, tilesY ) )
         return;
     uint8_t* const region = regions[wave];
+#if defined( VRC_LDS_TIMING )
+    unsigned long long phaseAcc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, phaseT0 = __builtin_readcyclecounter();
+    int phaseCur = 6;
+#endif
 
     const uint32_t tile = vrc_slot_tile( tileOrder, slot, tilesX, tilesY );
     if( tile == VRC_NO_TILE ) /* the waves of a workgroup are independent from here on */
@@ -315,8 +351,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
             store = true; /* the folded clear: a missed pixel is written as 0 */
     }
 
-    int cell[3] = { 0, 0, 0 }, stepDir[3] = { 1, 1, 1 };
-    float tMax[3] = { 0.f, 0.f, 0.f }, tDelta[3] = { 0.f, 0.f, 0.f };
+    int cell[3] = { 0, 0, 0 };
+    float tMax[3] = { 0.f, 0.f, 0.f };
     float t0 = 0.0f, t1 = 0.0f;
     uint32_t back = 0u;
     bool ddaEnd = false;
@@ -352,7 +388,6 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                 const float p = o[a] + d[a] * t0;
                 const float u = ( p - f.gridMin[a] ) * f.invCellSize[a];
                 const bool pos = d[a] > 0.0f;
-                stepDir[a] = pos ? 1 : -1;
                 const float kf = rintf( u );
                 const float tFace = ( ( f.gridMin[a] + f.cellSize[a] * kf ) - o[a] ) * id[a];
                 int c = (int)floorf( u );
@@ -366,14 +401,23 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                 cell[a] = c;
                 const float boundary = f.gridMin[a] + f.cellSize[a] * (float)( pos ? c + 1 : c );
                 tMax[a] = ( boundary - o[a] ) * id[a];
-                tDelta[a] = f.cellSize[a] * fabsf( id[a] );
             }
         }
     }
 
     /* ---- per-lane segment state ---------------------------------------------------------- */
-    bool hasSeg = false;
-    int32_t curNode = -1;
+    /* A lane marches its CURRENT brick segment and holds the NEXT one ready (round 3).  Round 2 walked to the next
+     * brick only when a lane had run out of steps, and batched those walks (the walk is ~500 instructions for the whole
+     * wave): a lane that left its brick through a side face -- on BASELINE C2 the brick borders sweep across a third of
+     * the rays inside every slab of bricks -- waited for company while the rest of its tile marched on, stayed one or
+     * more rounds behind them in depth for the rest of the slab, fell outside their box round after round and took its
+     * steps by gathers (30 % of the rounds had such lanes; the gather path was 0.68 of the kernel's 2.36 ms).  With
+     * the next segment in registers a lane never waits, the walks stay batched (they now run AHEAD of need), and the
+     * lanes of a tile stay within a step of each other in depth. */
+    bool hasSeg = false, hasPend = false, walkDone = done;
+    int32_t curNode = -1, pNode = -1;
+    uint32_t pfx = 0, pfy = 0, pfz = 0, pfdx = 0, pfdy = 0, pfdz = 0, pSlotBase = 0;
+    float pTravel = 0.0f;
     /* bricks already handed to the slab test; probe: what the walk does next at its cell (0: the cell
      * itself, 1..6: the cells around an edge / corner the ray leaves through, see vrc_pixel_grid_dda) */
     int32_t recent0 = -1, recent1 = -1, recent2 = -1, recent3 = -1;
@@ -403,28 +447,61 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
     {
         if( roundBudget-- == 0u )
             break;
-        /* A: live lanes without a segment walk their DDA to the next brick they sample.  The
-         * walk (ray/box set-up, ~200 instructions) is shared by the wave, so lanes that
-         * finish a brick early wait for company (VRC_LDS_REFILL lanes) or for the others to
-         * run dry, as the lanes of the gather kernel wait at the end of a brick's march loop. */
-        bool refill; /* wave-uniform */
-        {
-            const uint64_t needMask = __builtin_amdgcn_ballot_w64( !done && !hasSeg );
-            const uint64_t haveMask = __builtin_amdgcn_ballot_w64( hasSeg );
-            /* lanes that leave their brick within the next round: waiting for them keeps the
-             * wave in step (lanes that enter a brick one round apart are 8 voxels apart in
-             * depth for the rest of it and never share a box again) */
-            const uint64_t soonMask = __builtin_amdgcn_ballot_w64(
-                hasSeg && !( travel > stepSize * (float)VRC_LDS_G ) );
-            refill = !( needMask != 0ull && haveMask != 0ull &&
-                        ( __builtin_popcountll( needMask ) < VRC_LDS_REFILL || soonMask != 0ull ) );
-        }
-        while( refill && __builtin_amdgcn_ballot_w64( !done && !hasSeg ) != 0ull )
-        {
+        /* A: walks.  A lane without a NEXT segment walks its DDA to the next brick it samples -- while it still marches
+         * its current one.  The walk (ray/box set-up, ~500 instructions) is shared by the wave, so walks are batched:
+         * one runs when VRC_LDS_REFILL lanes lack a next segment, when such a lane's current segment ends within the
+         * coming round, or when a lane has nothing to march at all. */
+        auto promote = [&]() {
             if( !done && !hasSeg )
             {
-                if( ddaEnd || --budget < 0 )
+                if( hasPend )
+                {
+                    fx = pfx; fy = pfy; fz = pfz;
+                    fdx = pfdx; fdy = pfdy; fdz = pfdz;
+                    travel = pTravel;
+                    curNode = pNode;
+                    laneSlotBase = pSlotBase;
+                    hasSeg = true;
+                    hasPend = false;
+                }
+                else if( walkDone )
                     done = true;
+            }
+        };
+        promote();
+        bool refill; /* wave-uniform */
+        {
+            const bool lack = !done && !walkDone && !hasPend;
+            const uint64_t lackMask = __builtin_amdgcn_ballot_w64( lack );
+            const uint64_t idleMask = __builtin_amdgcn_ballot_w64( lack && !hasSeg );
+            const uint64_t soonMask = __builtin_amdgcn_ballot_w64(
+                lack && hasSeg && !( travel > stepSize * (float)( 2 * VRC_LDS_G ) ) );
+            refill = idleMask != 0ull || soonMask != 0ull || __builtin_popcountll( lackMask ) >= VRC_LDS_REFILL;
+        }
+        while( refill )
+        {
+            VRC_LDS_PHASE( 0 )
+            /* the ray and what follows from it are set up again for every walk instead of being kept in ~18
+             * registers across the march (same function of the same pixel: same bits); the pixel is passed
+             * through an empty asm so that the compiler does not hoist the set-up out of the loop again */
+            VRC_LDS_STAT( 3, 1 )
+            uint32_t pxw = px, pyw = py;
+            asm volatile( "" : "+v"( pxw ), "+v"( pyw ) );
+            /* ... and the frame constants the walk needs (the two 4x4 matrices, boxes, planes: ~100 scalars) are read
+             * from the kernel-argument segment here, inside the loop, through a pointer the compiler cannot see
+             * through: held in scalar registers across the march they spilled into vector lanes by the dozen */
+            const __attribute__( ( address_space( 4 ) ) ) vrc_frame* fwp =
+                (const __attribute__( ( address_space( 4 ) ) ) vrc_frame*)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile( "" : "+s"( fwp ) );
+            const vrc_frame& fw = *(const vrc_frame*)fwp;
+            const vrc_ray r = vrc_setup_ray( fw, pxw, fw.rowMap ? fw.rowMap[pyw] : pyw );
+            const int stepDir[3] = { r.dir.x > 0.0f ? 1 : -1, r.dir.y > 0.0f ? 1 : -1, r.dir.z > 0.0f ? 1 : -1 };
+            const float tDelta[3] = { fw.cellSize[0] * fabsf( r.invDir.x ), fw.cellSize[1] * fabsf( r.invDir.y ),
+                                      fw.cellSize[2] * fabsf( r.invDir.z ) };
+            if( !done && !walkDone && !hasPend )
+            {
+                if( ddaEnd || --budget < 0 )
+                    walkDone = true;
                 else
                 {
                     /* the walk of vrc_pixel_grid_dda (vrc_core.h), one candidate cell per iteration: the cells
@@ -442,8 +519,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                         cx += ( sub & 1u ) ? sgn * stepDir[0] : 0;
                         cy += ( sub & 2u ) ? sgn * stepDir[1] : 0;
                         cz += ( sub & 4u ) ? sgn * stepDir[2] : 0;
-                        look = cx >= 0 && cx < f.gridDim[0] && cy >= 0 && cy < f.gridDim[1] && cz >= 0 &&
-                               cz < f.gridDim[2];
+                        look = cx >= 0 && cx < fw.gridDim[0] && cy >= 0 && cy < fw.gridDim[1] && cz >= 0 &&
+                               cz < fw.gridDim[2];
                     }
                     else
                     {
@@ -466,8 +543,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                                 tMax[2] += tDelta[2];
                             }
                             walk = 0u;
-                            ddaEnd = cell[0] < 0 || cell[0] >= f.gridDim[0] || cell[1] < 0 ||
-                                     cell[1] >= f.gridDim[1] || cell[2] < 0 || cell[2] >= f.gridDim[2];
+                            ddaEnd = cell[0] < 0 || cell[0] >= fw.gridDim[0] || cell[1] < 0 ||
+                                     cell[1] >= fw.gridDim[1] || cell[2] < 0 || cell[2] >= fw.gridDim[2];
                         }
                         if( !ddaEnd )
                         {
@@ -489,7 +566,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                             }
                         }
                     }
-                    const int32_t node = look ? gridTable[( cz * f.gridDim[1] + cy ) * f.gridDim[0] + cx] : -1;
+                    const int32_t node = look ? gridTable[( cz * fw.gridDim[1] + cy ) * fw.gridDim[0] + cx] : -1;
                     if( node >= 0 && node != recent0 && node != recent1 && node != recent2 && node != recent3 )
                     {
                         recent3 = recent2;
@@ -499,38 +576,42 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                         const vrc_dev_node n = nodes[node];
                         vrc_segment s;
                         bool stop;
-                        if( vrc_brick_segment( f, r, n, stepSize, &s, &stop ) )
+                        if( vrc_brick_segment( fw, r, n, stepSize, &s, &stop ) )
                         {
                             if( s.dist > 0.0f )
                             {
-                                const vrc_sampler sm = vrc_make_sampler( n, f );
+                                const vrc_sampler sm = vrc_make_sampler( n, fw );
                                 /* same first-sample voxel as the gather kernel */
                                 const vrc_fixpos p0 = vrc_fixpos_init( sm, s.pos, s.step );
                                 /* trilinear: texel centres at i + 0.5 */
                                 const uint32_t h = LINEAR ? ( 1u << 23 ) : 0u;
-                                fx = p0.x - h;
-                                fy = p0.y - h;
-                                fz = p0.z - h;
-                                fdx = p0.dx;
-                                fdy = p0.dy;
-                                fdz = p0.dz;
-                                travel = s.dist;
-                                curNode = node;
-                                laneSlotBase = n.slotBase;
-                                hasSeg = true;
+                                pfx = p0.x - h;
+                                pfy = p0.y - h;
+                                pfz = p0.z - h;
+                                pfdx = p0.dx;
+                                pfdy = p0.dy;
+                                pfdz = p0.dz;
+                                pTravel = s.dist;
+                                pNode = node;
+                                pSlotBase = n.slotBase;
+                                hasPend = true;
                             }
                         }
                         else if( stop )
-                            done = true;
+                            walkDone = true; /* the reference leaves its brick loop here (Renderer.cu:183-184) */
                     }
                     if( endAfter )
                         ddaEnd = true;
                 }
             }
+            /* a lane that had nothing to march takes what it found; the walks go on while such lanes remain */
+            promote();
+            refill = __builtin_amdgcn_ballot_w64( !done && !walkDone && !hasPend && !hasSeg ) != 0ull;
         }
 
-        /* B: one round: up to VRC_LDS_G steps of every lane that has a segment, in up to VRC_LDS_PASSES
-         * passes through an LDS box each; what is left after the last pass takes its steps by gathers */
+        VRC_LDS_PHASE( 6 )
+        /* B: one round: every lane that has a segment takes steps through an LDS box (up to VRC_LDS_PASSES boxes);
+         * what no box served takes VRC_LDS_G steps by gathers */
         if( __builtin_amdgcn_ballot_w64( hasSeg ) == 0ull )
             break;
         bool inTodo = hasSeg;
@@ -540,117 +621,142 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
             if( todoMask == 0ull )
                 break;
             /* the lead: the tile centre if it still has steps to take in this round */
+            VRC_LDS_PHASE( 1 )
             const uint32_t lead = ( todoMask >> 15 ) & 1ull ? 15u
                                   : ( ( todoMask >> 48 ) & 1ull ? 48u : (uint32_t)__builtin_ctzll( todoMask ) );
             const int32_t brick = __builtin_amdgcn_readlane( curNode, lead );
             const uint8_t* const slotPtr = atlas + (uint32_t)__builtin_amdgcn_readlane( (int)laneSlotBase, lead );
+            constexpr uint32_t EXT = LINEAR ? 1u : 0u; /* the taps of a sample reach one voxel further */
 
-            /* voxels touched by the lane's next g samples -- all g of them, whether or not the lane's segment
-             * ends earlier (the march then reads inside the box for every lane and step and needs no address
-             * select); g is halved until the lead's own footprint fits the region */
-            uint32_t g = VRC_LDS_G;
-            uint32_t lox, hix, loy, hiy, loz, hiz;
-            uint32_t llx, lhx, lly, lhy, llz, lhz;
-            for( ;; )
-            {
-                const uint32_t k = g - 1u;
-                const uint32_t ex = fx + k * fdx, ey = fy + k * fdy, ez = fz + k * fdz;
-                const uint32_t ax = fx >> 24, ay = fy >> 24, az = fz >> 24;
-                const uint32_t bx = ex >> 24, by = ey >> 24, bz = ez >> 24;
-                const uint32_t ext = LINEAR ? 1u : 0u;
-                lox = ax < bx ? ax : bx; hix = ( ax < bx ? bx : ax ) + ext;
-                loy = ay < by ? ay : by; hiy = ( ay < by ? by : ay ) + ext;
-                loz = az < bz ? az : bz; hiz = ( az < bz ? bz : az ) + ext;
-                /* steps past the end of a segment may leave the slot: keep the copy inside it */
-                hix = hix < f.slotDim[0] - 1u ? hix : f.slotDim[0] - 1u;
-                hiy = hiy < f.slotDim[1] - 1u ? hiy : f.slotDim[1] - 1u;
-                hiz = hiz < f.slotDim[2] - 1u ? hiz : f.slotDim[2] - 1u;
-                lox = lox < hix ? lox : hix;
-                loy = loy < hiy ? loy : hiy;
-                loz = loz < hiz ? loz : hiz;
-                llx = (uint32_t)__builtin_amdgcn_readlane( (int)lox, lead );
-                lhx = (uint32_t)__builtin_amdgcn_readlane( (int)hix, lead );
-                lly = (uint32_t)__builtin_amdgcn_readlane( (int)loy, lead );
-                lhy = (uint32_t)__builtin_amdgcn_readlane( (int)hiy, lead );
-                llz = (uint32_t)__builtin_amdgcn_readlane( (int)loz, lead );
-                lhz = (uint32_t)__builtin_amdgcn_readlane( (int)hiz, lead );
-                /* the lead's own steps must fit: pieces are aligned to 8 in x, row pairs to 2 in y */
-                {
-                    const uint32_t ey2 = ( ( lhy | 1u ) - ( lly & ~1u ) + 1u ), ez1 = lhz - llz + 1u;
-                    if( ( lhx - llx + 8u <= VRC_LDS_PY && ey2 <= VRC_LDS_MAX_DY && ez1 <= VRC_LDS_MAX_DZ &&
-                          ey2 * ez1 <= VRC_LDS_ROWS ) || g == 1u )
-                        break;
-                }
-                g >>= 1;
-            }
-            /* Candidates: the lanes of the lead's brick whose steps lie within 32 voxels / 32 rows / 32 slices around
-             * the lead's (all scalar).  Two wave-wide ORs (six DPP steps each) of bit masks relative to that
-             * neighbourhood -- the slices; the row pairs and 8-voxel pieces each lane touches -- give the box of
-             * all of them. */
-            const uint32_t ex_ = lhx - llx + 1u, ey_ = lhy - lly + 1u, ez_ = lhz - llz + 1u;
-            const uint32_t sx = ex_ < VRC_LDS_PY - 7u ? ( VRC_LDS_PY - 7u - ex_ ) / 2u : 0u;
-            const uint32_t sy = ey_ < 31u ? ( 31u - ey_ ) / 2u : 0u;
-            const uint32_t sz = ez_ < 32u ? ( 32u - ez_ ) / 2u : 0u;
-            const uint32_t wx0 = ( llx - ( llx < sx ? llx : sx ) ) & ~7u;
-            const uint32_t wy0 = ( lly - ( lly < sy ? lly : sy ) ) & ~1u;
-            const uint32_t wz0 = llz - ( llz < sz ? llz : sz );
-            const bool cand = inTodo && curNode == brick && lox >= wx0 && hix < wx0 + VRC_LDS_PY && loy >= wy0 &&
-                              hiy < wy0 + 32u && loz >= wz0 && hiz < wz0 + 32u;
+            /* ---- the box: where the lanes ARE, extended along the march ------------------------------------
+             * Candidates: the lanes of the lead's brick whose current sample lies within 32 voxels around the
+             * lead's, per axis.  Three wave-wide ORs (six DPP steps each) of one-hot voxel masks relative to that
+             * neighbourhood give the bounding box of their current samples; it is extended in the direction of the
+             * march by as many steps (of the lead) as the region holds.  A lane then takes steps until its sample
+             * leaves the box (below): lanes that are behind the others in depth -- a lane changes bricks in the
+             * middle of a round -- take more steps than those ahead and the tile is level again after the pass,
+             * and where the tile is small (10 x 10 voxels across at the front of BASELINE C2's volume against
+             * 18 x 18 at its back) the box is deep and a pass is long. */
+            const uint32_t ax = fx >> 24, ay = fy >> 24, az = fz >> 24;
+            const uint32_t lax = (uint32_t)__builtin_amdgcn_readlane( (int)ax, lead );
+            const uint32_t lay = (uint32_t)__builtin_amdgcn_readlane( (int)ay, lead );
+            const uint32_t laz = (uint32_t)__builtin_amdgcn_readlane( (int)az, lead );
+            const int32_t ldx = __builtin_amdgcn_readlane( (int)fdx, lead ), ldy = __builtin_amdgcn_readlane( (int)fdy, lead ),
+                          ldz = __builtin_amdgcn_readlane( (int)fdz, lead );
+            const uint32_t wx0 = lax > 15u ? lax - 15u : 0u, wy0 = lay > 15u ? lay - 15u : 0u,
+                           wz0 = laz > 15u ? laz - 15u : 0u;
+            const bool cand = inTodo && curNode == brick && ax >= wx0 && ax + EXT < wx0 + 32u && ay >= wy0 &&
+                              ay + EXT < wy0 + 32u && az >= wz0 && az + EXT < wz0 + 32u;
+            const uint32_t one = LINEAR ? 3u : 1u;
+            const uint32_t xm = wave_or( cand ? one << ( ax - wx0 ) : 0u );
+            const uint32_t ym = wave_or( cand ? one << ( ay - wy0 ) : 0u );
+            const uint32_t zm = wave_or( cand ? one << ( az - wz0 ) : 0u );
+            /* inclusive voxel ranges of the samples' taps; the lead is a candidate, so no mask is empty */
+            uint32_t bx0 = wx0 + (uint32_t)__builtin_ctz( xm ), bx1 = wx0 + 31u - (uint32_t)__builtin_clz( xm );
+            uint32_t by0 = wy0 + (uint32_t)__builtin_ctz( ym ), by1 = wy0 + 31u - (uint32_t)__builtin_clz( ym );
+            uint32_t bz0 = wz0 + (uint32_t)__builtin_ctz( zm ), bz1 = wz0 + 31u - (uint32_t)__builtin_clz( zm );
             lds_box box;
             {
-                const uint32_t zb = ( ( 2u << ( hiz - loz ) ) - 1u ) << ( loz - wz0 );
-                const uint32_t p0 = ( loy - wy0 ) >> 1, p1 = ( hiy - wy0 ) >> 1;
-                const uint32_t yb = ( ( 2u << ( p1 - p0 ) ) - 1u ) << p0;
-                const uint32_t q0 = ( lox - wx0 ) >> 3, q1 = ( hix - wx0 ) >> 3;
-                const uint32_t xb = ( ( 2u << ( q1 - q0 ) ) - 1u ) << ( q0 + 16u );
-                const uint32_t zm = wave_or( cand ? zb : 0u );
-                const uint32_t yx = wave_or( cand ? ( yb | xb ) : 0u );
-                const uint32_t ym = yx & 0xFFFFu, xm = yx >> 16;
-                uint32_t zlo = (uint32_t)__builtin_ctz( zm ), zhi = 31u - (uint32_t)__builtin_clz( zm );
-                uint32_t ylo = (uint32_t)__builtin_ctz( ym ), yhi = 31u - (uint32_t)__builtin_clz( ym );
-                const uint32_t xlo = (uint32_t)__builtin_ctz( xm ), xhi = 31u - (uint32_t)__builtin_clz( xm );
-                /* More rows x slices than the region holds (or more slices than the staging loop loads): take
-                 * slices / row pairs off the side that reaches furthest beyond the lead's own; the lanes that
-                 * needed them get the next pass.  Scalar, and it ends at the lead's own box, which fits. */
-                const uint32_t lz0 = llz - wz0, lz1 = lhz - wz0, lp0 = ( lly - wy0 ) >> 1, lp1 = ( lhy - wy0 ) >> 1;
-                for( ;; )
+                /* does a box fit the region: pieces of 8 voxels in x, row pairs in y */
+                auto fits = [&]( uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1 ) {
+                    const uint32_t dx = ( x1 | 7u ) - ( x0 & ~7u ) + 1u, dy = ( y1 | 1u ) - ( y0 & ~1u ) + 1u, dz = z1 - z0 + 1u;
+                    return dx <= VRC_LDS_PY && dy <= VRC_LDS_MAX_DY && dz <= VRC_LDS_MAX_DZ && dy * dz <= VRC_LDS_ROWS;
+                };
+                /* the samples as they are do not fit (lanes far apart): give up the voxels furthest from the
+                 * lead's sample, one slab at a time; the lanes that needed them are left for the next pass */
+                while( !fits( bx0, bx1, by0, by1, bz0, bz1 ) )
                 {
-                    const uint32_t dz = zhi - zlo + 1u, dy = 2u * ( yhi - ylo + 1u );
-                    if( dz <= VRC_LDS_MAX_DZ && dy * dz <= VRC_LDS_ROWS )
+                    const uint32_t s0 = lax - bx0, s1 = bx1 - ( lax + EXT ), s2 = lay - by0, s3 = by1 - ( lay + EXT ),
+                                   s4 = laz - bz0, s5 = bz1 - ( laz + EXT );
+                    const uint32_t mxy = ( s0 > s1 ? s0 : s1 ) > ( s2 > s3 ? s2 : s3 ) ? ( s0 > s1 ? s0 : s1 ) : ( s2 > s3 ? s2 : s3 );
+                    const uint32_t m = mxy > ( s4 > s5 ? s4 : s5 ) ? mxy : ( s4 > s5 ? s4 : s5 );
+                    if( m == 0u )
+                        break; /* the lead's own taps: 2 x 2 x 2 voxels always fit */
+                    if( s0 == m ) ++bx0;
+                    else if( s1 == m ) --bx1;
+                    else if( s2 == m ) ++by0;
+                    else if( s3 == m ) --by1;
+                    else if( s4 == m ) ++bz0;
+                    else --bz1;
+                }
+                /* extend by the movement of k steps of the lead (rounded up, plus what the other lanes' slightly
+                 * different directions can add), k as large as fits; an axis along which the tile hardly moves
+                 * is extended by a voxel on both sides (its lanes may move either way) */
+                const uint32_t mx_ = (uint32_t)( ldx < 0 ? -ldx : ldx ), my_ = (uint32_t)( ldy < 0 ? -ldy : ldy ),
+                               mz_ = (uint32_t)( ldz < 0 ? -ldz : ldz );
+                const uint32_t hx = f.slotDim[0] - 1u, hy = f.slotDim[1] - 1u, hz = f.slotDim[2] - 1u;
+                uint32_t ex0 = bx0, ex1 = bx1, ey0 = by0, ey1 = by1, ez0 = bz0, ez1 = bz1;
+                for( uint32_t k = VRC_LDS_KMAX; k > 0u; k = k > 8u ? k - 4u : ( k > 4u ? k - 2u : k - 1u ) )
+                {
+                    auto reach = [&]( uint32_t m ) { return (uint32_t)( ( (uint64_t)m * k + ( m >> 6 ) * k + 0xFFFFFFull ) >> 24 ); };
+                    const uint32_t rx = reach( mx_ ), ry = reach( my_ ), rz = reach( mz_ );
+                    const bool bothx = mx_ * k < ( 1u << 24 ), bothy = my_ * k < ( 1u << 24 ), bothz = mz_ * k < ( 1u << 24 );
+                    const uint32_t nx0 = ( ldx < 0 || bothx ) ? ( bx0 > rx ? bx0 - rx : 0u ) : bx0;
+                    const uint32_t nx1 = ( ldx >= 0 || bothx ) ? ( bx1 + rx < hx ? bx1 + rx : hx ) : bx1;
+                    const uint32_t ny0 = ( ldy < 0 || bothy ) ? ( by0 > ry ? by0 - ry : 0u ) : by0;
+                    const uint32_t ny1 = ( ldy >= 0 || bothy ) ? ( by1 + ry < hy ? by1 + ry : hy ) : by1;
+                    const uint32_t nz0 = ( ldz < 0 || bothz ) ? ( bz0 > rz ? bz0 - rz : 0u ) : bz0;
+                    const uint32_t nz1 = ( ldz >= 0 || bothz ) ? ( bz1 + rz < hz ? bz1 + rz : hz ) : bz1;
+                    if( fits( nx0, nx1, ny0, ny1, nz0, nz1 ) )
+                    {
+                        ex0 = nx0; ex1 = nx1; ey0 = ny0; ey1 = ny1; ez0 = nz0; ez1 = nz1;
                         break;
-                    const uint32_t sz0 = lz0 - zlo, sz1 = zhi - lz1, sy0 = 2u * ( lp0 - ylo ), sy1 = 2u * ( yhi - lp1 );
-                    const uint32_t mz = sz0 > sz1 ? sz0 : sz1, my = sy0 > sy1 ? sy0 : sy1;
-                    if( dz > VRC_LDS_MAX_DZ || ( mz >= my && mz > 0u ) )
-                    {
-                        if( sz0 > sz1 ) ++zlo; else --zhi;
-                    }
-                    else
-                    {
-                        if( sy0 > sy1 ) ++ylo; else --yhi;
                     }
                 }
-                box.x0 = wx0 + 8u * xlo;
-                box.dx = 8u * ( xhi - xlo + 1u );
-                box.y0 = wy0 + 2u * ylo;
-                box.dy = 2u * ( yhi - ylo + 1u );
-                box.z0 = wz0 + zlo;
-                box.dz = zhi - zlo + 1u;
+                box.x0 = ex0 & ~7u;
+                box.dx = ( ex1 | 7u ) - box.x0 + 1u;
+                box.y0 = ey0 & ~1u;
+                box.dy = ( ey1 | 1u ) - box.y0 + 1u;
+                box.z0 = ez0;
+                box.dz = ez1 - ez0 + 1u;
             }
-            const bool part = cand && loy >= box.y0 && hiy < box.y0 + box.dy && loz >= box.z0 && hiz < box.z0 + box.dz;
+            /* ---- steps a lane takes in this pass: until its sample's taps leave the box -----------------------
+             * Per axis the number of steps k >= 0 with lo <= voxel(f + k d) and voxel(f + k d) + EXT <= hi, from a
+             * float quotient, then made exact: the last of them must be inside (integer arithmetic, two
+             * corrections at most: the quotient is good to a step). */
+            uint32_t nSteps = 0, nMin = 0, nMax = 0;
+            bool part = false;
+            auto countSteps = [&]() {
+                const uint32_t lo[3] = { box.x0, box.y0, box.z0 };
+                const uint32_t hi[3] = { box.x0 + box.dx - 1u - EXT, box.y0 + box.dy - 1u - EXT, box.z0 + box.dz - 1u - EXT };
+                const uint32_t p[3] = { fx, fy, fz }, d[3] = { fdx, fdy, fdz };
+                float nf = (float)VRC_LDS_NMAX;
+                bool inside = cand;
+#pragma unroll
+                for( int a = 0; a < 3; ++a )
+                {
+                    const uint32_t v = p[a] >> 24;
+                    inside = inside && v >= lo[a] && v <= hi[a];
+                    const int32_t sd = (int32_t)d[a];
+                    /* distance to the face the lane moves towards, in 2^-24 voxels; voxel hi is left at (hi+1) << 24 */
+                    const uint32_t dist = sd < 0 ? p[a] - ( lo[a] << 24 ) : ( ( hi[a] + 1u ) << 24 ) - 1u - p[a];
+                    const uint32_t mag = (uint32_t)( sd < 0 ? -sd : sd );
+                    const float q = (float)dist * __builtin_amdgcn_rcpf( (float)mag ); /* mag = 0: inf */
+                    nf = fminf( nf, q );
+                }
+                uint32_t n = inside ? (uint32_t)nf + 1u : 0u; /* steps 0 .. floor(q) */
+                n = n > VRC_LDS_NMAX ? VRC_LDS_NMAX : n;
+                /* the float quotient is good to a fraction of a step: if the last step it allows is outside after
+                 * all, the one before it is inside */
+                {
+                    const uint32_t k = n > 0u ? n - 1u : 0u;
+                    bool ok = true;
+#pragma unroll
+                    for( int a = 0; a < 3; ++a )
+                    {
+                        const uint32_t v = ( p[a] + k * d[a] ) >> 24;
+                        ok = ok && v >= lo[a] && v <= hi[a];
+                    }
+                    nSteps = ( n > 1u && !ok ) ? n - 1u : n;
+                }
+                part = nSteps > 0u;
+                /* fewest and most steps of the participating lanes, from one OR of one-hot masks */
+                const uint32_t nm = wave_or( part ? 1u << nSteps : 0u );
+                nMin = (uint32_t)__builtin_ctz( nm );
+                nMax = 31u - (uint32_t)__builtin_clz( nm );
+            };
             const uint32_t pz = VRC_LDS_PY * box.dy; /* slice pitch of this pass */
-            VRC_LDS_STAT( 0, 1 )
-            {
-                [[maybe_unused]] const uint64_t cm_ = __builtin_amdgcn_ballot_w64( inTodo && curNode == brick );
-                VRC_LDS_STAT( 1, pass == 0 ? __builtin_popcountll( todoMask ) : 0 )
-                VRC_LDS_STAT( 4, pass == 0 ? __builtin_popcountll( cm_ ) : 0 )
-                [[maybe_unused]] const uint64_t p0_ = __builtin_amdgcn_ballot_w64( part );
-                VRC_LDS_STAT( 7, pass == 0 ? __builtin_popcountll( p0_ ) : 0 )
-            }
-            {
-                [[maybe_unused]] const uint64_t pm_ = __builtin_amdgcn_ballot_w64( part );
-                VRC_LDS_STAT( 5, __builtin_popcountll( pm_ ) )
-            }
-            VRC_LDS_STAT( 6, pass == 0 ? 1 : 0 )
+            VRC_LDS_PHASE( 2 )
             /* ---- stage the box: atlas (micro-blocked) -> LDS (linear) --------------------- */
             {
                 const uint32_t x = box.x0 + sxr * 8u, y = box.y0 + syp * 2u;
@@ -659,28 +765,40 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                     ( ( y >> VRC_MB_SHIFT ) * f.sbx + ( x >> VRC_MB_SHIFT ) ) * VRC_MB_VOXELS +
                     ( ( y & 7u ) << 3 );
                 uint8_t* const dst = region + ldsLane;
-                /* every slice load of the pass is issued before the first LDS write; slices
+                /* every slice load of a batch is issued before the first LDS write; slices
                  * past the box repeat its last slice (branch-free, same cache lines) */
-#if defined( VRC_LDS_ABLATE_STAGE ) /* developer timing build: no copies (wrong pixels) */
-                if( box.dz > 1000u )
-#endif
+                /* the lanes' step counts are worked out while the loads are on their way */
                 if( box.dz <= 8u )
-                    lds_stage< 8 >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst, pz );
+                    lds_stage< 8 >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst, pz, countSteps );
                 else if( box.dz <= 11u )
-                    lds_stage< 11 >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst, pz );
+                    lds_stage< 11 >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst, pz, countSteps );
                 else
                 {
                     /* deeper boxes in two halves: at most 11 loads in flight */
                     const uint32_t h = ( box.dz + 1u ) / 2u;
-                    lds_stage< 11 >( slotPtr, partial, sliceStride, box.z0, h, on, dst, pz );
-                    lds_stage< 11 >( slotPtr, partial, sliceStride, box.z0 + h, box.dz - h, on, dst + h * pz, pz );
+                    lds_stage< 11 >( slotPtr, partial, sliceStride, box.z0, h, on, dst, pz, countSteps );
+                    lds_stage< 11 >( slotPtr, partial, sliceStride, box.z0 + h, box.dz - h, on, dst + h * pz, pz, []() {} );
                 }
             }
+            VRC_LDS_STAT( 0, 1 )
+#if defined( VRC_LDS_STATS )
+            if( pass == 0 )
+            {
+                const uint64_t m1_ = __builtin_amdgcn_ballot_w64( inTodo && curNode == brick );
+                const uint64_t m4_ = __builtin_amdgcn_ballot_w64( part );
+                VRC_LDS_STAT( 1, __builtin_popcountll( todoMask ) )
+                VRC_LDS_STAT( 4, __builtin_popcountll( m1_ ) )
+                VRC_LDS_STAT( 5, box.dy )
+                VRC_LDS_STAT( 6, box.dz )
+                VRC_LDS_STAT( 7, __builtin_popcountll( m4_ ) )
+            }
+#endif
+
             /* a wave's LDS accesses complete in issue order, so its own region needs no
              * s_barrier; the compiler must still not move the reads above the copies */
             __builtin_amdgcn_wave_barrier();
 
-            /* ---- march g steps from LDS ---------------------------------------------------- */
+            /* ---- march from LDS ------------------------------------------------------------ */
             const uint32_t bias = box.z0 * pz + box.y0 * VRC_LDS_PY + box.x0;
             /* one sample from the box: the entry (rgb*alpha', alpha') it composites */
             auto sampleLds = [&]( uint32_t a, uint32_t sx_, uint32_t sy_, uint32_t sz_ ) -> C {
@@ -696,85 +814,81 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
 #ifndef VRC_LDS_LBATCH
 #define VRC_LDS_LBATCH 2 /* trilinear samples whose 8 taps are read before the first is used */
 #endif
-            constexpr int BATCH = LINEAR ? VRC_LDS_LBATCH : VRC_LDS_G;
+            constexpr int BATCH = LINEAR ? VRC_LDS_LBATCH : 4;
+            VRC_LDS_PHASE( 3 )
             const C colorIn = color; /* for the replay of a lane that crosses the early-exit threshold */
-            uint32_t cnt = 0;        /* samples the lane took in this pass */
-            /* FASTR: a full pass (g = VRC_LDS_G) in which every participating lane has more than
-             * g steps left: no per-step "does this lane take this step" selects */
-            auto marchLds = [&]( auto fastTag ) {
-                constexpr bool FASTR = decltype( fastTag )::value;
+            uint32_t cnt = 0;        /* samples the lane composited in this pass */
+            uint32_t adv = 0;        /* steps its position advanced */
+            /* one batch of samples.  FAST: every participating lane takes every step of the batch and its segment
+             * goes on beyond it: no per-step selects */
+            auto batch = [&]( auto fastTag, uint32_t s0 ) {
+                constexpr bool FAST = decltype( fastTag )::value;
+                uint32_t a[BATCH], wfx[BATCH], wfy[BATCH], wfz[BATCH];
+                bool act[BATCH];
 #pragma unroll
-                for( int b0 = 0; b0 < VRC_LDS_G; b0 += BATCH )
+                for( int s = 0; s < BATCH; ++s )
                 {
-                    if( FASTR || (uint32_t)b0 < g ) /* wave-uniform */
-                    {
-                        uint32_t a[BATCH], wfx[BATCH], wfy[BATCH], wfz[BATCH];
-                        bool act[BATCH];
-#pragma unroll
-                        for( int s = 0; s < BATCH; ++s )
-                        {
-                            const bool take = FASTR ? true : ( (uint32_t)( b0 + s ) < g ); /* wave-uniform */
-                            act[s] = FASTR ? true : ( take && travel > 0.0f );
-                            /* a step past the end of the lane's segment may lie outside the slot, where the box
-                             * does not follow: it reads offset 0 */
-                            const uint32_t av = ( fz >> 24 ) * pz + ( fy >> 24 ) * VRC_LDS_PY + ( fx >> 24 ) - bias;
-                            a[s] = act[s] ? av : 0u;
-                            wfx[s] = fx;
-                            wfy[s] = fy;
-                            wfz[s] = fz;
-                            fx += take ? fdx : 0u;
-                            fy += take ? fdy : 0u;
-                            fz += take ? fdz : 0u;
-                            travel -= take ? stepSize : 0.0f;
-                        }
-                        C e[BATCH];
-                        if constexpr( LINEAR )
-                        {
-                            float t[BATCH][8];
-#pragma unroll
-                            for( int s = 0; s < BATCH; ++s )
-                                lds_taps( region + a[s], region + a[s] + pz, t[s] );
-#pragma unroll
-                            for( int s = 0; s < BATCH; ++s )
-                                e[s] = lds_classify( (const C*)nullptr, tab,
-                                                     lds_trilerp( t[s], wfx[s], wfy[s], wfz[s] ), lcls );
-                        }
-                        else
-                        {
-                            uint32_t d[BATCH];
-#pragma unroll
-                            for( int s = 0; s < BATCH; ++s )
-                                d[s] = (uint32_t)region[a[s]];
-#pragma unroll
-                            for( int s = 0; s < BATCH; ++s )
-                                e[s] = lut[d[s]];
-                        }
-#pragma unroll
-                        for( int s = 0; s < BATCH; ++s )
-                        {
-                            vrc_composite( color, e[s], !act[s] );
-                            if( !FASTR )
-                                cnt += act[s] ? 1u : 0u;
-                        }
-                    }
+                    const bool take = FAST ? true : ( s0 + (uint32_t)s < nSteps );
+                    act[s] = FAST ? true : ( take && travel > 0.0f );
+                    const uint32_t av = ( fz >> 24 ) * pz + ( fy >> 24 ) * VRC_LDS_PY + ( fx >> 24 ) - bias;
+                    a[s] = take ? av : 0u; /* a step the lane does not take may lie outside the box: it reads offset 0 */
+                    wfx[s] = fx;
+                    wfy[s] = fy;
+                    wfz[s] = fz;
+                    fx += take ? fdx : 0u;
+                    fy += take ? fdy : 0u;
+                    fz += take ? fdz : 0u;
+                    travel -= take ? stepSize : 0.0f;
+                    if( !FAST )
+                        adv += take ? 1u : 0u;
                 }
-            };
-            const bool fastPass =
-                g == VRC_LDS_G &&
-                __builtin_amdgcn_ballot_w64( part && !( travel > stepSize * (float)( VRC_LDS_G + 1 ) ) ) == 0ull;
-            if( fastPass )
-            {
-                VRC_LDS_STAT( 3, 1 )
-            }
-            if( part ) /* the other lanes keep their state */
-            {
-                if( fastPass )
+                C e[BATCH];
+                if constexpr( LINEAR )
                 {
-                    marchLds( std::true_type() );
-                    cnt = g;
+                    float t[BATCH][8];
+#pragma unroll
+                    for( int s = 0; s < BATCH; ++s )
+                        lds_taps( region + a[s], region + a[s] + pz, t[s] );
+#pragma unroll
+                    for( int s = 0; s < BATCH; ++s )
+                        e[s] = lds_classify( (const C*)nullptr, tab, lds_trilerp( t[s], wfx[s], wfy[s], wfz[s] ), lcls );
                 }
                 else
-                    marchLds( std::false_type() );
+                {
+                    uint32_t d[BATCH];
+#pragma unroll
+                    for( int s = 0; s < BATCH; ++s )
+                        d[s] = (uint32_t)region[a[s]];
+#pragma unroll
+                    for( int s = 0; s < BATCH; ++s )
+                        e[s] = lut[d[s]];
+                }
+#pragma unroll
+                for( int s = 0; s < BATCH; ++s )
+                {
+                    vrc_composite( color, e[s], !act[s] );
+                    if( !FAST )
+                        cnt += act[s] ? 1u : 0u;
+                }
+            };
+            if( part ) /* the other lanes keep their state */
+            {
+                /* groups of VRC_LDS_G steps that every participating lane takes in full, unrolled ... */
+                uint32_t s0 = 0;
+                while( s0 + VRC_LDS_G <= nMin &&
+                       __builtin_amdgcn_ballot_w64( !( travel > stepSize * (float)( VRC_LDS_G + 1 ) ) ) == 0ull )
+                {
+#pragma unroll
+                    for( int b0 = 0; b0 < VRC_LDS_G; b0 += BATCH )
+                        batch( std::true_type(), 0u );
+                    s0 += VRC_LDS_G;
+                    cnt += VRC_LDS_G;
+                    adv += VRC_LDS_G;
+                }
+                /* ... and the rest, batch by batch, each lane as far as it goes */
+#pragma unroll 1
+                for( ; s0 < nMax; s0 += BATCH )
+                    batch( std::false_type(), s0 );
                 if( COUNT )
                     nSamples += cnt;
             }
@@ -782,6 +896,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
              * a lane is over the threshold now iff one of its samples of this pass took it there; such a lane
              * takes its samples again one by one from the colour it came with and stops after the one that
              * crosses -- the reference's exit */
+            VRC_LDS_PHASE( 4 )
             const bool crossed = part && color.w > VRC_EARLY_EXIT;
             if( __builtin_amdgcn_ballot_w64( crossed ) != 0ull )
             {
@@ -790,10 +905,10 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                     color = colorIn;
                     if( COUNT )
                         nSamples -= cnt;
-                    uint32_t rx = fx - g * fdx, ry = fy - g * fdy, rz = fz - g * fdz;
+                    uint32_t rx = fx - adv * fdx, ry = fy - adv * fdy, rz = fz - adv * fdz;
                     bool fin = false;
 #pragma unroll 1
-                    for( uint32_t s = 0; s < g; ++s )
+                    for( uint32_t s = 0; s < nMax; ++s )
                     {
                         if( !fin && s < cnt )
                         {
@@ -814,6 +929,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
             __builtin_amdgcn_wave_barrier(); /* the next pass overwrites the region */
         }
 
+        VRC_LDS_PHASE( 5 )
         /* C: lanes no box of this round served: the same steps by byte gathers from the atlas */
 #if defined( VRC_LDS_ABLATE_GATHER ) /* developer timing build: the left-over lanes skip their steps (wrong pixels) */
         if( inTodo )
@@ -830,31 +946,50 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
             {
                 const uint32_t cyy = f.sbx * VRC_MB_VOXELS - 64u;
                 const uint32_t czz = f.sbx * f.sby * VRC_MB_VOXELS - 512u;
-#pragma unroll 1
-                for( int s = 0; s < VRC_LDS_G; ++s )
+                /* two steps at a time: the sixteen gathers of both are on their way before the first is used */
+#ifndef VRC_LDS_GBATCH
+#define VRC_LDS_GBATCH 2
+#endif
+#pragma unroll
+                for( int s0 = 0; s0 < VRC_LDS_G; s0 += VRC_LDS_GBATCH )
                 {
-                    const bool act = travel > 0.0f && !done;
-                    C e;
+                    bool act[VRC_LDS_GBATCH];
+                    C e[VRC_LDS_GBATCH];
                     if constexpr( LINEAR )
                     {
-                        const uint32_t ux = fx >> 24, uy = fy >> 24, uz = fz >> 24;
-                        uint32_t ax[2], ay[2], az[2];
+                        uint32_t wfx[VRC_LDS_GBATCH], wfy[VRC_LDS_GBATCH], wfz[VRC_LDS_GBATCH];
+                        float t[VRC_LDS_GBATCH][8];
 #pragma unroll
-                        for( int i = 0; i < 2; ++i )
+                        for( int s = 0; s < VRC_LDS_GBATCH; ++s )
                         {
-                            const uint32_t cx = ux + (uint32_t)i, cy = uy + (uint32_t)i, cz = uz + (uint32_t)i;
-                            ax[i] = vrc_mul24( cx >> VRC_MB_SHIFT, 504u ) + cx;
-                            ay[i] = vrc_mul24( cy >> VRC_MB_SHIFT, cyy ) + ( cy << 3 );
-                            az[i] = vrc_mul24( cz >> VRC_MB_SHIFT, czz ) + ( cz << 6 ) + laneSlotBase;
-                        }
-                        float t[8];
+                            act[s] = travel > 0.0f;
+                            const uint32_t ux = fx >> 24, uy = fy >> 24, uz = fz >> 24;
+                            uint32_t ax[2], ay[2], az[2];
 #pragma unroll
-                        for( int c = 0; c < 8; ++c )
-                        {
-                            const uint32_t idx = ax[c & 1] + ay[( c >> 1 ) & 1] + az[c >> 2];
-                            t[c] = (float)atlas[act ? idx : 0u];
+                            for( int i = 0; i < 2; ++i )
+                            {
+                                const uint32_t cx = ux + (uint32_t)i, cy = uy + (uint32_t)i, cz = uz + (uint32_t)i;
+                                ax[i] = vrc_mul24( cx >> VRC_MB_SHIFT, 504u ) + cx;
+                                ay[i] = vrc_mul24( cy >> VRC_MB_SHIFT, cyy ) + ( cy << 3 );
+                                az[i] = vrc_mul24( cz >> VRC_MB_SHIFT, czz ) + ( cz << 6 ) + laneSlotBase;
+                            }
+#pragma unroll
+                            for( int c = 0; c < 8; ++c )
+                            {
+                                const uint32_t idx = ax[c & 1] + ay[( c >> 1 ) & 1] + az[c >> 2];
+                                t[s][c] = (float)atlas[act[s] ? idx : 0u];
+                            }
+                            wfx[s] = fx;
+                            wfy[s] = fy;
+                            wfz[s] = fz;
+                            fx += fdx;
+                            fy += fdy;
+                            fz += fdz;
+                            travel -= stepSize;
                         }
-                        e = lds_classify( (const C*)nullptr, tab, lds_trilerp( t, fx, fy, fz ), lcls );
+#pragma unroll
+                        for( int s = 0; s < VRC_LDS_GBATCH; ++s )
+                            e[s] = lds_classify( (const C*)nullptr, tab, lds_trilerp( t[s], wfx[s], wfy[s], wfz[s] ), lcls );
                     }
                     else
                     {
@@ -862,24 +997,45 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                         sm.slotBase = laneSlotBase;
                         sm.cyy = cyy;
                         sm.czz = czz;
-                        const uint32_t iv = vrc_voxel_address( sm, fx >> 24, fy >> 24, fz >> 24 );
-                        e = lut[act ? (uint32_t)atlas[iv] : 256u];
+                        uint32_t d[VRC_LDS_GBATCH];
+#pragma unroll
+                        for( int s = 0; s < VRC_LDS_GBATCH; ++s )
+                        {
+                            act[s] = travel > 0.0f;
+                            const uint32_t iv = vrc_voxel_address( sm, fx >> 24, fy >> 24, fz >> 24 );
+                            d[s] = (uint32_t)atlas[act[s] ? iv : 0u];
+                            fx += fdx;
+                            fy += fdy;
+                            fz += fdz;
+                            travel -= stepSize;
+                        }
+#pragma unroll
+                        for( int s = 0; s < VRC_LDS_GBATCH; ++s )
+                            e[s] = lut[act[s] ? d[s] : 256u];
                     }
-                    vrc_composite( color, e, !act );
-                    if( COUNT )
-                        nSamples += act ? 1u : 0u;
-                    done = done || ( act && color.w > VRC_EARLY_EXIT );
-                    fx += fdx;
-                    fy += fdy;
-                    fz += fdz;
-                    travel -= stepSize;
+#pragma unroll
+                    for( int s = 0; s < VRC_LDS_GBATCH; ++s )
+                    {
+                        const bool on = act[s] && !done;
+                        vrc_composite( color, e[s], !on );
+                        if( COUNT )
+                            nSamples += on ? 1u : 0u;
+                        done = done || ( on && color.w > VRC_EARLY_EXIT );
+                    }
                 }
             }
         }
         if( hasSeg && ( done || !( travel > 0.0f ) ) )
             hasSeg = false;
+        VRC_LDS_PHASE( 6 )
     }
 
+#if defined( VRC_LDS_TIMING )
+    VRC_LDS_PHASE( 7 )
+    if( lane == 0 )
+        for( int i = 0; i < 8; ++i )
+            atomicAdd( &vrc_lds_phase[i], phaseAcc[i] );
+#endif
     if( store )
     {
         if constexpr( GREY )

@@ -21,17 +21,27 @@ ap.add_argument("--filter", type=int, default=0)
 a = ap.parse_args()
 s = orc.build_scene(voxels=(a.voxels,) * 3, block=a.block, viewport=(a.viewport,) * 2, spin=tuple(a.spin))
 with GpuScene(s) as g:
-    fn = g.L.vrc_debug_lds_stats
-    fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     out = (C.c_ulonglong * 8)()
+    fn = g.L.vrc_debug_lds_stats if hasattr(g.L, 'vrc_debug_lds_stats') else (lambda *a: 0)
+    if hasattr(g.L, 'vrc_debug_lds_stats'):
+        fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     fn(out, 1)
-    fb, n, st = g.render(kernel=vrc.KERNEL_LDS, filter_mode=a.filter, count=True)
+    pout = (C.c_ulonglong * 8)()
+    ph = getattr(g.L, "vrc_debug_lds_phases", None) if hasattr(g.L, "vrc_debug_lds_phases") else None
+    if ph is not None:
+        ph.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+        ph(pout, 1)
+    fb, n, st = g.render(kernel=vrc.KERNEL_LDS, filter_mode=a.filter, count=False if ph is not None else True)
+    if ph is not None:
+        ph(pout, 1)
     fn(out, 1)
-    passes, todo0, gathers, fast, cand0, lanes, rounds, part0 = list(out)
+    passes, todo0, gathers, walks, brick0, dy0, dz0, part0 = list(out)
     print("samples %d kernel_ms %.3f" % (n, st.kernel_ms))
-    print("rounds %d  box passes %d (%.2f per round, %d of them fast)  rounds that ended in the gather path %d" %
-          (rounds, passes, passes / max(rounds, 1), fast, gathers))
-    print("first pass of a round, lanes: with steps to take %.1f, of them in the lead's brick %.1f, of them in the window %.1f"
-          % (todo0 / max(rounds, 1), cand0 / max(rounds, 1), part0 / max(rounds, 1)))
-    print("mean participating lanes per pass %.1f  samples/pass %.1f  samples/round %.1f" %
-          (lanes / max(passes, 1), n / max(passes, 1), n / max(rounds, 1)))
+    print("box passes %d  walk iterations %d  rounds that ended in the gather path %d  samples/pass %.1f" %
+          (passes, walks, gathers, n / max(passes, 1)))
+    r = max(passes, 1)  # one pass per round in the product build
+    print("first pass of a round, lanes: with steps to take %.1f, in the lead's brick %.1f, in the box %.1f; "
+          "mean box %.1f rows x %.1f slices" % (todo0 / r, brick0 / r, part0 / r, dy0 / r, dz0 / r))
+    tot = float(sum(pout)) or 1.0
+    names = ["walks", "box", "stage (incl. load wait)", "march", "ERT check/replay", "gather path", "round bookkeeping", "set-up/other"]
+    print("wave cycles by phase: " + ", ".join("%s %.1f%%" % (nm, 100.0 * v / tot) for nm, v in zip(names, pout)))
