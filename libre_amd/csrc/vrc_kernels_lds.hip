@@ -443,6 +443,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
     /* exit guarantee of the round loop, whatever the state: every round advances at least one lane by a step or a
      * brick, so 64 lanes x (steps of the longest ray + cells it can cross) rounds are never reached */
     uint32_t roundBudget = 64u * ( (uint32_t)( 3.5f / stepSize ) + 8u * (uint32_t)( f.gridDim[0] + f.gridDim[1] + f.gridDim[2] ) + 64u );
+    bool events = true, anyLack = true; /* wave-uniform: see the head of the loop */
     for( ;; )
     {
         if( roundBudget-- == 0u )
@@ -468,15 +469,19 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                     done = true;
             }
         };
-        promote();
-        bool refill; /* wave-uniform */
+        /* all of this only when something changed: a segment ended in the last round (events), or lanes are known
+         * to lack a next segment (whether they are about to need it changes with every step they take) */
+        bool refill = false; /* wave-uniform */
+        if( events || anyLack )
         {
+            promote();
             const bool lack = !done && !walkDone && !hasPend;
             const uint64_t lackMask = __builtin_amdgcn_ballot_w64( lack );
             const uint64_t idleMask = __builtin_amdgcn_ballot_w64( lack && !hasSeg );
             const uint64_t soonMask = __builtin_amdgcn_ballot_w64(
                 lack && hasSeg && !( travel > stepSize * (float)( 2 * VRC_LDS_G ) ) );
             refill = idleMask != 0ull || soonMask != 0ull || __builtin_popcountll( lackMask ) >= VRC_LDS_REFILL;
+            anyLack = lackMask != 0ull;
         }
         while( refill )
         {
@@ -607,6 +612,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
             /* a lane that had nothing to march takes what it found; the walks go on while such lanes remain */
             promote();
             refill = __builtin_amdgcn_ballot_w64( !done && !walkDone && !hasPend && !hasSeg ) != 0ull;
+            anyLack = __builtin_amdgcn_ballot_w64( !done && !walkDone && !hasPend ) != 0ull;
         }
 
         VRC_LDS_PHASE( 6 )
@@ -754,6 +760,15 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                 const uint32_t nm = wave_or( part ? 1u << nSteps : 0u );
                 nMin = (uint32_t)__builtin_ctz( nm );
                 nMax = 31u - (uint32_t)__builtin_clz( nm );
+#if !defined( VRC_LDS_NO_STEP_CAP )
+                /* a level tile (its lanes within a step of each other) takes whole fast groups and leaves the odd
+                 * step to the next pass: the general batches that would take it cost a third of a fast group */
+                if( nMax - nMin <= 1u && nMin >= VRC_LDS_G )
+                {
+                    nMax = nMin - nMin % VRC_LDS_G;
+                    nSteps = nSteps < nMax ? nSteps : nMax;
+                }
+#endif
             };
             const uint32_t pz = VRC_LDS_PY * box.dy; /* slice pitch of this pass */
             VRC_LDS_PHASE( 2 )
@@ -814,7 +829,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
 #ifndef VRC_LDS_LBATCH
 #define VRC_LDS_LBATCH 2 /* trilinear samples whose 8 taps are read before the first is used */
 #endif
-            constexpr int BATCH = LINEAR ? VRC_LDS_LBATCH : 4;
+            constexpr int BATCH = LINEAR ? VRC_LDS_LBATCH : VRC_LDS_G; /* point sampling: one byte per sample in flight */
             VRC_LDS_PHASE( 3 )
             const C colorIn = color; /* for the replay of a lane that crosses the early-exit threshold */
             uint32_t cnt = 0;        /* samples the lane composited in this pass */
@@ -1025,8 +1040,12 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                 }
             }
         }
-        if( hasSeg && ( done || !( travel > 0.0f ) ) )
-            hasSeg = false;
+        {
+            const bool ended = hasSeg && ( done || !( travel > 0.0f ) );
+            events = __builtin_amdgcn_ballot_w64( ended ) != 0ull;
+            if( ended )
+                hasSeg = false;
+        }
         VRC_LDS_PHASE( 6 )
     }
 
