@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--gather", choices=["abi", "torch"], default="abi",
                     help="N>1: who moves the tiles: abi = vrc_gather_tiles (RCCL behind the C ABI, the product path); "
                          "torch = torch.distributed.gather (the round-1 path, kept as a cross-check)")
+    ap.add_argument("--require-abi-gather", action="store_true",
+                    help="N>1: exit non-zero instead of falling back to torch.distributed when the C-ABI tile "
+                         "exchange (vrc_gather_tiles over RCCL) is unavailable or fails its pattern check")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the trilinear-extension measurement")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
@@ -254,6 +257,8 @@ def main():
     gather_kind, gather_note = ("none", None) if world == 1 else (a.gather, None)
     bgather = None
     if world > 1 and gather_kind == "abi":
+        # a failing ncclCommInitRank should say why on stderr (RCCL prints its warnings there)
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
         try:
             uid = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
@@ -263,11 +268,18 @@ def main():
             bgather = sortfirst.AbiTileGather(app, layout, W, rank, "cuda", B)
             bgather.send[0, 0].fill_(float(rank + 1))
             torch.cuda.synchronize()
-            bgather.gather(0, 1, torch.cuda.current_stream().cuda_stream)
+            # The check runs on an explicit stream and its completion event is recorded on THAT stream: torch's
+            # default stream has handle 0, which vrc_gather_tiles takes as "the context's own (non-blocking)
+            # stream" -- an event on the default stream would not order against it, the watchdog below could
+            # never fire and the pattern could be read before the receives land (round-2 advisor finding).
+            cstream = torch.cuda.Stream()
+            assert cstream.cuda_stream != 0
+            with torch.cuda.stream(cstream):
+                bgather.gather(0, 1, cstream.cuda_stream)
+                done = torch.cuda.Event()
+                done.record(cstream)
             # a first exchange that never completes (a link that does not come up) must not look like a hung
             # benchmark: give it a minute, then stop this rank with a message (the launcher stops the others)
-            done = torch.cuda.Event()
-            done.record()
             t_wait = time.perf_counter()
             while not done.query():
                 if time.perf_counter() - t_wait > 60.0:
@@ -277,7 +289,8 @@ def main():
                 time.sleep(0.01)
             ok = True
             if rank == 0:
-                got = bgather.frames[0, :, 0, 0].cpu().numpy()
+                with torch.cuda.stream(cstream):  # same stream as the exchange (the event has completed anyway)
+                    got = bgather.frames[0, :, 0, 0].cpu().numpy()
                 want = np.zeros(H, dtype=np.float32)
                 for r_, y0_, h_ in sortfirst.flat_layout(layout):
                     want[y0_:y0_ + h_] = r_ + 1
@@ -286,7 +299,13 @@ def main():
         except Exception as e:  # noqa: BLE001
             ok, err = False, repr(e)
         if not all_ok(ok):
-            # loud, reported, and only for the plumbing around the kernels: the round-1 gather takes over
+            if a.require_abi_gather:
+                sys.stderr.write("bench.py rank %d: --require-abi-gather and the C-ABI tile gather is unavailable (%s)\n"
+                                 % (rank, err))
+                sys.stderr.flush()
+                os._exit(4)
+            # loud, reported (top-level "abi_gather_ok": false), and only for the plumbing around the kernels:
+            # the round-1 gather takes over
             sys.stderr.write("bench.py rank %d: C-ABI tile gather unavailable (%s); using torch.distributed\n" % (rank, err))
             gather_kind, gather_note, bgather = "torch", "C-ABI gather unavailable on at least one rank (%s)" % err, None
     if world > 1 and gather_kind == "torch":
@@ -318,18 +337,27 @@ def main():
                if (world > 1 and not batched) else None)
     counter = [0]
     last_frame = [None]  # rank 0: the most recently assembled frame (--check-frames)
+    gather_events = []   # (start, end) event pairs around every tile exchange while timing[0] is set
+    timing = [False]
 
     def flush(half, n):
         # one gather + one assembly for the n frames rendered into this half
         with torch.cuda.stream(gstream):
             for i in range(n):
                 gstream.wait_event(rendered[half * B + i])
+            if timing[0]:
+                g0 = torch.cuda.Event(enable_timing=True)
+                g0.record(gstream)
             if gather_kind == "abi":
                 bgather.gather(half, n, gstream.cuda_stream)
             else:
                 bgather.gather(half, n)
             if rank == 0:
                 last_frame[0] = bgather.assemble(n)[n - 1]
+            if timing[0]:
+                g1 = torch.cuda.Event(enable_timing=True)
+                g1.record(gstream)
+                gather_events.append((g0, g1, n))
             ev = torch.cuda.Event()
             ev.record(gstream)
             consumed[half] = ev
@@ -355,9 +383,16 @@ def main():
             app.select_slot(k)
             app.render_frame(readback=False)
             if gathers is not None:  # sort-first assembly: tiles to rank 0 over RCCL/xGMI
+                if timing[0]:
+                    g0 = torch.cuda.Event(enable_timing=True)
+                    g0.record(streams[k])
                 gathers[k].gather(fbs[k])
                 if rank == 0:
                     last_frame[0] = gathers[k].assemble()
+                if timing[0]:
+                    g1 = torch.cuda.Event(enable_timing=True)
+                    g1.record(streams[k])
+                    gather_events.append((g0, g1, 1))
 
     def drain():
         # a partial batch at the end of a run of frames
@@ -402,6 +437,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    timing[0] = True
     t0 = time.perf_counter()
     for _ in range(a.steps):
         frame()
@@ -410,6 +446,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = all_max(time.perf_counter() - t0)
+    timing[0] = False
 
     # HIP-event kernel time of the timed region (events recorded by the library around every raycast launch on
     # the render stream): mean over the launches, which must be the timed frames, one launch each
@@ -419,6 +456,33 @@ def main():
         klaunch += s_.kernel_launches
     assert klaunch == a.steps, "kernel launches in the timed region: %d, frames: %d" % (klaunch, a.steps)
     kernel_ms_per_frame = all_max(ksum / klaunch)  # slowest rank's kernel per frame
+
+    # ---- per rank, so that a scaling line can tell throughput from latency (N > 1) ----------------------
+    # kernel_ms: this rank's mean raycast kernel per frame (HIP events of the library); gather_ms: device time
+    # between the start and the end of the tile exchange (+ assembly on rank 0) per frame, on the stream that
+    # carries it; single_frame_latency_ms: wall time of ONE frame with nothing else in flight -- render of this
+    # rank's bands, exchange, assembly, synchronised -- the figure an interactive viewer feels, which the
+    # frames-in-flight throughput above hides
+    my_gather_ms = None
+    if gather_events:
+        my_gather_ms = sum(g0.elapsed_time(g1) for g0, g1, _ in gather_events) / max(1, sum(n for _, _, n in gather_events))
+    lat = []
+    if world > 1:
+        for _ in range(8):
+            dist.barrier()
+            torch.cuda.synchronize()
+            tl = time.perf_counter()
+            frame()
+            drain()
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - tl) * 1e3)
+        all_slots(app.stats)
+    mine = {"rank": rank, "kernel_ms": ksum / klaunch, "gather_ms": my_gather_ms,
+            "single_frame_latency_ms": (sorted(lat)[len(lat) // 2] if lat else None), "rows": rows}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     # the frame assembled from the ranks' bands is the frame one application renders (outside the timing)
     frame_check = None
@@ -662,6 +726,13 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic (mem:// rule of datasources/memory/MemoryDataSource.cpp:54-57)",
+            # N > 1: did the tiles move through the C ABI (vrc_gather_tiles over RCCL)?  false = this line was
+            # measured on the torch.distributed fallback and is NOT a measurement of the C-ABI exchange
+            "abi_gather_ok": (None if world == 1 else gather_kind == "abi"),
+            "frames_in_flight": K, "frames_per_exchange": B,
+            "single_frame_latency_ms": (max(r["single_frame_latency_ms"] for r in per_rank) if world > 1 else
+                                        dt / a.steps * 1e3),
+            "per_rank": per_rank,
             "config": {"workload": ("C2: %s uint8, %dx%d viewport, leaves only (%d bricks of %d^3), "
                                     "%d samples/ray, linear-ramp TF alpha=%.3g, default camera"
                                     % (uri, W, H, n_nodes, a.block + 8,
@@ -675,7 +746,8 @@ def main():
                                          {"abi": "vrc_gather_tiles (RCCL behind the C ABI, straight into the frame)",
                                           "torch": "torch.distributed.gather + placement copy",
                                           "none": "nothing (one rank)"}[gather_kind], B, K),
-                       "tile_gather": gather_kind, "tile_gather_note": gather_note,
+                       "tile_gather": {"abi": "abi", "torch": "torch-fallback" if a.gather == "abi" else "torch", "none": "none"}[gather_kind],
+                       "tile_gather_note": gather_note,
                        "world_size_checked": world,
                        "sort_first_frame_check": frame_check,
                        "samples_per_frame": samples_frame,

@@ -491,6 +491,16 @@ VRC_HD bool vrc_brick_segment( const vrc_frame& f, const vrc_ray& r, const vrc_d
     const float d2 = vrc_dot( diff, diff );
     const float invLen = 1.0f / sqrtf( d2 );
     s->pos = rayStart;
+#if defined( VRC_DEV_BUILD ) && defined( VRC_TEST_BIAS_ENTRY )
+    /* NEGATIVE CONTROL of the parity rule (tests/test_cpu_harness.py::test_parity_rule_rejects_a_biased_kernel; never in
+     * the product: __graft_entry__.build() does not define VRC_DEV_BUILD): every brick segment starts 2e-7 world units
+     * early, so its first sample -- the reference puts it exactly on the brick face, cuda/Renderer.cu:195-196 -- always
+     * reads the voxel on the near side of the face.  Every such flip is inside the oracle's tie zone; the rule must
+     * still reject a kernel that takes all of them. */
+    s->pos.x -= r.dir.x * 2e-7f;
+    s->pos.y -= r.dir.y * 2e-7f;
+    s->pos.z -= r.dir.z * 2e-7f;
+#endif
     s->step.x = diff.x * invLen * stepSize;
     s->step.y = diff.y * invLen * stepSize;
     s->step.z = diff.z * invLen * stepSize;

@@ -844,6 +844,12 @@ static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
         const f3 rayStop = { origin.x + dir.x * tFar, origin.y + dir.y * tFar,
                              origin.z + dir.z * tFar };
         f3 pos = rayStart;
+        if( j->opt.entryBias != 0.0f ) /* test instrument (orc_options.entryBias), not the reference */
+        {
+            pos.x -= dir.x * j->opt.entryBias;
+            pos.y -= dir.y * j->opt.entryBias;
+            pos.z -= dir.z * j->opt.entryBias;
+        }
         const f3 diff = { rayStop.x - rayStart.x, rayStop.y - rayStart.y, rayStop.z - rayStart.z };
         const f3 ndiff = normalize_f3( diff );
         const f3 step = { ndiff.x * stepSize, ndiff.y * stepSize, ndiff.z * stepSize };
@@ -1564,6 +1570,7 @@ uint64_t orc_raycast( const uint8_t* atlas, const uint32_t atlasDim[3], float* p
         job.opt.lodScreenSpaceError = job.opt.lodWorldSpacePerPixel = 0.f;
         job.opt.tieBudget = NULL;
         job.opt.tieDelta = 0.f;
+        job.opt.entryBias = 0.f;
     }
     job.lod = NULL;
     lod_grid* lodGrid = NULL;

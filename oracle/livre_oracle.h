@@ -113,6 +113,13 @@ typedef struct
      * rounding): whether it is taken hangs on the last bit of the ray (sliver_budget in the .c file). */
     float* tieBudget;
     float tieDelta;
+    /* TEST INSTRUMENT, not part of the restated algorithm (0 = off), cudaRaycaster variant only: every brick
+     * segment's first sample position is moved this many world units back along the ray (step and length
+     * unchanged), so that the sample the reference puts exactly ON the brick face (Renderer.cu:195-196) reads
+     * the voxel on the near side of it: the frame in which every brick-entry tie goes the other way.  The
+     * bias check of tests/scenes.py (assert_no_tie_bias) projects a kernel's error onto the difference between
+     * that frame and the nominal one. */
+    float entryBias;
 } orc_options;
 
 /* ---- NodeId: livre/core/data/NodeId.h:38-49, livre/core/types.h:191-195, mathTypes.h:82 */

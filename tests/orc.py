@@ -56,7 +56,7 @@ class Options(C.Structure):
                 ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32), ("rowStride", C.c_uint32),
                 ("voxelBytes", C.c_int), ("variant", C.c_int), ("rayLod", C.c_int),
                 ("lodScreenSpaceError", C.c_float), ("lodWorldSpacePerPixel", C.c_float),
-                ("tieBudget", C.c_void_p), ("tieDelta", C.c_float)]
+                ("tieBudget", C.c_void_p), ("tieDelta", C.c_float), ("entryBias", C.c_float)]
 
 
 def build_oracle():
@@ -74,6 +74,15 @@ def build_harness(sanitize=False):
         subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-O2", "-std=c++17", "-fPIC",
                                "-shared", "-mfma", "-ffp-contract=fast-honor-pragmas",
                                "-Wno-unknown-pragmas", "-o", tmp, src])
+        os.replace(tmp, out)
+        return out
+    if sanitize == "bias":
+        # negative control of the parity rule: a build whose brick-entry samples always read the near-side voxel
+        out = os.path.join(HARNESS_DIR, "libharness_bias.so")
+        src = os.path.join(HARNESS_DIR, "harness.cpp")
+        tmp = "%s.%d.tmp" % (out, os.getpid())
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-Wno-unknown-pragmas", "-DVRC_DEV_BUILD", "-DVRC_TEST_BIAS_ENTRY", "-o", tmp, src])
         os.replace(tmp, out)
         return out
     out = HARNESS_SO if not sanitize else os.path.join(HARNESS_DIR, "libharness_asan.so")
@@ -420,8 +429,12 @@ def world_space_per_pixel(s, top=0.05, bottom=-0.05):
 TIE_DELTA = 2.0 ** -11
 
 
+#: world units by which the "every brick-entry tie the other way" frame starts its brick segments early
+ENTRY_BIAS = 2e-7
+
+
 def oracle_render(s, frac_bits=8, threads=8, rows=None, fb=None, filter_mode=0, variant=0, ray_lod=None,
-                  budget=False):
+                  budget=False, entry_bias=0.0):
     """Run the oracle integrator on a scene. Returns (rgba[H,W,4], samples), with budget=True
     (rgba, samples, tie_budget[H,W]) (orc_options.tieBudget, the per-pixel part of the parity tolerance).
     ray_lod = (screenSpaceError, worldSpacePerPixel): per-ray adaptive LOD over a node hierarchy."""
@@ -435,7 +448,7 @@ def oracle_render(s, frac_bits=8, threads=8, rows=None, fb=None, filter_mode=0, 
     tb = prev if (prev is not None and not first_pass) else np.zeros((s.H, s.W), dtype=np.float32)
     opt = Options(frac_bits, filter_mode, threads, 0, s.H, 1, s.atlas.dtype.itemsize, variant,
                   1 if ray_lod else 0, ray_lod[0] if ray_lod else 0.0, ray_lod[1] if ray_lod else 0.0,
-                  tb.ctypes.data, TIE_DELTA)
+                  tb.ctypes.data, TIE_DELTA, entry_bias)
     if rows is not None:
         opt.rowBegin, opt.rowEnd, opt.rowStride = rows
     n = L.orc_raycast(s.atlas.ctypes.data, u32x3(*s.atlas_dim), fb.ctypes.data, s.W, s.H,
@@ -545,6 +558,17 @@ def budget_of(frame):
     return out
 
 
+def note_stat(**kw):
+    """Append a record of the calling test to the VRC_PARITY_STATS file (tools/parity_summary.py)."""
+    if _STATS_FILE:
+        import inspect
+        import json
+        fr = inspect.stack()
+        who = next((f.function for f in fr[1:] if f.function.startswith("test_")), fr[1].function)
+        with open(_STATS_FILE, "a") as f:
+            f.write(json.dumps(dict(test=who, note=True, **kw)) + "\n")
+
+
 def compare(a, b):
     """(max-abs, mean-abs, fraction of pixels with any channel over 2e-3)."""
     d = np.abs(a.astype(np.float64) - b.astype(np.float64))
@@ -565,7 +589,9 @@ def compare(a, b):
                    flip_weight=flip_weight(_LAST_SCENE) if _LAST_SCENE is not None else None)
         if tb is not None:
             ex = pix - 2.0 * tb
-            rec.update(budget_mean=float(tb.mean()), budget_max=float(tb.max()),
+            rec.update(pixel_mean=float(pix.mean()), needs_budget=float((pix > 5e-5).mean()),
+                       budget_use=float(max(pix.mean() - 2e-5, 0.0) / tb.mean()) if tb.mean() > 0 else 0.0,
+                       budget_mean=float(tb.mean()), budget_max=float(tb.max()),
                        excess_max=float(ex.max()), n_excess_over_1e5=int((ex > 1e-5).sum()),
                        n_excess_over_2e5=int((ex > 2e-5).sum()), n_excess_over_5e5=int((ex > 5e-5).sum()),
                        n_excess_over_1e4=int((ex > 1e-4).sum()),

@@ -14,6 +14,7 @@ def test_reference_order_matches_oracle(name):
     want, n_want = orc.oracle_render(s, threads=4)
     got, n_got, _ = orc.harness_render(s, kernel=1)
     scenes.assert_parity(got, want, name)
+    scenes.assert_no_tie_bias(got, want, orc.oracle_render(s, threads=4, entry_bias=orc.ENTRY_BIAS)[0], name)
     # same bricks, same per-brick loop: the sample count is identical -- except where a
     # boundary sample reads the neighbouring voxel and a ray crosses the early-exit threshold
     # one sample sooner or later (only the high-opacity noise scene)
@@ -30,6 +31,7 @@ def test_grid_dda_matches_oracle(name):
     got, n_got, grid_ok = orc.harness_render(s, kernel=2)
     assert grid_ok
     scenes.assert_parity(got, want, name)
+    scenes.assert_no_tie_bias(got, want, orc.oracle_render(s, threads=4, entry_bias=orc.ENTRY_BIAS)[0], name)
     # the walk hands the cells around tied edges / corners to the reference's slab test: the same samples, one
     # for one (the high-opacity noise scene: a ray may cross the early-exit threshold a sample sooner or later)
     if name == "hash64_ert":
@@ -340,3 +342,28 @@ def test_random_views_all_kernel_forms_match_the_oracle(seed):
     want_gl, _ = orc.oracle_render(s, threads=4, variant=1)
     got, _, _ = orc.harness_render(s, kernel=2, variant=1)
     _fuzz_parity(got, want_gl, "seed %d glRaycaster %r" % (seed, kw))
+
+
+@pytest.mark.parametrize("name", ["hash64_axis", "hash64_spin", "hash_spr300", "hash64_ert"])
+def test_parity_rule_rejects_a_biased_kernel(name):
+    # NEGATIVE CONTROL of the parity rule (tests/scenes.py).  A host build of the kernel code whose brick segments start
+    # 2e-7 world units early (VRC_DEV_BUILD + VRC_TEST_BIAS_ENTRY, vrc_core.h: vrc_brick_segment): the first sample of
+    # every segment, which the reference puts exactly on the brick face (cuda/Renderer.cu:195-196, :208-214), then
+    # ALWAYS reads the voxel on the near side of the face.  Every one of those flips lies inside the oracle's tie zone,
+    # so the frame passes the per-pixel rule |d| <= E0 + 2 B -- a systematic error hiding in the budget.  The bias
+    # check must throw it out; the unbiased build of the same code passes both on the same scene.
+    s = scenes.get(name)
+    want, _ = orc.oracle_render(s, threads=4)
+    flipped, _ = orc.oracle_render(s, threads=4, entry_bias=orc.ENTRY_BIAS)
+    assert np.abs(flipped - want).max() > 3 * scenes.E0  # the scene has ties that matter
+    good, _, _ = orc.harness_render(s, kernel=2)
+    scenes.assert_parity(good, want, name + " unbiased")
+    assert abs(scenes.assert_no_tie_bias(good, want, flipped, name + " unbiased")) < 0.1
+    biased, _, _ = orc.harness_render(s, kernel=2, sanitize="bias")
+    tb = orc.budget_of(want)
+    d = np.abs(biased.astype(np.float64) - want.astype(np.float64)).max(axis=-1)
+    inside = float((d <= scenes.E0 + scenes.TIE_FACTOR * tb).mean())
+    assert inside > 0.99, "the control is only meaningful while the per-pixel rule alone lets it through"
+    assert scenes.tie_bias(biased, want, flipped) > 0.9
+    with pytest.raises(AssertionError):
+        scenes.assert_no_tie_bias(biased, want, flipped, name + " biased")

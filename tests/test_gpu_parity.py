@@ -61,15 +61,19 @@ def test_atlas_layout_roundtrip(vrc):
 def test_scene_parity_both_kernels(vrc, golden, name):
     s = scenes.get(name)
     want, n_want = orc.oracle_render(s, threads=8)
+    # the oracle's "every brick-entry tie the other way" frame, for the bias check (tests/scenes.py)
+    flipped, _ = orc.oracle_render(s, threads=8, entry_bias=orc.ENTRY_BIAS)
     with _gpu(s) as g:
         ref, n_ref, st = g.render(kernel=vrc.KERNEL_REFERENCE_ORDER)
         assert st.kernel_variant == vrc.KERNEL_REFERENCE_ORDER
         scenes.assert_parity(ref, want, name + " ref-order vs oracle")
+        scenes.assert_no_tie_bias(ref, want, flipped, name + " ref-order")
         scenes.assert_parity(ref, golden[name], name + " ref-order vs golden", budget=orc.budget_of(want))
         assert abs(n_ref - n_want) <= 1e-4 * n_want + 8
         dda, n_dda, st = g.render(kernel=vrc.KERNEL_GRID_DDA)
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
         scenes.assert_parity(dda, want, name + " dda vs oracle")
+        scenes.assert_no_tie_bias(dda, want, flipped, name + " dda")
         # the grid walk composites the reference's samples, one for one (opaque noise scene: a ray may cross
         # the early-exit threshold a sample sooner or later where a tie falls the other way)
         assert n_dda == n_want or (name == "hash64_ert" and abs(n_dda - n_want) <= 1e-4 * n_want)
@@ -87,6 +91,7 @@ def test_scene_parity_both_kernels(vrc, golden, name):
         # the reference's float position accumulation (VRC_OPT_STEPPING = 0) is kept and tested
         flt, n_flt, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, stepping=0)
         scenes.assert_parity(flt, want, name + " dda float stepping vs oracle")
+        scenes.assert_no_tie_bias(flt, want, flipped, name + " dda float stepping")
         assert n_flt == n_dda
 
 
@@ -382,10 +387,13 @@ def test_noise_in_136_cubed_slots_every_kernel_form(vrc, spin):
         ref, n_ref, st = g.render(kernel=vrc.KERNEL_REFERENCE_ORDER)
         assert st.kernel_variant == vrc.KERNEL_REFERENCE_ORDER
         scenes.assert_parity(ref, want, "136^3 noise, reference order")
+        flipped, _ = orc.oracle_render(s, threads=16, entry_bias=orc.ENTRY_BIAS)
+        scenes.assert_no_tie_bias(ref, want, flipped, "136^3 noise, reference order")
         assert n_ref == n_want
         dda, n_dda, st = g.render(kernel=vrc.KERNEL_GRID_DDA)
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
         scenes.assert_parity(dda, want, "136^3 noise, grid DDA, fixed-point stepping")
+        scenes.assert_no_tie_bias(dda, want, flipped, "136^3 noise, grid DDA, fixed-point stepping")
         assert n_dda == n_want
         flt, n_flt, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, stepping=0)
         scenes.assert_parity(flt, want, "136^3 noise, grid DDA, float stepping")
@@ -393,6 +401,7 @@ def test_noise_in_136_cubed_slots_every_kernel_form(vrc, spin):
         lds, n_lds, st = g.render(kernel=vrc.KERNEL_LDS)
         assert st.kernel_variant == vrc.KERNEL_LDS
         scenes.assert_parity(lds, want, "136^3 noise, LDS-staged")
+        scenes.assert_no_tie_bias(lds, want, flipped, "136^3 noise, LDS-staged")
         assert n_lds == n_dda
         gl, _, _ = g.render(variant=vrc.VARIANT_GLRAYCASTER)
         scenes.assert_parity(gl, want_gl, "136^3 noise, glRaycaster variant")
@@ -435,6 +444,8 @@ def test_c2_noise_volume_rows_at_1024_and_2048(vrc, c2_noise_scene):
         got2, n_got2, st2 = g.render()
         assert st2.kernel_variant == vrc.KERNEL_GRID_DDA
     scenes.assert_parity(got[::64], want[::64], "C2 noise rows")
+    flipped, _ = orc.oracle_render(s, threads=16, rows=rows, entry_bias=orc.ENTRY_BIAS)
+    scenes.assert_no_tie_bias(got[::64], want[::64], flipped[::64], "C2 noise rows (the kernel instance the bench times)")
     scenes.assert_parity(ref[::64], want[::64], "C2 noise rows, reference order")
     scenes.assert_parity(flt[::64], want[::64], "C2 noise rows, float stepping")
     assert abs(n_want * 64 - n_got) <= 0.03 * n_got and n_flt == n_got and n_ref == n_got
