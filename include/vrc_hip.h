@@ -278,19 +278,22 @@ typedef struct
     uint32_t rows;
 } vrc_band;
 /* Collective over the communicator, asynchronous on hip_stream (NULL: ctx's render stream, i.e. behind
- * the vrc_render calls that produced the bands).  `bands` lists every band of the frame, identical on
- * all ranks; a rank's bands lie stacked in `local` in list order (what vrc_set_row_map renders),
+ * the vrc_render calls that produced the bands; another stream is made to wait for what ctx's render
+ * stream holds at the time of the call).  `bands` lists every band of the width x height frame, identical
+ * on all ranks; a rank's bands lie stacked in `local` in list order (what vrc_set_row_map renders),
  * width x rows RGBA32F each.  On rank `root` band b lands at row bands[b].frame_row of `frame` (its
  * own bands by device copies); `frame` is ignored elsewhere.  n_frames > 1 moves that many consecutive
  * frames with one group of sends/receives: frame f of a rank starts local_frame_stride bytes after
- * frame f-1 in `local`, and frame_stride bytes in `frame`. */
+ * frame f-1 in `local`, and frame_stride bytes in `frame`.  Every band must lie inside the frame
+ * (frame_row + rows <= height, checked in 64 bits) and a frame stride must hold a frame: nothing is
+ * queued on any rank otherwise (VRC_EINVAL). */
 int vrc_gather_tiles( vrc_ctx* ctx, vrc_comm* comm, const vrc_band* bands, uint32_t n_bands, uint32_t width,
-                      uint32_t n_frames, const void* local_device, size_t local_frame_stride,
+                      uint32_t height, uint32_t n_frames, const void* local_device, size_t local_frame_stride,
                       void* frame_device, size_t frame_stride, int root, void* hip_stream );
 
 const char* vrc_last_error( void );
 /* ABI version of this header */
-#define VRC_ABI_VERSION 2
+#define VRC_ABI_VERSION 3 /* 3: vrc_gather_tiles takes the frame height */
 int vrc_abi_version( void );
 
 #ifdef __cplusplus

@@ -1197,13 +1197,20 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     {
         const double nMax = 1.7320508 * (double)render->samplesPerRay +
                             3.0 * ( f.gridDim[0] + f.gridDim[1] + f.gridDim[2] ) + 8.0;
-        a.depthSplit = c->lutMaxAlpha < 1.0f && nMax * std::log1p( -(double)c->lutMaxAlpha ) > std::log( 1.0 - 0.999 );
+        /* with a margin: the kernel accumulates the opacity in float with contracted multiply-adds and regroups the
+         * far half's additions, ~1e-6 absolute after 2000 samples = 1e-3 of the 0.001 of transmittance left at
+         * the threshold; the bound must clear the threshold by ten times that (0.01 in the logarithm), so that a
+         * frame at the limit takes the single-wave kernel rather than a split that might meet an early exit */
+        a.depthSplit = VRC_TILE_W == 8u && c->lutMaxAlpha < 1.0f &&
+                       nMax * std::log1p( -(double)c->lutMaxAlpha ) > std::log( 1.0 - 0.999 ) + 0.01;
     }
     /* ray compaction: the table-driven point-sampling walk kernel; packed 16-bit pixel coordinates */
     a.ertParts = 0;
     a.rayList = nullptr;
+    /* (the same predicate as the launcher's, vrc_launch_raycast: what vrc_get_ray_counts reports is what ran) */
     if( c->optErtParts > 1 && !a.depthSplit && useDda && !useLds && !c->rayLod && !linear && pool->elemBytes == 1 &&
-        !pool->bigAtlas && !c->cachedClamp && c->optStepping != 0 && c->fbW < 65536u && c->fbH < 65536u )
+        !pool->bigAtlas && !c->cachedClamp && c->optStepping != 0 && c->fbW < 65536u && c->fbH < 65536u &&
+        VRC_TILE_W == 8u )
     {
         const size_t pixels = (size_t)c->fbW * c->fbH;
         if( pixels > c->dRayListCap )

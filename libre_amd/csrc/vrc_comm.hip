@@ -117,6 +117,7 @@ struct vrc_comm
 {
     ncclComm_t comm = nullptr; /* NULL for a world of one: nothing to exchange */
     int rank = 0, world = 1, device = 0;
+    hipEvent_t ordered = nullptr; /* vrc_gather_tiles on a caller's stream: "the render stream up to here" */
 };
 
 extern "C" {
@@ -185,6 +186,8 @@ void vrc_comm_destroy( vrc_comm* c )
         if( r )
             (void)r->CommDestroy( c->comm );
     }
+    if( c->ordered )
+        (void)hipEventDestroy( c->ordered );
     delete c;
 }
 
@@ -198,13 +201,13 @@ int vrc_comm_info( const vrc_comm* c, int* rank, int* world )
 }
 
 int vrc_gather_tiles( vrc_ctx* ctx, vrc_comm* c, const vrc_band* bands, uint32_t nBands, uint32_t width,
-                      uint32_t nFrames, const void* local, size_t localFrameStride, void* frame,
+                      uint32_t height, uint32_t nFrames, const void* local, size_t localFrameStride, void* frame,
                       size_t frameStride, int root, void* hipStream )
 {
     if( !ctx || !c || ( !bands && nBands ) )
         return vrc_internal_fail( VRC_EINVAL, "vrc_gather_tiles: NULL argument" );
-    if( root < 0 || root >= c->world || nFrames == 0 || width == 0 )
-        return vrc_internal_fail( VRC_EINVAL, "vrc_gather_tiles: bad root / frame count / width" );
+    if( root < 0 || root >= c->world || nFrames == 0 || width == 0 || height == 0 )
+        return vrc_internal_fail( VRC_EINVAL, "vrc_gather_tiles: bad root / frame count / width / height" );
     const bool isRoot = c->rank == root;
     if( isRoot && !frame )
         return vrc_internal_fail( VRC_EINVAL, "vrc_gather_tiles: the display rank needs a frame" );
@@ -215,6 +218,10 @@ int vrc_gather_tiles( vrc_ctx* ctx, vrc_comm* c, const vrc_band* bands, uint32_t
     {
         if( bands[b].rank >= (uint32_t)c->world )
             return vrc_internal_fail( VRC_EINVAL, "vrc_gather_tiles: band of a rank outside the communicator" );
+        /* in 64 bits: frame_row = 0xFFFFFFFF with rows = 2 must not wrap into the frame (a device write outside
+         * the frame on the display rank otherwise) */
+        if( (uint64_t)bands[b].frame_row + (uint64_t)bands[b].rows > (uint64_t)height )
+            return vrc_internal_fail( VRC_EINVAL, "vrc_gather_tiles: band outside the frame" );
         if( bands[b].rank == (uint32_t)c->rank )
             localRows += bands[b].rows;
     }
@@ -222,14 +229,32 @@ int vrc_gather_tiles( vrc_ctx* ctx, vrc_comm* c, const vrc_band* bands, uint32_t
         return vrc_internal_fail( VRC_EINVAL, "vrc_gather_tiles: this rank has bands but no local buffer" );
     if( nFrames > 1 && ( localFrameStride < localRows * rowBytes ) )
         return vrc_internal_fail( VRC_EINVAL, "vrc_gather_tiles: local frame stride smaller than a frame's bands" );
+    if( isRoot && nFrames > 1 && frameStride < (size_t)height * rowBytes )
+        return vrc_internal_fail( VRC_EINVAL, "vrc_gather_tiles: frame stride smaller than a frame" );
 
     int device = 0;
-    hipStream_t stream = hipStream ? (hipStream_t)hipStream : vrc_internal_ctx_stream( ctx, &device );
-    if( hipStream )
-        (void)vrc_internal_ctx_stream( ctx, &device );
+    const hipStream_t ctxStream = vrc_internal_ctx_stream( ctx, &device );
+    hipStream_t stream = hipStream ? (hipStream_t)hipStream : ctxStream;
     const hipError_t he = hipSetDevice( device );
     if( he != hipSuccess )
         return vrc_internal_fail( VRC_EHIP, std::string( "vrc_gather_tiles: hipSetDevice: " ) + hipGetErrorString( he ) );
+    /* a caller's stream is ordered behind the render stream that produced `local` (the context's own stream when the
+     * renders ran there: vrc_set_stream'ed renders already are on the caller's streams) */
+    if( stream != ctxStream )
+    {
+        if( !c->ordered )
+        {
+            const hipError_t ee = hipEventCreateWithFlags( &c->ordered, hipEventDisableTiming );
+            if( ee != hipSuccess )
+                return vrc_internal_fail( VRC_EHIP, std::string( "vrc_gather_tiles: hipEventCreate: " ) + hipGetErrorString( ee ) );
+        }
+        hipError_t ee = hipEventRecord( c->ordered, ctxStream );
+        if( ee == hipSuccess )
+            ee = hipStreamWaitEvent( stream, c->ordered, 0 );
+        if( ee != hipSuccess )
+            return vrc_internal_fail( VRC_EHIP, std::string( "vrc_gather_tiles: ordering behind the render stream: " ) +
+                                                    hipGetErrorString( ee ) );
+    }
 
     Rccl* r = c->comm ? rccl() : nullptr;
     if( c->comm && !r )

@@ -390,7 +390,8 @@ int lvh_app_set_layout( lvh_app* app, const uint32_t* rank, const uint32_t* y0, 
     std::vector< vrc_band > l( n );
     for( uint32_t i = 0; i < n; ++i )
     {
-        if( y0[i] + h[i] > app->params.height ) return fail( "lvh_app_set_layout: band outside the frame" );
+        if( uint64_t( y0[i] ) + uint64_t( h[i] ) > uint64_t( app->params.height ) ) /* 64 bits: y0 = 0xFFFFFFFF, h = 2 */
+            return fail( "lvh_app_set_layout: band outside the frame" );
         l[i].rank = rank[i];
         l[i].frame_row = y0[i];
         l[i].rows = h[i];
@@ -404,7 +405,7 @@ int lvh_app_gather_tiles( lvh_app* app, uint32_t nFrames, const void* localDevic
 {
     if( !app || !app->comm ) return fail( "lvh_app_gather_tiles: no communicator (lvh_app_comm_create)" );
     if( vrc_gather_tiles( app->renderer().deviceContext(), app->comm, app->layout.data(),
-                          uint32_t( app->layout.size() ), app->params.width, nFrames, localDevice,
+                          uint32_t( app->layout.size() ), app->params.width, app->params.height, nFrames, localDevice,
                           localFrameStride, frameDevice, frameStride, root, hipStream ) != VRC_OK )
         return fail( vrc_last_error() );
     return 0;

@@ -118,7 +118,7 @@ def load_library(path=None):
     L.vrc_comm_destroy.argtypes = [vp]
     L.vrc_comm_destroy.restype = None
     L.vrc_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    L.vrc_gather_tiles.argtypes = [vp, vp, C.POINTER(Band), C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t,
+    L.vrc_gather_tiles.argtypes = [vp, vp, C.POINTER(Band), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t,
                                    vp, C.c_size_t, C.c_int, vp]
     if path is None:
         _lib = L

@@ -141,7 +141,7 @@ int vrc_comm_info( const vrc_comm* c, int* rank, int* world )
     if( world ) *world = c->world;
     return VRC_OK;
 }
-int vrc_gather_tiles( vrc_ctx*, vrc_comm*, const vrc_band*, uint32_t, uint32_t, uint32_t, const void*, size_t, void*,
+int vrc_gather_tiles( vrc_ctx*, vrc_comm*, const vrc_band*, uint32_t, uint32_t, uint32_t, uint32_t, const void*, size_t, void*,
                       size_t, int, void* )
 {
     return VRC_OK;

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in declared:
         assert hasattr(L, name), "libvrc_hip.so does not export %s" % name
     assert sorted(vrc.EXPORTS) == declared
-    assert L.vrc_abi_version() == 2
+    assert L.vrc_abi_version() == 3
 
 
 def test_comm_of_one_rank_needs_no_rccl_and_no_gpu_for_argument_checks(built):
@@ -36,7 +36,7 @@ def test_comm_of_one_rank_needs_no_rccl_and_no_gpu_for_argument_checks(built):
     assert L.vrc_comm_create(None, 0, 1, None, C.byref(comm)) == vrc.VRC_EINVAL
     assert b"bad ctx" in L.vrc_last_error()
     assert L.vrc_comm_info(None, None, None) == vrc.VRC_EINVAL
-    assert L.vrc_gather_tiles(None, None, None, 0, 16, 1, None, 0, None, 0, 0, None) == vrc.VRC_EINVAL
+    assert L.vrc_gather_tiles(None, None, None, 0, 16, 16, 1, None, 0, None, 0, 0, None) == vrc.VRC_EINVAL
     assert C.sizeof(vrc.Band) == 12
     L.vrc_comm_destroy(None)
 

@@ -837,3 +837,13 @@ def test_reference_order_tile_culling_with_row_bands_and_mixed_levels(drv):
         app.height = H
         again, _ = app.render_frame()
         assert (again == full).all()
+
+
+def test_layout_bands_are_checked_in_64_bits(drv):
+    # lvh_app_set_layout: y0 + h must not wrap (y0 = 0xFFFFFFFF, h = 2 passed the 32-bit sum and became an
+    # out-of-bounds device write on the display rank; round-2 advisor finding)
+    with drv.App("mem://#64,64,64,16", 48, 40, device=0, synchronous=True) as app:
+        app.set_layout([[(0, 20), (20, 20)]])
+        for bad in ([(39, 2)], [(0xFFFFFFFF, 2)], [(40, 0xFFFFFFFF)], [(1, 40)]):
+            with pytest.raises(RuntimeError):
+                app.set_layout([bad])

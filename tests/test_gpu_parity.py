@@ -914,7 +914,7 @@ def test_gather_tiles_places_bands_at_their_rows(vrc):
     local = torch.arange(F * rows * W * 4, dtype=torch.float32, device="cuda").reshape(F, rows, W, 4)
     frame = torch.full((F, H, W, 4), -1.0, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
-    vrc.check(L, L.vrc_gather_tiles(ctx, comm, arr, len(bands), W, F, local.data_ptr(), rows * W * 16,
+    vrc.check(L, L.vrc_gather_tiles(ctx, comm, arr, len(bands), W, H, F, local.data_ptr(), rows * W * 16,
                                     frame.data_ptr(), H * W * 16, 0, None))
     vrc.check(L, L.vrc_synchronize(ctx))
     want = torch.full((F, H, W, 4), -1.0)
@@ -925,9 +925,25 @@ def test_gather_tiles_places_bands_at_their_rows(vrc):
     assert (frame.cpu() == want).all()
     # errors: band of a rank outside the communicator, missing frame on the display rank, bad root
     bad = (vrc.Band * 1)(vrc.Band(1, 0, 1))
-    assert L.vrc_gather_tiles(ctx, comm, bad, 1, W, 1, local.data_ptr(), 0, frame.data_ptr(), 0, 0, None) == vrc.VRC_EINVAL
-    assert L.vrc_gather_tiles(ctx, comm, arr, len(bands), W, 1, local.data_ptr(), 0, None, 0, 0, None) == vrc.VRC_EINVAL
-    assert L.vrc_gather_tiles(ctx, comm, arr, len(bands), W, 1, local.data_ptr(), 0, frame.data_ptr(), 0, 1, None) == vrc.VRC_EINVAL
+    assert L.vrc_gather_tiles(ctx, comm, bad, 1, W, H, 1, local.data_ptr(), 0, frame.data_ptr(), 0, 0, None) == vrc.VRC_EINVAL
+    assert L.vrc_gather_tiles(ctx, comm, arr, len(bands), W, H, 1, local.data_ptr(), 0, None, 0, 0, None) == vrc.VRC_EINVAL
+    assert L.vrc_gather_tiles(ctx, comm, arr, len(bands), W, H, 1, local.data_ptr(), 0, frame.data_ptr(), 0, 1, None) == vrc.VRC_EINVAL
+    # a band that reaches past the frame -- also when frame_row + rows wraps in 32 bits -- and a frame stride that
+    # does not hold a frame are refused before anything is queued (round-2 advisor finding)
+    for y0, h in ((H - 1, 2), (0xFFFFFFFF, 2), (H, 0xFFFFFFFF)):
+        past = (vrc.Band * 1)(vrc.Band(0, y0, h))
+        assert L.vrc_gather_tiles(ctx, comm, past, 1, W, H, 1, local.data_ptr(), 0, frame.data_ptr(), 0, 0, None) == vrc.VRC_EINVAL
+    assert L.vrc_gather_tiles(ctx, comm, arr, len(bands), W, H, F, local.data_ptr(), rows * W * 16,
+                              frame.data_ptr(), H * W * 16 - 16, 0, None) == vrc.VRC_EINVAL
+    assert (frame.cpu() == want).all()  # untouched by the refused calls
+    # on a caller's stream the exchange is ordered behind the context's render stream
+    st = torch.cuda.Stream()
+    frame.fill_(-1.0)
+    torch.cuda.synchronize()
+    vrc.check(L, L.vrc_gather_tiles(ctx, comm, arr, len(bands), W, H, F, local.data_ptr(), rows * W * 16,
+                                    frame.data_ptr(), H * W * 16, 0, C.c_void_p(st.cuda_stream)))
+    st.synchronize()
+    assert (frame.cpu() == want).all()
     # a communicator of more ranks needs an id (and RCCL)
     c2 = C.c_void_p()
     assert L.vrc_comm_create(ctx, 0, 2, None, C.byref(c2)) == vrc.VRC_ECOMM
