@@ -184,6 +184,10 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU fallback")
+    if vrc.load_library().vrc_is_dev_build():
+        # a library compiled with -DVRC_DEV_BUILD may carry timing ablations that render wrong pixels on purpose
+        raise SystemExit("bench.py refuses a developer build of libvrc_hip.so (VRC_DEV_BUILD): build the product "
+                         "with __graft_entry__.build()")
     # rehearsal knobs (1-GPU box): BENCH_FORCE_DEVICE=0 puts every rank on one card and
     # BENCH_BACKEND=gloo replaces RCCL; the judged runs use neither
     if "BENCH_FORCE_DEVICE" in os.environ:
@@ -456,6 +460,7 @@ def main():
         klaunch += s_.kernel_launches
     assert klaunch == a.steps, "kernel launches in the timed region: %d, frames: %d" % (klaunch, a.steps)
     kernel_ms_per_frame = all_max(ksum / klaunch)  # slowest rank's kernel per frame
+    launched_kernel = (vrc.load_library().vrc_last_kernel() or b"").decode()  # the instance the timed frames ran
 
     # ---- per rank, so that a scaling line can tell throughput from latency (N > 1) ----------------------
     # kernel_ms: this rank's mean raycast kernel per frame (HIP events of the library); gather_ms: device time
@@ -701,11 +706,28 @@ def main():
     if rank == 0:
         # measured HBM traffic per launch, from the committed rocprofv3 PMC passes (bench.py cannot
         # run the profiler on itself); only quoted for the workload it was measured on
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r2_traffic_c2.json")
+        traffic, valu, tnote = None, None, "no committed PMC passes for this workload"
+        tpath = os.path.join(ROOT, "profiles", "r3_traffic_c2.json")
         if (world == 1 and a.voxels == 1024 and a.block == 128 and a.viewport == 1024
                 and tuple(a.spin) == (0.0, 0.0) and not ray_lod_on and os.path.exists(tpath)):
-            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
+            tj = json.load(open(tpath))
+            # the counters are only quoted for the kernel instance they were collected on
+            if launched_kernel and tj["kernel"].split(" ")[0] == launched_kernel:
+                traffic = tj["traffic_bytes_per_launch"]
+                tnote = "FETCH_SIZE + WRITE_SIZE bytes per launch from profiles/r3_traffic_c2.json (same kernel instance)"
+                if "sq_insts_valu_per_launch" in tj:
+                    # a VALU figure next to the HBM fraction.  One wave-instruction holds its SIMD's
+                    # issue for 4 cycles (2 for the dual-issue classes, profiles/r3_ubench_valu_lds_issue_costs.txt:
+                    # the floor below prices every instruction at its measured class cost); 1024 SIMDs
+                    steps = tj["wave_steps_per_launch"]
+                    floor_ms = tj["valu_issue_ns_per_simd_per_launch"] * 1e-6
+                    valu = {"insts_per_step": tj["sq_insts_valu_per_launch"] / steps,
+                            "insts_per_launch": tj["sq_insts_valu_per_launch"], "wave_steps_per_launch": steps,
+                            "issue_floor_ms": floor_ms, "frac": floor_ms / kernel_ms_per_frame,
+                            "source": tj.get("valu_source")}
+            else:
+                tnote = ("profiles/r3_traffic_c2.json is a profile of %s, this run launched %s: not quoted"
+                         % (tj["kernel"].split(" ")[0], launched_kernel or "?"))
         n_nodes = (a.voxels // a.block) ** 3
         # interior voxels of marched bricks + one RGBA32F write + node table + TF, each input
         # voxel once per frame.  With N ranks a rank's row bands sweep rows/H of the volume (the bands are
@@ -763,13 +785,11 @@ def main():
                        "extension_per_ray_lod": ray_lod,
                        "volume_n": volume_n},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("vrc_k_raycast_raylod<false,false,true,0,unsigned char>" if ray_lod_on else
-                                    # grey transfer function (the linear ramp is one): the two-float table form,
-                                    # MODE 3 = VRC_MODE_GREY, bit-identical frames (VRC_OPT_GREY_TABLE)
-                                    ("vrc_k_raycast<true,false,false,true,0,unsigned char,8,false>"
-                                     if os.environ.get("VRC_GREY_TABLE", "1")[:1] == "0" else
-                                     "vrc_k_raycast<true,false,false,true,3,unsigned char,14,false>")),
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": tnote,
+                         "valu": valu,
+                         # what the library says it launched (vrc_last_kernel): MODE 3 = the two-float table form of a
+                         # grey transfer function (the linear ramp is one), bit-identical frames (VRC_OPT_GREY_TABLE)
+                         "kernel": launched_kernel,
                          "kernel_ms_per_frame": kernel_ms_per_frame,
                          "algorithmic_bytes_per_launch": per_rank_alg,
                          "algorithmic_bytes_per_frame_all_ranks": alg_bytes,
@@ -777,8 +797,7 @@ def main():
                          "note": "not HBM-bound: the kernel sits on a plateau of vector issue (16.3 instructions per "
                                  "64-sample step = 61 % of the issue slots) and gather latency that five waves per "
                                  "SIMD do not cover; L1 look-ups, loads in flight and occupancy were each changed by "
-                                 "20-40 % without moving the time (DESIGN.md section 4); traffic = FETCH_SIZE + WRITE_SIZE bytes per "
-                                 "launch from profiles/r2_traffic_c2.json"},
+                                 "20-40 % without moving the time (DESIGN.md section 4)"},
         }
         if world == 1 and not a.no_cpu_baseline and not ray_lod_on:
             try:

@@ -292,9 +292,15 @@ int vrc_gather_tiles( vrc_ctx* ctx, vrc_comm* comm, const vrc_band* bands, uint3
                       void* frame_device, size_t frame_stride, int root, void* hip_stream );
 
 const char* vrc_last_error( void );
+/* the kernel instance the calling thread's last vrc_render launched (template arguments spelled as rocprofv3 prints
+ * them), "" before the first: lets a benchmark check that a profile it quotes is a profile of what it ran */
+const char* vrc_last_kernel( void );
 /* ABI version of this header */
 #define VRC_ABI_VERSION 3 /* 3: vrc_gather_tiles takes the frame height */
+/* = VRC_ABI_VERSION for the product build; -VRC_ABI_VERSION for a developer build of the library (compiled with
+ * -DVRC_DEV_BUILD: experiment switches, statistics, ablations that render wrong pixels on purpose) */
 int vrc_abi_version( void );
+int vrc_is_dev_build( void );
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,8 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdarg>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -183,6 +185,14 @@ struct vrc_ctx
 };
 
 int vrc_internal_fail( int code, const std::string& msg ) { return fail( code, msg ); }
+static thread_local char tlsKernel[160] = "";
+void vrc_internal_note_kernel( const char* fmt, ... )
+{
+    va_list ap;
+    va_start( ap, fmt );
+    vsnprintf( tlsKernel, sizeof( tlsKernel ), fmt, ap );
+    va_end( ap );
+}
 hipStream_t vrc_internal_ctx_stream( vrc_ctx* c, int* deviceOut )
 {
     if( deviceOut )
@@ -193,7 +203,14 @@ hipStream_t vrc_internal_ctx_stream( vrc_ctx* c, int* deviceOut )
 extern "C" {
 
 const char* vrc_last_error( void ) { return g_lastError.c_str(); }
+const char* vrc_last_kernel( void ) { return tlsKernel; }
+#if defined( VRC_DEV_BUILD )
+int vrc_abi_version( void ) { return -VRC_ABI_VERSION; }
+int vrc_is_dev_build( void ) { return 1; }
+#else
 int vrc_abi_version( void ) { return VRC_ABI_VERSION; }
+int vrc_is_dev_build( void ) { return 0; }
+#endif
 
 /* ---------------------------------------------------------------------------------------- */
 int vrc_ctx_create( int device, vrc_ctx** out )

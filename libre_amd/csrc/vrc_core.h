@@ -13,6 +13,57 @@
 #ifndef VRC_CORE_H
 #define VRC_CORE_H
 
+/* ---- one guard for every compile-time switch of the kernels (round 3) ------------------------------------------
+ * The product is built with NONE of them on the command line (__graft_entry__.build()).  Timing ablations that
+ * render wrong pixels on purpose (VRC_ABLATE_*), alternative layouts and schedules, statistics builds, the biased
+ * negative control of the parity tests and every tuning value live behind VRC_DEV_BUILD: a stray -DVRC_... without
+ * it does not compile, and a library built with it says so (vrc_abi_version() < 0, vrc_is_dev_build() = 1;
+ * bench.py refuses it).  tools/build_variants.sh and the test harnesses pass -DVRC_DEV_BUILD. */
+#if !defined( VRC_DEV_BUILD ) && ( \
+    defined( VRC_ABLATE_NO_FETCH ) || \
+    defined( VRC_ABLATE_HALF_FETCH ) || \
+    defined( VRC_ABLATE_QUARTER_FETCH ) || \
+    defined( VRC_ZRUN ) || \
+    defined( VRC_SETPRIO ) || \
+    defined( VRC_INT_STEPS ) || \
+    defined( VRC_PIPELINE ) || \
+    defined( VRC_LAYOUT ) || \
+    defined( VRC_LAYOUT_PADX ) || \
+    defined( VRC_LANES_ROWMAJOR ) || \
+    defined( VRC_NO_SERIAL_STEPS ) || \
+    defined( VRC_NO_ADDR_TABLES ) || \
+    defined( VRC_ADDR_TABLES ) || \
+    defined( VRC_TEST_BIAS_ENTRY ) || \
+    defined( VRC_DEV_KNOBS ) || \
+    defined( VRC_LDS_STATS ) || \
+    defined( VRC_LDS_TIMING ) || \
+    defined( VRC_LDS_ABLATE_GATHER ) || \
+    defined( VRC_LDS_NO_STEP_CAP ) || \
+    defined( VRC_LDS_PASSES ) || \
+    defined( VRC_LDS_KMAX ) || \
+    defined( VRC_LDS_MAX_DZ ) || \
+    defined( VRC_LDS_LBATCH ) || \
+    defined( VRC_LDS_GBATCH ) || \
+    defined( VRC_LDS_G ) || \
+    defined( VRC_LDS_WAVES ) || \
+    defined( VRC_LDS_REFILL ) || \
+    defined( VRC_GROUP ) || \
+    defined( VRC_GREY_GROUP ) || \
+    defined( VRC_GREY_PAD_KB ) || \
+    defined( VRC_TAIL_GROUP ) || \
+    defined( VRC_LGROUP ) || \
+    defined( VRC_SPLIT_GROUP ) || \
+    defined( VRC_SMALL_GROUP ) || \
+    defined( VRC_SMALL_LAUNCH_TILES ) || \
+    defined( VRC_TILE_W ) || \
+    defined( VRC_WAVES_PER_WG ) || \
+    defined( VRC_MIN_WAVES ) || \
+    defined( VRC_RL_WAVES ) || \
+    defined( VRC_RL_MIN_BLOCKS ) )
+#error "developer switches of the raycast kernels need -DVRC_DEV_BUILD (the product is built without any of them)"
+#endif
+
+
 #include <stdint.h>
 
 #if defined( __HIPCC__ )
@@ -854,16 +905,32 @@ VRC_HD bool vrc_march_segment_as( const vrc_frame& f, const vrc_dev_node& n, vrc
 #if defined( VRC_ZRUN )
     uint32_t zrunTag = 0xFFFFFFFFu, zrunWord = 0u;
 #endif
+#if defined( VRC_INT_STEPS ) /* developer measurement (round 3): the fast groups counted in integers.
+                              * Only equal to the reference's float chain when the step is a power of two (every
+                              * subtraction is then exact); measured on C2, where it is (1/1024): see DESIGN.md section 4 */
+    uint32_t fastLeft = (uint32_t)( travel / stepSize ); /* exact for a power-of-two step */
+    float travelDone = 0.0f;
+    while( fastLeft > (uint32_t)( GROUP + 1 ) )
+#else
     while( travel > guard )
+#endif
     {
         uint32_t idx[GROUP];
         if( FIXED )
             vrc_group_indices_fixed< GROUP >( sm, fp, idx );
         else
             vrc_group_indices< CLAMP, GROUP >( sm, pos, s.step, idx );
+#if defined( VRC_INT_STEPS )
+        fastLeft -= (uint32_t)GROUP;
+        travelDone += stepSize * (float)GROUP;
+#else
 #pragma unroll
         for( int k = 0; k < GROUP; ++k )
             travel -= stepSize; /* same sequential subtraction as the reference */
+#endif
+#if defined( VRC_SETPRIO ) && defined( __HIP_DEVICE_COMPILE__ ) /* developer measurement */
+        __builtin_amdgcn_s_setprio( 3 );
+#endif
         E e[GROUP];
 #if defined( VRC_ZRUN ) && defined( __HIP_DEVICE_COMPILE__ ) && VRC_LAYOUT == 5
         /* developer experiment (tools/dev_layouts.sh): a lane keeps the dword of its voxel
@@ -907,6 +974,9 @@ VRC_HD bool vrc_march_segment_as( const vrc_frame& f, const vrc_dev_node& n, vrc
             e[k] = vrc_entry< PERSAMPLE, E >( lut, (uint32_t)atlas[idx[k]], cls );
 #endif
         }
+#if defined( VRC_SETPRIO ) && defined( __HIP_DEVICE_COMPILE__ )
+        __builtin_amdgcn_s_setprio( 0 );
+#endif
         const E saved = color;
 #pragma unroll
         for( int k = 0; k < GROUP; ++k )
@@ -931,6 +1001,9 @@ VRC_HD bool vrc_march_segment_as( const vrc_frame& f, const vrc_dev_node& n, vrc
         }
     }
 
+#if defined( VRC_INT_STEPS )
+    travel -= travelDone; /* exact for a power-of-two step */
+#endif
     /* tail: general form, in smaller groups (fewer slots wasted on steps no lane takes) */
 #if defined( VRC_TAIL_GROUP )
     constexpr int TAILG = VRC_TAIL_GROUP;

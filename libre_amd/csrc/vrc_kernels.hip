@@ -580,6 +580,9 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
 #endif
     const uint32_t ldsPad =
         ( MODE == VRC_MODE_GREY && GROUP <= VRC_GREY_GROUP && VRC_WAVES_PER_WG == 4u ) ? VRC_GREY_PAD_KB * 1024u : 0u;
+    vrc_internal_note_kernel( "vrc_k_raycast<%s,%s,%s,%s,%d,%s,%d,%s>", DDA ? "true" : "false", CLAMP ? "true" : "false",
+                              COUNT ? "true" : "false", FIXED ? "true" : "false", (int)MODE,
+                              sizeof( ATLAS_T ) == 1 ? "unsigned char" : "unsigned short", (int)GROUP, BIG ? "true" : "false" );
     hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG > ),
                         dim3( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_WAVES_PER_WG - 1u ) / VRC_WAVES_PER_WG ),
                         dim3( VRC_WG_THREADS ), ldsPad, stream, a.frame, a.nodes, a.gridTable,

@@ -1083,6 +1083,8 @@ hipError_t vrc_launch_raycast_lds( const vrc_raycast_args& a, hipStream_t stream
     const dim3 grid( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_LDS_WAVES - 1u ) / VRC_LDS_WAVES ),
         block( 64u * VRC_LDS_WAVES );
     const bool count = a.sampleCounter != nullptr;
+    vrc_internal_note_kernel( "vrc_k_raycast_lds<%s,%s,%s>", count ? "true" : "false", a.linear ? "true" : "false",
+                              a.greyTable ? "true" : "false" );
 #define VRC_LDS_LAUNCH( COUNT, LINEAR, GREY )                                                         \
     hipLaunchKernelGGL( ( vrc_k_raycast_lds< COUNT, LINEAR, GREY > ), grid, block, 0, stream, a.frame, \
                         a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut, a.classifier,           \

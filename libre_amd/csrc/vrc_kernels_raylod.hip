@@ -99,6 +99,8 @@ static hipError_t launch_raylod( const vrc_raycast_args& a, hipStream_t stream )
     const uint32_t lutEntries = ( MODE == VRC_MODE_TABLE || MODE == VRC_MODE_GREY )
                                     ? a.frame.lodLevels * VRC_LUT_ENTRIES
                                     : VRC_TFP_ENTRIES;
+    vrc_internal_note_kernel( "vrc_k_raycast_raylod<%s,%s,%s,%d,%s>", CLAMP ? "true" : "false", COUNT ? "true" : "false",
+                              FIXED ? "true" : "false", (int)MODE, sizeof( ATLAS_T ) == 1 ? "unsigned char" : "unsigned short" );
     hipLaunchKernelGGL( ( vrc_k_raycast_raylod< CLAMP, COUNT, FIXED, MODE, ATLAS_T > ),
                         dim3( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_RL_WAVES - 1u ) / VRC_RL_WAVES ),
                         dim3( VRC_RL_THREADS ),

@@ -56,7 +56,7 @@ EXPORTS = [
     "vrc_pool_release_slot", "vrc_pool_info", "vrc_pool_synchronize", "vrc_pool_read_region",
     "vrc_pool_histogram",
     "vrc_update", "vrc_pre_render", "vrc_set_row_map", "vrc_set_framebuffer", "vrc_get_framebuffer", "vrc_render",
-    "vrc_post_render", "vrc_synchronize", "vrc_get_stats", "vrc_get_ray_counts", "vrc_last_error", "vrc_abi_version",
+    "vrc_post_render", "vrc_synchronize", "vrc_get_stats", "vrc_get_ray_counts", "vrc_last_error", "vrc_last_kernel", "vrc_abi_version", "vrc_is_dev_build",
     "vrc_comm_unique_id", "vrc_comm_create", "vrc_comm_destroy", "vrc_comm_info", "vrc_gather_tiles",
 ]
 COMM_ID_BYTES = 128
@@ -83,6 +83,8 @@ def load_library(path=None):
     vp = C.c_void_p
     L.vrc_last_error.restype = C.c_char_p
     L.vrc_abi_version.restype = C.c_int
+    L.vrc_is_dev_build.restype = C.c_int
+    L.vrc_last_kernel.restype = C.c_char_p
     L.vrc_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.vrc_ctx_destroy.argtypes = [vp]
     L.vrc_ctx_destroy.restype = None

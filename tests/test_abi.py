@@ -24,7 +24,9 @@ def test_library_exports_every_declared_symbol(built):
     for name in declared:
         assert hasattr(L, name), "libvrc_hip.so does not export %s" % name
     assert sorted(vrc.EXPORTS) == declared
-    assert L.vrc_abi_version() == 3
+    assert L.vrc_abi_version() == 3  # the product build; a -DVRC_DEV_BUILD library reports -3
+    assert L.vrc_is_dev_build() == 0
+    assert L.vrc_last_kernel() == b""
 
 
 def test_comm_of_one_rank_needs_no_rccl_and_no_gpu_for_argument_checks(built):
@@ -74,3 +76,19 @@ def test_no_oracle_in_product_tree():
                     txt = open(os.path.join(root, f), errors="replace").read()
                     assert "livre_oracle" not in txt and "orc_raycast" not in txt, os.path.join(root, f)
                     assert "libharness" not in txt, os.path.join(root, f)
+
+
+def test_developer_switches_need_the_dev_build_guard(tmp_path):
+    # vrc_core.h: a stray -DVRC_ABLATE_NO_FETCH (wrong pixels by design) or any other kernel switch without
+    # -DVRC_DEV_BUILD must not compile; with the guard it does (and such a library reports vrc_abi_version() < 0)
+    import subprocess
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "%s/libre_amd/csrc/vrc_core.h"\nint main() { return 0; }\n'
+                   % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    base = ["g++", "-std=c++17", "-fsyntax-only", "-Wno-unknown-pragmas", str(src)]
+    assert subprocess.run(base, capture_output=True).returncode == 0
+    for sw in ("-DVRC_ABLATE_NO_FETCH", "-DVRC_ZRUN", "-DVRC_PIPELINE", "-DVRC_LAYOUT=5", "-DVRC_LANES_ROWMAJOR",
+               "-DVRC_GROUP=4", "-DVRC_LDS_STATS", "-DVRC_TEST_BIAS_ENTRY"):
+        r = subprocess.run(base + [sw], capture_output=True, text=True)
+        assert r.returncode != 0 and "VRC_DEV_BUILD" in r.stderr, sw
+        assert subprocess.run(base + [sw, "-DVRC_DEV_BUILD"], capture_output=True).returncode == 0, sw

@@ -4,4 +4,4 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p variants
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -fno-slp-vectorize $2 -o variants/libvrc_hip_$1.so libre_amd/csrc/vrc_api.hip libre_amd/csrc/vrc_kernels.hip libre_amd/csrc/vrc_kernels_lds.hip libre_amd/csrc/vrc_kernels_raylod.hip libre_amd/csrc/vrc_comm.hip -ldl
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -fno-slp-vectorize -DVRC_DEV_BUILD $2 -o variants/libvrc_hip_$1.so libre_amd/csrc/vrc_api.hip libre_amd/csrc/vrc_kernels.hip libre_amd/csrc/vrc_kernels_lds.hip libre_amd/csrc/vrc_kernels_raylod.hip libre_amd/csrc/vrc_comm.hip -ldl

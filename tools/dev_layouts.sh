@@ -9,7 +9,7 @@ mkdir -p variants
 S=libre_amd/csrc
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift; shift
-  ( /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -fno-slp-vectorize $flags \
+  ( /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -fno-slp-vectorize -DVRC_DEV_BUILD $flags \
       -o variants/$name.so $S/vrc_api.hip $S/vrc_kernels.hip $S/vrc_kernels_lds.hip $S/vrc_kernels_raylod.hip $S/vrc_comm.hip -ldl \
       > variants/$name.log 2>&1 && echo "built $name" || echo "FAILED $name (variants/$name.log)" ) &
   while [ $(jobs -r | wc -l) -ge 6 ]; do sleep 1; done
