@@ -1093,6 +1093,16 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     if( c->optKernel == VRC_KERNEL_AUTO && useDda && !c->cachedOneCell && !linear &&
         nNodes <= VRC_REFERENCE_ORDER_MAX_NODES )
         useDda = false;
+    /* glRaycaster with more than one sample per pixel (fragRaycast.glsl:121-129): the pixel is averaged brick by
+     * brick in the host's order -- the reference-order loop is the only form that has a "brick by brick" */
+    const bool glSuper = c->optVariant == VRC_VARIANT_GLRAYCASTER && render->samplesPerPixel > 1u;
+    if( glSuper )
+    {
+        if( c->optKernel == VRC_KERNEL_GRID_DDA || c->optKernel == VRC_KERNEL_LDS )
+            return fail( VRC_EINVAL, "vrc_render: the glRaycaster variant with samplesPerPixel > 1 is rendered by the "
+                                     "reference-order kernel (VRC_OPT_KERNEL = AUTO or REFERENCE_ORDER)" );
+        useDda = false;
+    }
     if( c->optKernel == VRC_KERNEL_REFERENCE_ORDER )
         useDda = false;
     else if( c->optKernel == VRC_KERNEL_GRID_DDA && !c->cachedGridOk )
@@ -1105,8 +1115,8 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
                              ( !linear || c->optTfFracBits == 8 );
     if( c->optKernel == VRC_KERNEL_LDS && !ldsEligible )
         return fail( VRC_EINVAL, "vrc_render: the LDS kernel needs a grid-aligned node set of 8-bit bricks with overlap >= 1 (trilinear: VRC_OPT_TF_FRAC_BITS = 8)" );
-    const bool useLds = !c->rayLod && ( c->optKernel == VRC_KERNEL_LDS ||
-                                        ( c->optKernel == VRC_KERNEL_AUTO && linear && ldsEligible ) );
+    const bool useLds = !c->rayLod && !glSuper && ( c->optKernel == VRC_KERNEL_LDS ||
+                                                    ( c->optKernel == VRC_KERNEL_AUTO && linear && ldsEligible ) );
 
     vrc_raycast_args a;
     std::memset( &a, 0, sizeof( a ) );
@@ -1127,6 +1137,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
                         c->fbW, c->fbH, centre, centre );
         f.rowMap = c->rowMap.empty() ? nullptr : c->dRowMap;
         f.variant = c->optVariant == VRC_VARIANT_GLRAYCASTER ? VRC_VARIANT_GL : VRC_VARIANT_CUDA;
+        f.samplesPerPixel = ( f.variant == VRC_VARIANT_GL && render->samplesPerPixel > 1u ) ? render->samplesPerPixel : 1u;
         if( c->rayLod )
         {
             f.lodLevels = c->cachedLodLevels;
@@ -1244,7 +1255,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     }
     c->lastErtParts = a.ertParts;
     /* grey transfer function, frame starting from zero: two-float table entries, the same bits (VRC_MODE_GREY) */
-    a.greyTable = c->optGreyTable && c->tfGrey && f.clearFirst;
+    a.greyTable = c->optGreyTable && c->tfGrey && f.clearFirst && !glSuper; /* (a sub-ray starts from the pixel so far) */
     a.classifier = vrc_make_classifier( lp );
 
     /* order the march after every brick upload issued so far (fixes quirk Q9) */

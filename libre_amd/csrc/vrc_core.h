@@ -156,6 +156,10 @@ struct vrc_frame
     /* 0: cudaRaycaster semantics (cuda/Renderer.cu); 1: the GLSL twin's
      * (glRaycaster/shaders/fragRaycast.glsl), see vrc_brick_segment */
     uint32_t variant;
+    /* glRaycaster variant only: nSamplesPerPixel of fragRaycast.glsl:121-129, :212-214 (>= 1).  More than one:
+     * every brick is marched by that many jittered rays per pixel and the pixel becomes their average, brick by
+     * brick (vrc_pixel_gl_supersampled); the CUDA kernel ignores RenderData.samplesPerPixel (quirk Q3) */
+    uint32_t samplesPerPixel;
     /* 1: first march into a pixel buffer that vrc_pre_render declared cleared but did not touch:
      * every pixel starts from 0 and is stored, hit or miss (the clear of
      * cuda/PixelBufferObject.cu:80 folded into the march: one pass over the frame less) */
@@ -413,12 +417,13 @@ struct vrc_ray
 };
 
 /* Renderer.cu:106-149 + :159-160: pixel -> world ray, global box, clip planes, near plane */
-VRC_HD vrc_ray vrc_setup_ray( const vrc_frame& f, uint32_t px, uint32_t py )
+/* wx, wy: window-space position the ray is cast through (gl_FragCoord of the GLSL twin; its jittered
+ * sub-pixel positions, fragRaycast.glsl:123-127) */
+VRC_HD vrc_ray vrc_setup_ray_at( const vrc_frame& f, float wx, float wy )
 {
     VRC_STRICT_FP
     vrc_ray r;
     /* Renderer.cu:40-51 */
-    const float wx = (float)px + f.pixelOffX, wy = (float)py + f.pixelOffY;
     const float nx = 2.0f * ( wx - f.vpX - ( f.vpW / 2.0f ) ) / f.vpW;
     const float ny = 2.0f * ( wy - f.vpY - ( f.vpH / 2.0f ) ) / f.vpH;
     const vrc_f4 ndc = { nx, ny, 1.0f, 1.0f };
@@ -464,6 +469,26 @@ VRC_HD vrc_ray vrc_setup_ray( const vrc_frame& f, uint32_t px, uint32_t py )
     const vrc_f3 ne = vrc_normalize( e3 );
     r.tNearPlane = -f.nearPlane / ne.z;
     return r;
+}
+
+VRC_HD vrc_ray vrc_setup_ray( const vrc_frame& f, uint32_t px, uint32_t py )
+{
+    VRC_STRICT_FP
+    return vrc_setup_ray_at( f, (float)px + f.pixelOffX, (float)py + f.pixelOffY );
+}
+
+/* rand() of fragRaycast.glsl:59-62: fract(sin(dot(co, vec2(12.9898, 78.233))) * 43758.5453).  What a GL
+ * implementation's sin() returns for arguments of 1e4..1e6 is implementation-defined to more bits than the
+ * factor 43758 leaves, so no two GPUs jitter alike; THIS build defines it with the sine evaluated in double
+ * (libm and the device library agree to the float), the rest in float without contraction -- the oracle's
+ * gl_rand, bit for bit. */
+VRC_HD float vrc_gl_rand( float x, float y )
+{
+    VRC_STRICT_FP
+    const float d = x * 12.9898f + y * 78.233f;
+    const float sn = (float)sin( (double)d );
+    const float v = sn * 43758.5453f;
+    return v - floorf( v );
 }
 
 /* One brick segment of one ray, Renderer.cu:179-201: returns false if the brick is skipped.
@@ -1447,6 +1472,69 @@ VRC_HD bool vrc_pyramid_may_hit( const vrc_tile_pyramid& p, const float bmin[3],
 }
 #define VRC_TILE_CANDIDATES 1024u /* per wave; a tile that could hit more runs the plain loop */
 
+/* glRaycaster with nSamplesPerPixel > 1 (fragRaycast.glsl:113-215; one draw per brick, in the host's order): for
+ * every brick the fragment casts n rays through gl_FragCoord + (rand, rand) / 2, each marches THIS brick starting
+ * from the pixel's colour so far, and the pixel becomes the average of the n results (:212-214).  A `discard` inside
+ * the loop (a sub-ray that misses the volume or the brick, :140-143, :159-160, :176-177) discards the fragment: the
+ * brick then leaves the pixel as it was.  Sub-sample 0 has rand(0,0) = 0: the pixel centre. */
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP, bool BIG = false >
+VRC_HD void vrc_pixel_gl_supersampled( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
+                                       const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
+                                       const vrc_classifier& cls, vrc_f4* __restrict__ pixelBuffer, uint32_t px,
+                                       uint32_t py, uint32_t& nSamples, const uint16_t* candidates,
+                                       uint32_t nCandidates )
+{
+    VRC_STRICT_FP
+    const uint32_t row = f.rowMap ? f.rowMap[py] : py;
+    const uint32_t pixelPos = py * f.width + px;
+    const float fx = (float)px + f.pixelOffX, fy = (float)row + f.pixelOffY; /* gl_FragCoord.xy */
+    const vrc_f4 zero = { 0.f, 0.f, 0.f, 0.f };
+    vrc_f4 color = f.clearFirst ? zero : pixelBuffer[pixelPos];
+    const uint32_t n = f.samplesPerPixel;
+    const float fn = (float)n;
+    const uint32_t nLoop = candidates ? nCandidates : f.nodeCount;
+    for( uint32_t c = 0; c < nLoop; ++c )
+    {
+        if( color.w > VRC_EARLY_EXIT ) /* :115-117: this and every later brick's fragment is discarded */
+            break;
+        const uint32_t i = candidates ? (uint32_t)candidates[c] : c;
+        const vrc_dev_node node = nodes[i];
+        vrc_f4 sum = zero;
+        bool discard = false;
+        uint32_t cnt = 0;
+        for( uint32_t k = 0; k < n; ++k )
+        {
+            const float fk = (float)k;
+            const float dx = vrc_gl_rand( fx * fk, fy * fk ) / 2.0f;
+            const float dy = vrc_gl_rand( fx * 2.0f * fk, fy * 2.0f * fk ) / 2.0f;
+            const vrc_ray r = vrc_setup_ray_at( f, fx + dx, fy + dy );
+            vrc_segment s;
+            bool stop;
+            if( !r.hit || !vrc_brick_segment( f, r, node, f.stepSize, &s, &stop ) )
+            {
+                discard = true;
+                break;
+            }
+            vrc_f4 local = color;
+            (void)vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >( f, node, s, atlas, lut, cls, local, cnt );
+            sum.x += local.x;
+            sum.y += local.y;
+            sum.z += local.z;
+            sum.w += local.w;
+        }
+        if( !discard )
+        {
+            color.x = sum.x / fn;
+            color.y = sum.y / fn;
+            color.z = sum.z / fn;
+            color.w = sum.w / fn;
+            if( COUNT )
+                nSamples += cnt;
+        }
+    }
+    pixelBuffer[pixelPos] = color;
+}
+
 template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP, bool BIG = false >
 VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
                                        const ATLAS_T* __restrict__ atlas, const vrc_f4* lut,
@@ -1455,6 +1543,12 @@ VRC_HD void vrc_pixel_reference_order( const vrc_frame& f, const vrc_dev_node* _
                                        uint32_t& nSamples, const uint16_t* candidates = nullptr,
                                        uint32_t nCandidates = 0 )
 {
+    if( f.variant == VRC_VARIANT_GL && f.samplesPerPixel > 1u )
+    {
+        vrc_pixel_gl_supersampled< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >( f, nodes, atlas, lut, cls, pixelBuffer,
+                                                                                   px, py, nSamples, candidates, nCandidates );
+        return;
+    }
     const vrc_ray r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
     const uint32_t pixelPos = py * f.width + px;
     const vrc_f4 zero = { 0.f, 0.f, 0.f, 0.f };

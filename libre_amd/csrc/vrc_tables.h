@@ -335,6 +335,7 @@ inline void vrc_fill_frame( vrc_frame& f, const vrc_view_data& view, const vrc_r
     f.sbx = geom.slotDim[0] / VRC_MB;
     f.sby = geom.slotDim[1] / VRC_MB;
     f.rowMap = nullptr;
+    f.samplesPerPixel = 1u; /* the caller sets it for the glRaycaster variant */
     f.lodLevels = 0;
     f.lodBase = 0.f;
 }

@@ -941,11 +941,175 @@ static uint64_t raycast_pixel( const job_t* j, uint32_t x, uint32_t y )
 }
 
 
+/* rand() of fragRaycast.glsl:59-62.  sin() of arguments up to ~1e6 is implementation-defined in GLSL to more
+ * bits than the factor 43758.5453 leaves, so the jitter is "unpinned" by construction; this restatement fixes it:
+ * dot product and the rest in float, the sine in double (vrc_gl_rand in vrc_core.h is the same definition). */
+static float gl_rand( float x, float y )
+{
+    const float d = x * 12.9898f + y * 78.233f;
+    const float sn = (float)sin( (double)d );
+    const float v = sn * 43758.5453f;
+    return v - floorf( v );
+}
+
+/* glRaycaster with nSamplesPerPixel > 1 (fragRaycast.glsl:113-215): one fragment per pixel and BRICK; for each of
+ * the n jittered sub-pixel rays the brick is marched starting from the pixel's colour so far (localResult = result,
+ * :125), the pixel becomes the average of the n results (:212-214).  Any `discard` inside the sub-sample loop
+ * (:140-143, :159-160, :176-177) discards the whole fragment: that brick leaves the pixel unchanged.  The tie budget
+ * (test instrument) gets each sub-ray's ties divided by n; the parts that follow a single ray past its early exit
+ * are not carried over (the tests of this mode use transfer functions that do not reach the threshold). */
+static uint64_t raycast_pixel_gl_ss( const job_t* j, uint32_t x, uint32_t y )
+{
+    const orc_view_data* viewData = j->view;
+    const orc_render_data* renderData = j->render;
+    uint64_t nSamples = 0;
+    const uint32_t n = renderData->samplesPerPixel;
+    const size_t pixelPos = (size_t)y * j->width + x;
+    float* px = j->pixelBuffer + pixelPos * 4;
+    float color[4] = { px[0], px[1], px[2], px[3] };
+    const float fx = (float)x + 0.5f, fy = (float)y + 0.5f; /* gl_FragCoord.xy */
+    const f3 eyePos = { viewData->eyePosition[0], viewData->eyePosition[1], viewData->eyePosition[2] };
+    const f3 origin = eyePos;
+    const f3 globalBoxMin = { viewData->aabbMin[0], viewData->aabbMin[1], viewData->aabbMin[2] };
+    const f3 globalBoxMax = { viewData->aabbMax[0], viewData->aabbMax[1], viewData->aabbMax[2] };
+    const float r0 = renderData->dataSourceRange[0], r1 = renderData->dataSourceRange[1];
+    const float multiplyer = 1.0f / ( r1 - r0 );
+    const float addedValue = -r0 / ( r1 - r0 );
+    const float alphaCorrection = (float)renderData->maxSamplesPerRay / (float)renderData->samplesPerRay;
+    const float stepSize = 1.0f / (float)renderData->samplesPerRay;
+
+    for( uint32_t i = 0; i < j->nodeCount; ++i )
+    {
+        if( color[3] > EARLY_EXIT ) /* :115-117 */
+            break;
+        const orc_node_data* nodeData = &j->nodes[i];
+        const f3 boxMin = { nodeData->aabbMin[0], nodeData->aabbMin[1], nodeData->aabbMin[2] };
+        const f3 boxSize = { nodeData->aabbSize[0], nodeData->aabbSize[1], nodeData->aabbSize[2] };
+        const f3 boxMax = { boxMin.x + boxSize.x, boxMin.y + boxSize.y, boxMin.z + boxSize.z };
+        const f3 texMin = { nodeData->textureMin[0], nodeData->textureMin[1], nodeData->textureMin[2] };
+        const f3 texSize = { nodeData->textureSize[0], nodeData->textureSize[1], nodeData->textureSize[2] };
+        const f3 vpw = { texSize.x * (float)j->atlasDim[0] / boxSize.x, texSize.y * (float)j->atlasDim[1] / boxSize.y,
+                         texSize.z * (float)j->atlasDim[2] / boxSize.z };
+        float brickResult[4] = { 0.f, 0.f, 0.f, 0.f };
+        float budget = 0.0f;
+        uint64_t cnt = 0;
+        int discard = 0;
+        for( uint32_t k = 0; k < n && !discard; ++k )
+        {
+            const float fk = (float)k;
+            const float xPixelDelta = gl_rand( fx * fk, fy * fk ) / 2.0f;                     /* :123 */
+            const float yPixelDelta = gl_rand( fx * 2.0f * fk, fy * 2.0f * fk ) / 2.0f;       /* :124 */
+            float localResult[4] = { color[0], color[1], color[2], color[3] };               /* :125 */
+            const f4 pixelEyeSpacePos = eye_space_from_window( fx + xPixelDelta, fy + yPixelDelta,
+                                                               viewData->glViewport, viewData->invProjMatrix );
+            const f4 pixelWorldSpacePos = mat_mul_vec4( viewData->invViewMatrix, pixelEyeSpacePos );
+            const f3 d0 = { pixelWorldSpacePos.x - eyePos.x, pixelWorldSpacePos.y - eyePos.y,
+                            pixelWorldSpacePos.z - eyePos.z };
+            f3 dir = normalize_f3( d0 );
+            if( dir.x == 0.0f ) dir.x = EPSILON;
+            if( dir.y == 0.0f ) dir.y = EPSILON;
+            if( dir.z == 0.0f ) dir.z = EPSILON;
+            float tnearGlobal, tfarGlobal;
+            intersect_box( origin, dir, globalBoxMin, globalBoxMax, &tnearGlobal, &tfarGlobal );
+            if( !( tnearGlobal <= tfarGlobal ) ) { discard = 1; break; }                      /* :139-140 */
+            float tnear = 0.0f, tfar = 0.0f;
+            intersect_box( origin, dir, boxMin, boxMax, &tnear, &tfar );
+            if( !( tnear <= tfar ) ) { discard = 1; break; }                                  /* :142-143 */
+            const f3 e3 = { pixelEyeSpacePos.x, pixelEyeSpacePos.y, pixelEyeSpacePos.z };
+            const f3 nPixelEyeSpacePos = normalize_f3( e3 );
+            const float tNearPlane = -viewData->nearPlane / nPixelEyeSpacePos.z;
+            if( tnear < tNearPlane )
+                tnear = tNearPlane;
+            const float a = tnear - tnearGlobal;
+            const float residu = a - stepSize * floorf( a / stepSize ); /* GLSL mod() */
+            if( residu > 0.0f )
+                tnear += stepSize - residu;
+            if( tnear > tfar ) { discard = 1; break; }                                        /* :159-160 */
+            for( uint32_t p = 0; p < j->nPlanes; ++p )
+            {
+                const float* cp = j->clipPlanes + 4 * p;
+                const f3 planeNormal = { cp[0], cp[1], cp[2] };
+                float rn = dot3( dir, planeNormal );
+                if( rn == 0.0f )
+                    rn = EPSILON;
+                const float t = -( dot3( planeNormal, eyePos ) + cp[3] ) / rn;
+                if( rn > 0.0f )
+                    tnear = fmaxf( tnear, t );
+                else
+                    tfar = fminf( tfar, t );
+            }
+            if( tnear > tfar ) { discard = 1; break; }                                        /* :176-177 */
+            const f3 rayStart = { origin.x + dir.x * tnear, origin.y + dir.y * tnear, origin.z + dir.z * tnear };
+            const f3 rayStop = { origin.x + dir.x * tfar, origin.y + dir.y * tfar, origin.z + dir.z * tfar };
+            f3 pos = rayStart;
+            const f3 diff = { rayStop.x - rayStart.x, rayStop.y - rayStart.y, rayStop.z - rayStart.z };
+            const f3 ndiff = normalize_f3( diff );
+            const f3 step = { ndiff.x * stepSize, ndiff.y * stepSize, ndiff.z * stepSize };
+            const float dist = sqrtf( dot3( diff, diff ) );
+            const float endEps = 4e-6f * fmaxf( 1.0f, fabsf( tfar ) );
+            uint32_t kStep = 0;
+            float travel;
+            for( travel = dist; travel > 0.0f;
+                 pos.x += step.x, pos.y += step.y, pos.z += step.z, travel -= stepSize, ++kStep )
+            {
+                const f3 texPos = { ( ( pos.x - boxMin.x ) / boxSize.x ) * texSize.x + texMin.x,
+                                    ( ( pos.y - boxMin.y ) / boxSize.y ) * texSize.y + texMin.y,
+                                    ( ( pos.z - boxMin.z ) / boxSize.z ) * texSize.z + texMin.z };
+                const float density = j->opt.filter
+                                          ? fetch_trilinear( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos )
+                                          : fetch_nearest( j->atlas, j->opt.voxelBytes, j->atlasDim, texPos );
+                if( j->opt.tieBudget ) /* test instrument, see orc_options */
+                {
+                    if( !j->opt.filter )
+                        budget += tie_budget( j, texPos, density, multiplyer, addedValue, alphaCorrection,
+                                              1.0f - localResult[3], kStep, vpw );
+                    if( travel <= endEps && kStep > 0 )
+                        budget += sample_weight( j, texPos, multiplyer, addedValue, alphaCorrection,
+                                                 1.0f - localResult[3] );
+                }
+                float transferFn[4];
+                orc_tf_fetch( j->tf, density * multiplyer + addedValue, j->opt.tfFracBits, transferFn );
+                orc_composite( transferFn, localResult, alphaCorrection );
+                ++cnt;
+                if( localResult[3] > EARLY_EXIT ) /* :205-206 */
+                    break;
+            }
+            if( j->opt.tieBudget && travel > -endEps && travel <= 0.0f && kStep > 0 ) /* a sample that barely was not taken */
+            {
+                const f3 texPos = { ( ( pos.x - boxMin.x ) / boxSize.x ) * texSize.x + texMin.x,
+                                    ( ( pos.y - boxMin.y ) / boxSize.y ) * texSize.y + texMin.y,
+                                    ( ( pos.z - boxMin.z ) / boxSize.z ) * texSize.z + texMin.z };
+                budget += sample_weight( j, texPos, multiplyer, addedValue, alphaCorrection, 1.0f - localResult[3] );
+            }
+            brickResult[0] += localResult[0];
+            brickResult[1] += localResult[1];
+            brickResult[2] += localResult[2];
+            brickResult[3] += localResult[3];
+        }
+        if( discard )
+            continue;
+        const float fn = (float)n;
+        color[0] = brickResult[0] / fn; /* :214 */
+        color[1] = brickResult[1] / fn;
+        color[2] = brickResult[2] / fn;
+        color[3] = brickResult[3] / fn;
+        nSamples += cnt;
+        if( j->opt.tieBudget )
+            j->opt.tieBudget[pixelPos] += budget / fn;
+    }
+    px[0] = color[0];
+    px[1] = color[1];
+    px[2] = color[2];
+    px[3] = color[3];
+    return nSamples;
+}
+
 /* one pixel of the GLSL twin, renderers/glRaycaster/shaders/fragRaycast.glsl:113-215, with the
  * per-brick draws (GLRaycastRenderer.cpp:431-510) folded into one loop over the sorted bricks:
  * the accumulation image (imageLoad/imageStore, :115, :214) is the running colour; a brick the
  * ray misses or that lies behind the early-exit threshold is "discard".  nSamplesPerPixel = 1
- * (jitter rand(0,0)/2 = 0, :121-127).  Differences from Renderer.cu, line by line:
+ * (jitter rand(0,0)/2 = 0, :121-127; more samples per pixel: raycast_pixel_gl_ss above).  Differences from
+ * Renderer.cu, line by line:
  *   :127     gl_FragCoord = pixel centre (x+0.5, y+0.5), the CUDA kernel uses (x, y)
  *   :101     intersectBox returns t0 <= t1 (CUDA: tfar > tnear)
  *   :149-150 tnear is raised to the near plane only (CUDA also clamps to the global interval)
@@ -1529,7 +1693,8 @@ static void* worker_main( void* p )
         const uint32_t y = (uint32_t)y64;
         for( uint32_t x = 0; x < j->width; ++x )
             n += j->lod ? raycast_pixel_ray_lod( j, x, y )
-                        : j->opt.variant == 1 ? raycast_pixel_gl( j, x, y ) : raycast_pixel( j, x, y );
+                        : j->opt.variant == 1 ? ( j->render->samplesPerPixel > 1u ? raycast_pixel_gl_ss( j, x, y ) : raycast_pixel_gl( j, x, y ) )
+                                              : raycast_pixel( j, x, y );
     }
     w->samples = n;
     return NULL;

@@ -91,6 +91,7 @@ static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3]
     vrc_fill_frame( f, *view, *render, geom, t.g, pl, nPlanes, nNodes, W, H, (float)pixelOffX + centre,
                     (float)pixelOffY + centre );
     f.variant = variant == 1 ? VRC_VARIANT_GL : VRC_VARIANT_CUDA;
+    f.samplesPerPixel = ( variant == 1 && render->samplesPerPixel > 1u ) ? render->samplesPerPixel : 1u;
     if( rayLod )
     {
         f.lodLevels = t.lodLevels;

@@ -287,6 +287,28 @@ def test_glraycaster_variant_matches_its_oracle(name):
         assert abs(n_got - n_want) <= 3e-4 * n_want + 8
 
 
+@pytest.mark.parametrize("name,spp", [("hash64_spin", 2), ("hash64_axis", 4), ("mem_ragged", 3), ("hash_clip", 2)])
+def test_glraycaster_supersampling_matches_its_oracle(name, spp):
+    # glRaycaster with nSamplesPerPixel > 1 (fragRaycast.glsl:121-129, :212-214): every brick marched by spp jittered
+    # rays per pixel from the pixel's colour so far, the pixel their average; a sub-ray that misses discards the brick
+    # for the pixel.  The reference-order loop is the form that renders it (the GLSL twin is one draw per brick).
+    import ctypes as C
+    s = scenes.get(name)
+    s.render = orc.RenderData(s.render.samplesPerRay, spp, s.render.maxSamplesPerRay, s.render.datatype,
+                              (C.c_float * 2)(*s.render.dataSourceRange))
+    want, n_want = orc.oracle_render(s, threads=4, variant=1)
+    one = scenes.get(name)
+    want1, _ = orc.oracle_render(one, threads=4, variant=1)
+    assert np.abs(want - want1).max() > 1e-3  # the jitter does something
+    got, n_got, _ = orc.harness_render(s, kernel=1, variant=1)
+    scenes.assert_parity(got, want, "%s gl spp %d" % (name, spp))
+    assert abs(n_got - n_want) <= 3e-4 * n_want + 8
+    # sub-sample 0 is the pixel centre (rand(0, 0) = 0): spp = 1 through the same code is the plain GL frame
+    s.render.samplesPerPixel = 1
+    got1, _, _ = orc.harness_render(s, kernel=1, variant=1)
+    scenes.assert_parity(got1, want1, "%s gl spp 1" % name)
+
+
 def test_the_two_reference_variants_differ():
     s = scenes.get("hash64_spin")
     cuda, _ = orc.oracle_render(s, threads=4)

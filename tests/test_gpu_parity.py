@@ -218,6 +218,28 @@ def test_glraycaster_variant_parity(vrc, name):
         scenes.assert_parity(back, orc.oracle_render(s, threads=8)[0], name + " cuda after gl")
 
 
+@pytest.mark.parametrize("name,spp", [("hash64_spin", 2), ("hash64_axis", 4), ("mem_ragged", 3), ("hash_clip", 2)])
+def test_glraycaster_supersampling_parity(vrc, name, spp):
+    # glRaycaster with nSamplesPerPixel > 1 (fragRaycast.glsl:121-129, :212-214): spp jittered rays per pixel and
+    # brick, averaged brick by brick; rendered by the reference-order kernel (AUTO selects it), refused by the others
+    s = scenes.get(name)
+    s.render = orc.RenderData(s.render.samplesPerRay, spp, s.render.maxSamplesPerRay, s.render.datatype,
+                              (C.c_float * 2)(*s.render.dataSourceRange))
+    want, n_want = orc.oracle_render(s, threads=8, variant=1)
+    with _gpu(s) as g:
+        got, n_got, st = g.render(variant=vrc.VARIANT_GLRAYCASTER)
+        assert st.kernel_variant == vrc.KERNEL_REFERENCE_ORDER
+        scenes.assert_parity(got, want, "%s gl spp %d" % (name, spp))
+        assert abs(n_got - n_want) <= 3e-4 * n_want + 8
+        for k in (vrc.KERNEL_GRID_DDA, vrc.KERNEL_LDS):
+            with pytest.raises(vrc.VrcError):
+                g.render(kernel=k, variant=vrc.VARIANT_GLRAYCASTER)
+        # the CUDA variant ignores samplesPerPixel (quirk Q3)
+        cuda, _, _ = g.render()
+        one = scenes.get(name)
+        scenes.assert_parity(cuda, orc.oracle_render(one, threads=8)[0], name + " cuda ignores spp")
+
+
 def test_brick_histogram_side_kernel(vrc):
     # tests/lib/cache.cpp:103-120 (known answer): mem://#1024,1024,512,32, first child of the
     # root: every interior voxel is 17, 32^3 voxels x scale 8^3 = 2^24 in bin 17, nothing else
