@@ -55,6 +55,9 @@ void lvh_app_destroy( lvh_app* app );
 int lvh_app_set_camera( lvh_app* app, const float position[3], const float lookat[3],
                         float spin_x, float spin_y );
 int lvh_app_set_modelview( lvh_app* app, const float mv[16] );
+/* FrameInfo::timeStep of the following frames (the frame number of livre/eq/Channel.cpp:259-270): must lie in the
+ * data source's frame range (lvh_datasource_frame_range) */
+int lvh_app_set_time_step( lvh_app* app, uint32_t time_step );
 int lvh_app_set_colormap( lvh_app* app, const float rgba256[1024] );
 int lvh_app_set_clip_planes( lvh_app* app, const float* planes, uint32_t n );
 /* sort-first row bands rendered by this process in one launch: bands (y0[i], h[i]) of the full
@@ -127,6 +130,9 @@ int lvh_datasource_brick( const char* volume_uri, uint64_t node_id, uint8_t* out
 int lvh_datasource_info( const char* volume_uri, uint32_t voxels[3], uint32_t max_block[3],
                          uint32_t overlap[3], float world_size[3], uint32_t* depth,
                          uint32_t root_blocks[3], uint32_t* data_type, uint32_t* comp_count );
+/* VolumeInformation::frameRange: [first, end) of the time steps the source holds (livre/core/data/
+ * VolumeInformation.h; uvf://: one per TOC block of the file, datasources/uvf/UVFDataSource.cpp:144) */
+int lvh_datasource_frame_range( const char* volume_uri, uint32_t range[2] );
 int lvh_datasource_node( const char* volume_uri, uint64_t node_id, int* valid, uint32_t block_size[3],
                          uint32_t voxel_box[6], float world_box[6] );
 

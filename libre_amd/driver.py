@@ -26,7 +26,7 @@ class FrameStats(C.Structure):  # lvh_frame_stats
 
 EXPORTS = [
     "lvh_last_error", "lvh_app_create", "lvh_app_destroy", "lvh_app_set_camera",
-    "lvh_app_set_modelview", "lvh_app_set_colormap", "lvh_app_set_clip_planes",
+    "lvh_app_set_modelview", "lvh_app_set_time_step", "lvh_datasource_frame_range", "lvh_app_set_colormap", "lvh_app_set_clip_planes",
     "lvh_app_set_bands", "lvh_app_set_frames_in_flight", "lvh_app_select_slot", "lvh_app_set_option", "lvh_app_set_data_range", "lvh_app_set_ray_lod", "lvh_app_set_stream", "lvh_app_set_framebuffer", "lvh_app_render_frame",
     "lvh_app_get_stats", "lvh_app_wait_uploads", "lvh_app_synchronize", "lvh_app_volume_info",
     "lvh_comm_unique_id", "lvh_app_comm_create", "lvh_app_set_layout", "lvh_app_gather_tiles",
@@ -120,6 +120,9 @@ class App:
     def set_camera(self, position=(0.0, 0.0, 1.5), lookat=(0.0, 0.0, 0.0), spin=(0.0, 0.0)):
         check(self.L, self.L.lvh_app_set_camera(self.h, (C.c_float * 3)(*position),
                                                 (C.c_float * 3)(*lookat), spin[0], spin[1]))
+
+    def set_time_step(self, t):
+        check(self.L, self.L.lvh_app_set_time_step(self.h, C.c_uint32(t)))
 
     def set_colormap(self, rgba256):
         a = np.ascontiguousarray(rgba256, dtype=np.float32).reshape(1024)
@@ -268,6 +271,13 @@ def datasource_info(volume_uri):
                                    C.byref(cc)))
     return dict(voxels=list(v), max_block=list(mb), overlap=list(ov), world_size=list(ws), depth=depth.value,
                 root_blocks=list(rb), data_type=dt.value, comp_count=cc.value)
+
+
+def datasource_frame_range(volume_uri):
+    L = load_library()
+    r = (C.c_uint32 * 2)()
+    check(L, L.lvh_datasource_frame_range(volume_uri.encode(), r))
+    return (int(r[0]), int(r[1]))
 
 
 def datasource_node(volume_uri, node_id):

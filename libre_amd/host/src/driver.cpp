@@ -29,6 +29,7 @@ struct lvh_app
     RenderSettings renderSettings;
     RendererParameters vrParameters;
     uint32_t frameId = 0;
+    uint32_t timeStep = 0;                 /* lvh_app_set_time_step: FrameInfo::timeStep (livre/eq/Channel.cpp:259-270) */
     RenderStatistics lastStats;
     std::vector< uint32_t > rowMap; /* lvh_app_set_bands */
     std::vector< std::unique_ptr< Renderer > > extraRenderers; /* frames in flight beyond the first */
@@ -90,7 +91,7 @@ struct lvh_app
         uint32_t t[4];
         tile( t );
         const Frustum frustum( camera.getModelViewMatrix(), projection() );
-        return RenderInputs{ FrameInfo( frustum, 0, frameId ),
+        return RenderInputs{ FrameInfo( frustum, timeStep, frameId ),
                              Range{ { 0.0f, 1.0f } },
                              dataSourceRange(),
                              PixelViewport( 0, 0, int32_t( t[2] ), int32_t( t[3] ) ),
@@ -157,6 +158,16 @@ int lvh_app_set_camera( lvh_app* app, const float pos[3], const float lookat[3],
     app->camera.setCameraPosition( Vector3f( pos[0], pos[1], pos[2] ) );
     app->camera.setCameraLookAt( Vector3f( lookat[0], lookat[1], lookat[2] ) );
     app->camera.spinModel( sx, sy );
+    return 0;
+}
+
+int lvh_app_set_time_step( lvh_app* app, uint32_t timeStep )
+{
+    if( !app ) return fail( "NULL argument" );
+    const Vector2ui range = app->dataSource->getVolumeInfo().frameRange;
+    if( timeStep < range[0] || timeStep >= range[1] )
+        return fail( "lvh_app_set_time_step: time step outside the data source's frame range" );
+    app->timeStep = timeStep;
     return 0;
 }
 
@@ -659,6 +670,23 @@ int lvh_datasource_info( const char* uri, uint32_t voxels[3], uint32_t maxBlock[
         if( depth ) *depth = vi.rootNode.getDepth();
         if( dataType ) *dataType = uint32_t( vi.dataType );
         if( compCount ) *compCount = vi.compCount;
+        return 0;
+    }
+    catch( const std::exception& e )
+    {
+        return fail( e.what() );
+    }
+}
+
+int lvh_datasource_frame_range( const char* uri, uint32_t range[2] )
+{
+    try
+    {
+        if( !uri || !range ) return fail( "NULL argument" );
+        DataSource dataSource{ std::string( uri ) };
+        const Vector2ui r = dataSource.getVolumeInfo().frameRange;
+        range[0] = r[0];
+        range[1] = r[1];
         return 0;
     }
     catch( const std::exception& e )

@@ -73,7 +73,7 @@ struct TocEntry
 class UVFDataSource : public DataSourcePlugin
 {
 public:
-    explicit UVFDataSource( const DataSourcePluginData& initData ) : _map( nullptr ), _fd( -1 ), _size( 0 ), _offset( 0 )
+    explicit UVFDataSource( const DataSourcePluginData& initData ) : _map( nullptr ), _fd( -1 ), _size( 0 )
     {
         const std::string& path = initData.getURI().getPath();
         _fd = ::open( path.c_str(), O_RDONLY );
@@ -140,6 +140,15 @@ public:
         const Vector3ui pos = node.getAbsolutePosition();
         const size_t index = _lodFirstEntry[lod] + pos[0] + size_t( pos[1] ) * layout[0] +
                              size_t( pos[2] ) * layout[0] * layout[1];
+        /* the brick key carries the frame (UVFDataSource.cpp:258-261).  The reference then reads the entry from the
+         * FIRST table of contents whatever the frame (its _uvfTOCBlock and _offset are those of the first TOC block,
+         * :152-200, :264-267): every frame shows time step 0.  Here every TOC block of the file is a time step with
+         * its own table and payload (Tuvok's UVFDataset does the same when it opens the file). */
+        const uint32_t frame = node.getNodeId().getTimeStep();
+        if( frame >= _steps.size() )
+            throw std::runtime_error( "UVF: time step outside the data set" );
+        const std::vector< TocEntry >& _toc = _steps[frame].toc;
+        const size_t _offset = _steps[frame].offset;
         if( index >= _toc.size() )
             throw std::runtime_error( "UVF: brick index outside the table of contents" );
         const TocEntry& e = _toc[index];
@@ -180,38 +189,16 @@ private:
                           ( _lodSize[lod][2] + inner[2] - 1 ) / inner[2] );
     }
 
-    void parse()
+    /* one table of contents = one time step: ExtendedOctree header (105 bytes) + one entry per brick */
+    void parseTocBlock( Reader& r, bool first )
     {
-        Reader r{ static_cast< const uint8_t* >( _map ), _size, 0 };
-        if( _size < 8 || std::memcmp( r.p, "UVF-DATA", 8 ) != 0 )
-            throw std::runtime_error( "UVF data format initialization failed" );
-        r.pos = 8;
-        _volumeInfo.bigEndian = r.get< uint8_t >() != 0;
-        if( _volumeInfo.bigEndian )
-            throw std::runtime_error( "UVF data format initialization failed" );
-        r.get< uint64_t >(); /* version */
-        r.get< uint64_t >(); /* checksum semantics */
-        const uint64_t checksumLength = r.get< uint64_t >();
-        r.skip( size_t( checksumLength ) );
-        r.get< uint64_t >(); /* offset to the first data block */
+        Timestep step;
+        step.offset = r.pos; /* brick offsets count from here (:167-190) */
 
-        /* walk the chain of data blocks to the table of contents (UVFDataSource.cpp:152-165) */
-        for( ;; )
-        {
-            const size_t blockStart = r.pos;
-            const uint64_t idLength = r.get< uint64_t >();
-            r.skip( size_t( idLength ) );
-            const uint64_t semantics = r.get< uint64_t >();
-            r.get< uint64_t >(); /* block compression scheme */
-            const uint64_t next = r.get< uint64_t >();
-            if( semantics == BS_TOC_BLOCK )
-                break;
-            if( next == 0 )
-                throw std::runtime_error( "UVF TOC block not found in data set" );
-            r.pos = blockStart + size_t( next );
-        }
-        _offset = r.pos; /* brick offsets count from here (:167-190) */
-
+        const VolumeInformation before = _volumeInfo;
+        const std::vector< Vector3ui > lodSizeBefore = _lodSize;
+        _lodSize.clear();
+        _lodFirstEntry.clear();
         const uint32_t componentType = r.get< uint32_t >();
         _volumeInfo.compCount = uint32_t( r.get< uint64_t >() );
         r.get< uint8_t >(); /* precomputed normals */
@@ -245,7 +232,6 @@ private:
         const float maxDomain = float( _volumeInfo.voxels.find_max() );
         _volumeInfo.worldSpacePerVoxel = 1.0f / maxDomain;
         _volumeInfo.worldSize = Vector3f( float( domain[0] ), float( domain[1] ), float( domain[2] ) ) / maxDomain;
-        _volumeInfo.frameRange = Vector2ui( 0u, 1u );
 
         /* LOD pyramid: halve, rounding up, down to one voxel */
         Vector3ui s = _volumeInfo.voxels;
@@ -263,8 +249,8 @@ private:
             const Vector3ui layout = brickLayout( l );
             nBricks += size_t( layout[0] ) * layout[1] * layout[2];
         }
-        _toc.resize( nBricks );
-        for( TocEntry& e : _toc )
+        step.toc.resize( nBricks );
+        for( TocEntry& e : step.toc )
         {
             e.offset = r.get< uint64_t >();
             e.length = r.get< uint64_t >();
@@ -272,6 +258,54 @@ private:
             e.uncompressed = r.get< uint64_t >();
             r.get< uint64_t >();
         }
+        if( !first && ( before.voxels != _volumeInfo.voxels || before.maximumBlockSize != _volumeInfo.maximumBlockSize ||
+                        before.overlap != _volumeInfo.overlap || before.dataType != _volumeInfo.dataType ||
+                        before.compCount != _volumeInfo.compCount || lodSizeBefore != _lodSize ) )
+            throw std::runtime_error( "UVF: time steps of different shapes" );
+        _steps.push_back( std::move( step ) );
+    }
+
+    void parse()
+    {
+        Reader r{ static_cast< const uint8_t* >( _map ), _size, 0 };
+        if( _size < 8 || std::memcmp( r.p, "UVF-DATA", 8 ) != 0 )
+            throw std::runtime_error( "UVF data format initialization failed" );
+        r.pos = 8;
+        _volumeInfo.bigEndian = r.get< uint8_t >() != 0;
+        if( _volumeInfo.bigEndian )
+            throw std::runtime_error( "UVF data format initialization failed" );
+        r.get< uint64_t >(); /* version */
+        r.get< uint64_t >(); /* checksum semantics */
+        const uint64_t checksumLength = r.get< uint64_t >();
+        r.skip( size_t( checksumLength ) );
+        r.get< uint64_t >(); /* offset to the first data block */
+
+        /* walk the chain of data blocks (UVFDataSource.cpp:152-165 stops at the first table of contents; Tuvok's
+         * UVFDataset::Open takes every TOC block as one time step, and GetNumberOfTimesteps() -- the reference's
+         * frame range, :144 -- counts them) */
+        bool first = true;
+        for( ;; )
+        {
+            const size_t blockStart = r.pos;
+            const uint64_t idLength = r.get< uint64_t >();
+            r.skip( size_t( idLength ) );
+            const uint64_t semantics = r.get< uint64_t >();
+            r.get< uint64_t >(); /* block compression scheme */
+            const uint64_t next = r.get< uint64_t >();
+            if( semantics == BS_TOC_BLOCK )
+            {
+                parseTocBlock( r, first );
+                first = false;
+            }
+            if( next == 0 )
+                break;
+            if( next > _size || blockStart > _size - size_t( next ) )
+                throw std::runtime_error( "UVF data format initialization failed" );
+            r.pos = blockStart + size_t( next );
+        }
+        if( _steps.empty() )
+            throw std::runtime_error( "UVF TOC block not found in data set" );
+        _volumeInfo.frameRange = Vector2ui( 0u, uint32_t( _steps.size() ) );
 
         /* UVFDataSource.cpp:77-92: the tree is as deep as the LODs whose brick layout is still
          * more than one brick in every direction, plus the one above */
@@ -290,10 +324,14 @@ private:
     void* _map;
     int _fd;
     size_t _size;
-    size_t _offset;
     std::vector< Vector3ui > _lodSize;
     std::vector< size_t > _lodFirstEntry;
-    std::vector< TocEntry > _toc;
+    struct Timestep
+    {
+        size_t offset = 0;
+        std::vector< TocEntry > toc;
+    };
+    std::vector< Timestep > _steps; /* one per TOC block of the file */
 };
 
 namespace

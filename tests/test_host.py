@@ -1,6 +1,7 @@
 """Host-side (C++ mirror of Libre's plugin surface) checks that need no GPU: the reference's
 own unit-test known answers, restated against libLivreHipRaycastPipeline.so."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -236,6 +237,52 @@ def test_raw_data_source_bricked_out_of_core(drv, tmp_path, dtype):
     assert (whole.view(vol.dtype) == vol.ravel()).all()
 
 
+def test_raw_pyramid_is_kept_on_disk(drv, tmp_path, monkeypatch):
+    # the LOD pyramid of a bricked raw:// volume: the first run that builds it leaves <file>.lvpyr next to the volume,
+    # later runs map it (datasource_brick opens the source anew every call = a new "run"); a file that belongs to
+    # other data is recognised (size / mtime / shape in its header) and replaced; LIVRE_HIP_PYRAMID=0 turns it off
+    vol = orc.hash_volume(48, 32, 64).astype(np.uint16) * np.uint16(257)
+    path = str(tmp_path / "vol.raw")
+    vol.tofile(path)
+    uri = "raw://%s#48,32,64,uint16,16" % path
+    vi = orc.mem_volume_info(48, 32, 64, 16)
+    coarse = orc.pack(vi.depth - 2, 0, 0, 0)
+    pyr = path + ".lvpyr"
+    monkeypatch.setenv("LIVRE_HIP_PYRAMID", "0")
+    first = drv.datasource_brick(uri, coarse).copy()
+    assert not os.path.exists(pyr)
+    monkeypatch.delenv("LIVRE_HIP_PYRAMID")
+    assert (drv.datasource_brick(uri, coarse) == first).all()
+    assert os.path.exists(pyr) and open(pyr, "rb").read(8) == b"LVPYR001"
+    size = os.path.getsize(pyr)
+    # served from the file: poison the file's first level and see the poison come back
+    raw = bytearray(open(pyr, "rb").read())
+    import struct
+    levels = struct.unpack_from("<I", raw, 8 + 24 + 12 + 4)[0]
+    assert levels == vi.depth - 1
+    off = struct.unpack_from("<Q", raw, 56 + 24)[0]
+    d1 = [(v + 1) // 2 for v in (48, 32, 64)]
+    for i in range(d1[0] * d1[1] * d1[2] * 2):
+        raw[off + i] = 0xAB
+    mtime = os.stat(path).st_mtime_ns
+    open(pyr, "wb").write(raw)
+    poisoned = drv.datasource_brick(uri, coarse)
+    assert (poisoned == 0xAB).all()
+    # the volume changes (same size, new mtime): the pyramid file is stale, rebuilt and rewritten
+    vol2 = (vol + np.uint16(1))
+    vol2.tofile(path)
+    os.utime(path, ns=(mtime + 5_000_000_000, mtime + 5_000_000_000))
+    fresh = drv.datasource_brick(uri, coarse).view(np.uint16)
+    assert (fresh == first.view(np.uint16) + 1).all()
+    assert os.path.getsize(pyr) == size and open(pyr, "rb").read()[off:off + 2] != b"\xab\xab"
+    # a cache directory instead of the volume's own
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    monkeypatch.setenv("LIVRE_HIP_PYRAMID_DIR", str(cache))
+    assert (drv.datasource_brick(uri, coarse).view(np.uint16) == fresh).all()
+    assert os.path.exists(str(cache / "vol.raw.lvpyr"))
+
+
 def _uvf_python_decoder(path):
     """Independent reader of the fixture (numpy + zlib): LOD sizes, brick layouts, bricks."""
     import struct
@@ -315,6 +362,71 @@ def test_uvf_bricks_match_an_independent_decoder(drv):
     # neighbouring bricks agree on their shared overlap voxels: the payload layout is understood
     a, b = py["get"](0, 0, 0, 0), py["get"](0, 1, 0, 0)
     assert (a[:, :, 28:32] == b[:, :, 0:4]).all()
+
+
+def _two_time_step_uvf(tmp_path):
+    """The fixture with its TOC block appended once more at the end of the block chain (a second time step, as
+    Tuvok writes time series: one TOC block per step), and one brick of the FIRST step's payload damaged, so that
+    the two steps can be told apart."""
+    import struct
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mouse_reduced.uvf")
+    d = bytearray(open(src, "rb").read())
+    pos = 9 + 24 + struct.unpack_from("<Q", d, 25)[0] + 8
+    blocks = []
+    while True:
+        start = pos
+        n, = struct.unpack_from("<Q", d, pos)
+        sem, _, nxt = struct.unpack_from("<QQQ", d, pos + 8 + n)
+        blocks.append((start, n, sem, nxt))
+        if nxt == 0:
+            break
+        pos = start + nxt
+    toc_start, toc_n, sem, toc_len = blocks[0]
+    assert sem == 9
+    last_start, last_n, _, _ = blocks[-1]
+    copy = bytearray(d[toc_start:toc_start + toc_len])
+    struct.pack_into("<Q", copy, 8 + toc_n + 16, 0)                          # the copy ends the chain
+    struct.pack_into("<Q", d, last_start + 8 + last_n + 16, len(d) - last_start)  # the old last block points at it
+    out = d + copy
+    # damage the first brick of tree level 1 (LOD 0) in the FIRST step: its zlib stream no longer inflates
+    base = toc_start + 8 + toc_n + 24
+    off, ln, comp, _, _ = struct.unpack_from("<QQIQQ", out, base + 105)
+    assert comp == 1
+    for i in range(8, 40):
+        out[base + off + i] ^= 0xFF
+    path = str(tmp_path / "two_steps.uvf")
+    open(path, "wb").write(out)
+    return path
+
+
+def test_uvf_time_steps(drv, tmp_path):
+    # datasources/uvf/UVFDataSource.cpp:144: frameRange = (0, number of time steps); :258-267: the brick key carries
+    # the frame -- but the reference then looks the brick up in the FIRST table of contents (every frame shows step
+    # 0).  Here every TOC block of the file is a time step with its own table and payload.
+    one = "uvf://" + os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mouse_reduced.uvf")
+    assert drv.datasource_frame_range(one) == (0, 1)
+    assert drv.datasource_frame_range("mem://#64,64,64,16")[0] == 0
+    path = _two_time_step_uvf(tmp_path)
+    uri = "uvf://" + path
+    assert drv.datasource_frame_range(uri) == (0, 2)
+    assert drv.datasource_info(uri)["voxels"] == [75, 75, 138]
+    py = _uvf_python_decoder(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mouse_reduced.uvf"))
+    # step 1 is the intact copy: every brick of both levels decodes to the fixture's bricks
+    for level, lod in ((1, 0), (0, 1)):
+        lay = py["layouts"][lod]
+        for z in range(lay[2]):
+            for y in range(lay[1]):
+                for x in range(lay[0]):
+                    want = py["get"](lod, x, y, z)
+                    got = drv.datasource_brick(uri, orc.pack(level, x, y, z, 1))
+                    assert got.size == want.size and (got.reshape(want.shape) == want).all()
+    # step 0: the damaged brick is reported, its neighbour is fine -- the two steps have their own payloads
+    with pytest.raises(RuntimeError):
+        drv.datasource_brick(uri, orc.pack(1, 0, 0, 0, 0))
+    assert (drv.datasource_brick(uri, orc.pack(1, 1, 0, 0, 0)).reshape(py["get"](0, 1, 0, 0).shape) == py["get"](0, 1, 0, 0)).all()
+    # a frame outside the range is refused
+    with pytest.raises(RuntimeError):
+        drv.datasource_brick(uri, orc.pack(1, 0, 0, 0, 2))
 
 
 def test_host_library_under_sanitizers(tmp_path):
