@@ -60,11 +60,19 @@
  * third shape with 16 rows lost as many at the back of the volume.  The price of the run-time slice pitch is one
  * address addition per trilinear sample (the second tap plane). */
 #define VRC_LDS_PY 32u
+#ifndef VRC_LDS_ROWS
 #define VRC_LDS_ROWS 264u
+#endif
+#ifndef VRC_LDS_OCC
+#define VRC_LDS_OCC 4 /* workgroups per CU the launch bounds ask for */
+#endif
+#ifndef VRC_LDS_STAGE_N
+#define VRC_LDS_STAGE_N 11 /* slice loads in flight in one staging batch */
+#endif
 #define VRC_LDS_REGION ( VRC_LDS_PY * VRC_LDS_ROWS )
 #define VRC_LDS_MAX_DY 32u /* 16 row pairs: one per staging lane group */
 #ifndef VRC_LDS_MAX_DZ
-#define VRC_LDS_MAX_DZ 22u /* two staging halves of 11 slice loads in flight */
+#define VRC_LDS_MAX_DZ ( 2u * VRC_LDS_STAGE_N ) /* two staging halves */
 #endif
 #ifndef VRC_LDS_KMAX
 #define VRC_LDS_KMAX 8u /* steps of the lead a box is extended by at most (measured on C2, ms per frame: 4: 2.78, 6: 2.29,
@@ -262,7 +270,7 @@ __device__ __forceinline__ float lds_trilerp( const float v[8], uint32_t fx, uin
  * entries are (grey, alpha) pairs, bit-identical to the four-float form (vrc_core.h, VRC_MODE_GREY) */
 template < bool COUNT, bool LINEAR, bool GREY = false >
 /* four workgroups per CU: 4 x (4 regions of 8.25 KiB + the table) = 152 of the CU's 160 KiB */
-__global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
+__global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_raycast_lds(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ gridTable, const uint8_t* __restrict__ atlas,
     const vrc_f4* __restrict__ lutGlobal, const vrc_classifier cls,
@@ -785,14 +793,14 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, 4 ) void vrc_k_raycast_lds(
                 /* the lanes' step counts are worked out while the loads are on their way */
                 if( box.dz <= 8u )
                     lds_stage< 8 >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst, pz, countSteps );
-                else if( box.dz <= 11u )
-                    lds_stage< 11 >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst, pz, countSteps );
+                else if( box.dz <= (uint32_t)VRC_LDS_STAGE_N )
+                    lds_stage< VRC_LDS_STAGE_N >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst, pz, countSteps );
                 else
                 {
                     /* deeper boxes in two halves: at most 11 loads in flight */
                     const uint32_t h = ( box.dz + 1u ) / 2u;
-                    lds_stage< 11 >( slotPtr, partial, sliceStride, box.z0, h, on, dst, pz, countSteps );
-                    lds_stage< 11 >( slotPtr, partial, sliceStride, box.z0 + h, box.dz - h, on, dst + h * pz, pz, []() {} );
+                    lds_stage< VRC_LDS_STAGE_N >( slotPtr, partial, sliceStride, box.z0, h, on, dst, pz, countSteps );
+                    lds_stage< VRC_LDS_STAGE_N >( slotPtr, partial, sliceStride, box.z0 + h, box.dz - h, on, dst + h * pz, pz, []() {} );
                 }
             }
             VRC_LDS_STAT( 0, 1 )
