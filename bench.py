@@ -524,7 +524,7 @@ def main():
             torch.cuda.synchronize()
             st_ = app.stats()
             tri_ms = st_.kernel_ms_sum / max(1, st_.kernel_launches)
-            trilinear = {"kernel": "vrc_k_raycast_lds<false,true> (voxels staged through LDS per wave)",
+            trilinear = {"kernel": (vrc.load_library().vrc_last_kernel() or b"").decode() + " (voxels staged through LDS per wave)",
                          "kernel_ms_per_frame": tri_ms, "samples_per_frame": int(tri_samples),
                          "Msamples_per_s": tri_samples / tri_ms / 1e3,
                          "lds_request_rate_GBps": tri_samples * 8 / tri_ms / 1e6,
@@ -712,7 +712,7 @@ def main():
                 and tuple(a.spin) == (0.0, 0.0) and not ray_lod_on and os.path.exists(tpath)):
             tj = json.load(open(tpath))
             # the counters are only quoted for the kernel instance they were collected on
-            if launched_kernel and tj["kernel"].split(" ")[0] == launched_kernel:
+            if launched_kernel and tj["kernel"].startswith(launched_kernel + " "):
                 traffic = tj["traffic_bytes_per_launch"]
                 tnote = "FETCH_SIZE + WRITE_SIZE bytes per launch from profiles/r3_traffic_c2.json (same kernel instance)"
                 if "sq_insts_valu_per_launch" in tj:
@@ -727,7 +727,7 @@ def main():
                             "source": tj.get("valu_source")}
             else:
                 tnote = ("profiles/r3_traffic_c2.json is a profile of %s, this run launched %s: not quoted"
-                         % (tj["kernel"].split(" ")[0], launched_kernel or "?"))
+                         % (tj["kernel"].split(" (")[0], launched_kernel or "?"))
         n_nodes = (a.voxels // a.block) ** 3
         # interior voxels of marched bricks + one RGBA32F write + node table + TF, each input
         # voxel once per frame.  With N ranks a rank's row bands sweep rows/H of the volume (the bands are
@@ -794,8 +794,8 @@ def main():
                          "algorithmic_bytes_per_launch": per_rank_alg,
                          "algorithmic_bytes_per_frame_all_ranks": alg_bytes,
                          "launches_per_frame": 1,
-                         "note": "not HBM-bound: the kernel sits on a plateau of vector issue (16.3 instructions per "
-                                 "64-sample step = 61 % of the issue slots) and gather latency that five waves per "
+                         "note": "not HBM-bound: vector issue (valu.frac of the kernel time at the measured class costs; "
+                                 "the build without any gather runs in 0.265 ms) and gather latency that five waves per "
                                  "SIMD do not cover; L1 look-ups, loads in flight and occupancy were each changed by "
                                  "20-40 % without moving the time (DESIGN.md section 4)"},
         }
