@@ -103,6 +103,8 @@ private:
     vrc_ctx* _ctx;
     uint32_t _computedSamplesPerRay;
     bool _lastRayLod = false;
+    std::vector< Vector4f > _uploadedPlanes; /* what the device layer has (vrc_update): render() uploads a change */
+    void uploadSettings( const RenderInputs& renderInputs );
     /* render(): the sorted node list of the last call, kept while the bricks and the model-view matrix repeat */
     std::vector< const CacheObject* > _sortedFor;
     std::vector< Identifier > _sortedForIds;

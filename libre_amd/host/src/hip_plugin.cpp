@@ -394,10 +394,9 @@ vrc_view_data makeViewData( const RenderInputs& renderInputs ) /* CudaRaycastRen
 }
 }
 
-void HipRaycastRenderer::preRender( const RenderInputs& renderInputs, const ConstCacheObjects& renderData )
+/* update(): cuda/Renderer.cu:245-250 -- transfer function and clip planes to the device layer */
+void HipRaycastRenderer::uploadSettings( const RenderInputs& renderInputs )
 {
-    const StageClock clock( StageClock::PreRender );
-    /* update(): cuda/Renderer.cu:245-250 */
     const std::vector< Vector4f >& planes = renderInputs.renderSettings.getClipPlanes().getPlanes();
     if( planes.size() > 6 )
         throw std::runtime_error( "More than 6 clip planes" );
@@ -415,6 +414,13 @@ void HipRaycastRenderer::preRender( const RenderInputs& renderInputs, const Cons
     throwOnVrcError( vrc_update( _ctx, colors.data(), planes.empty() ? nullptr : flat,
                                  uint32_t( planes.size() ) ),
                      "vrc_update" );
+    _uploadedPlanes = planes;
+}
+
+void HipRaycastRenderer::preRender( const RenderInputs& renderInputs, const ConstCacheObjects& renderData )
+{
+    const StageClock clock( StageClock::PreRender );
+    uploadSettings( renderInputs );
 
     const VolumeInformation& volInfo = renderInputs.dataSource.getVolumeInfo();
     if( renderInputs.vrParameters.getSamplesPerRay() == 0 ) /* CudaRaycastRenderer.cpp:113-129 */
@@ -446,6 +452,9 @@ void HipRaycastRenderer::render( const RenderInputs& renderInputs, const ConstCa
     _lastRayLod = false;
     if( renderData.empty() ) /* CudaRaycastRenderer.cpp:157-158 */
         return;
+    /* the passes of one frame may carry different clip planes (per-ray LOD in slabs, HipRaycastPipeline) */
+    if( renderInputs.renderSettings.getClipPlanes().getPlanes() != _uploadedPlanes )
+        uploadSettings( renderInputs );
     std::unique_ptr< StageClock > clock( new StageClock( StageClock::SortAndFill ) );
     /* CudaRaycastRenderer.cpp:160-163: sort front to back by distance of the box centre.
      * (keys are precomputed; the reference recomputes them inside the comparator) */
@@ -950,11 +959,19 @@ struct HipRaycastPipeline::Impl
         if( rayLod )
         {
             NodeIds hierarchy = nodeIds;
-            rayLod = withAncestors( in, hierarchy ) && hierarchy.size() <= maxNodesPerPass;
+            rayLod = withAncestors( in, hierarchy );
+            if( rayLod && hierarchy.size() > maxNodesPerPass )
+            {
+                /* the hierarchy does not fit the atlas: the reference's answer to "does not fit" is passes
+                 * (CudaRaycastPipeline.cpp:149-185); for per-ray LOD a pass is a SLAB of space (below) */
+                if( renderRayLodInSlabs( statistics, renderer, in, hierarchy, maxNodesPerPass ) )
+                    return;
+                rayLod = false;
+            }
             if( rayLod )
                 nodeIds.swap( hierarchy );
             else if( std::getenv( "LIVRE_HIP_TRACE" ) )
-                std::fprintf( stderr, "[livre_hip] per-ray LOD not possible for this frame (ragged tree or atlas too small): per-brick cut\n" );
+                std::fprintf( stderr, "[livre_hip] per-ray LOD not possible for this frame (ragged tree, or no slab of the atlas's size): per-brick cut\n" );
         }
         RenderInputs plain( in );
         plain.vrParameters.rayLOD = false;
@@ -1024,6 +1041,135 @@ struct HipRaycastPipeline::Impl
         statistics.nAvailable = nodeIds.size();
         statistics.nNotAvailable = 0;
         statistics.nRenderAvailable = statistics.nAvailable;
+    }
+
+    /* Per-ray LOD over a hierarchy larger than the atlas (round 3).  Per-ray LOD picks, at every point of a ray,
+     * the level the screen-space-error rule asks for there and falls back to the next resident one -- so a pass that
+     * holds only SOME bricks would make rays fall back where the single pass would not.  A pass is therefore a slab
+     * of space across the view's main axis, bounded by faces of the finest bricks, with every brick of every level
+     * that reaches into the slab resident, and the rays confined to it by two clip planes (the kernel's own
+     * tNearGlobal / tFarGlobal, cuda/Renderer.cu:132-149): inside a slab every ray sees exactly the bricks it would
+     * see in the whole hierarchy.  Slabs are rendered front to back into the accumulating pixel buffer
+     * (Renderer.cu:151-157), as the reference's passes are.  A run that crosses a slab face is cut there (sampling
+     * restarts at the face, as it does at every brick face): the frame is the per-ray LOD frame with those extra
+     * restarts, and it is what the oracle renders from the same slabs (tests/test_gpu_parity.py).
+     * Returns false (nothing rendered) if even the thinnest slab does not fit or there is no room for two planes. */
+    bool renderRayLodInSlabs( RenderStatistics& statistics, Renderer& renderer, const RenderInputs& in,
+                              const NodeIds& hierarchy, uint32_t maxNodesPerPass )
+    {
+        const std::vector< Vector4f >& userPlanes = in.renderSettings.getClipPlanes().getPlanes();
+        if( userPlanes.size() + 2u > 6u || hierarchy.empty() )
+            return false;
+        const Frustum& frustum = in.frameInfo.frustum;
+        /* main axis of the view, and which way the rays run along it */
+        std::vector< Boxf > boxes;
+        boxes.reserve( hierarchy.size() );
+        uint32_t finest = 0;
+        Vector3f lo( 1e30f ), hi( -1e30f );
+        for( const NodeId& id : hierarchy )
+        {
+            boxes.push_back( in.dataSource.getNode( id ).getWorldBox() );
+            finest = std::max( finest, id.getLevel() );
+            for( int a = 0; a < 3; ++a )
+            {
+                lo[a] = std::min( lo[a], boxes.back().getMin()[a] );
+                hi[a] = std::max( hi[a], boxes.back().getMax()[a] );
+            }
+        }
+        const Vector3f dir = ( lo + hi ) * 0.5f - frustum.getEyePos();
+        int axis = 0;
+        for( int a = 1; a < 3; ++a )
+            if( std::fabs( dir[a] ) > std::fabs( dir[axis] ) )
+                axis = a;
+        const bool forward = dir[axis] > 0.0f;
+        /* candidate faces: those of the finest bricks present (coarser faces are among them up to rounding) */
+        std::vector< float > faces;
+        for( size_t i = 0; i < hierarchy.size(); ++i )
+            if( hierarchy[i].getLevel() == finest )
+            {
+                faces.push_back( boxes[i].getMin()[axis] );
+                faces.push_back( boxes[i].getMax()[axis] );
+            }
+        faces.push_back( lo[axis] );
+        faces.push_back( hi[axis] );
+        std::sort( faces.begin(), faces.end() );
+        const float eps = 1e-5f * std::max( hi[axis] - lo[axis], 1e-6f );
+        faces.erase( std::unique( faces.begin(), faces.end(), [eps]( float a, float b ) { return b - a <= eps; } ), faces.end() );
+        if( !forward )
+            std::reverse( faces.begin(), faces.end() );
+        auto inSlab = [&]( size_t i, float a, float b ) { /* the brick reaches into the open slab (a, b), a < b */
+            return boxes[i].getMax()[axis] > a + eps && boxes[i].getMin()[axis] < b - eps;
+        };
+        struct Slab
+        {
+            float a, b; /* a < b whatever the direction */
+            NodeIds ids;
+        };
+        std::vector< Slab > slabs;
+        for( size_t f0 = 0; f0 + 1 < faces.size(); )
+        {
+            size_t f1 = f0 + 1, best = 0;
+            NodeIds bestIds;
+            for( ; f1 < faces.size(); ++f1 )
+            {
+                const float a = std::min( faces[f0], faces[f1] ), b = std::max( faces[f0], faces[f1] );
+                NodeIds ids;
+                for( size_t i = 0; i < hierarchy.size(); ++i )
+                    if( inSlab( i, a, b ) )
+                        ids.push_back( hierarchy[i] );
+                if( ids.size() > maxNodesPerPass )
+                    break;
+                best = f1;
+                bestIds.swap( ids );
+            }
+            if( best == 0 )
+                return false; /* one layer of the finest bricks with their ancestors is more than the atlas holds */
+            if( !bestIds.empty() )
+                slabs.push_back( { std::min( faces[f0], faces[best] ), std::max( faces[f0], faces[best] ), bestIds } );
+            f0 = best;
+        }
+        _keptValid = false;
+        _keptObjects.clear();
+        _lastPasses = uint32_t( slabs.size() );
+        _lastRayLod = true;
+        size_t bricks = 0;
+        for( size_t i = 0; i < slabs.size(); ++i )
+        {
+            uint32_t renderStages = RENDER_FRAME;
+            if( i == 0 )
+                renderStages |= RENDER_BEGIN;
+            if( i + 1 == slabs.size() )
+                renderStages |= RENDER_END;
+            RenderInputs slabIn( in );
+            Vector4f pa( 0.0f ), pb( 0.0f ); /* kept: n.x + d >= 0 (Renderer.cu:132-146) */
+            pa[axis] = 1.0f;
+            pa[3] = -slabs[i].a;
+            pb[axis] = -1.0f;
+            pb[3] = slabs[i].b;
+            slabIn.renderSettings.getClipPlanes().addPlane( pa );
+            slabIn.renderSettings.getClipPlanes().addPlane( pb );
+            ConstCacheObjects objects;
+            {
+                const StageClock clock( StageClock::Upload );
+                objects = upload( slabs[i].ids, in );
+            }
+            if( objects.size() != slabs[i].ids.size() )
+                throw std::runtime_error( "per-ray LOD in slabs: a slab's bricks could not be made resident" );
+            renderer.render( slabIn, objects, renderStages );
+            _lastRayLod = _lastRayLod && static_cast< HipRaycastRenderer& >( renderer.getPlugin() ).lastRenderUsedRayLOD();
+            bricks += objects.size();
+            if( std::getenv( "LIVRE_HIP_TRACE" ) )
+                std::fprintf( stderr, "[livre_hip] per-ray LOD slab %zu of %zu: axis %d [%g, %g], %zu bricks\n", i + 1,
+                              slabs.size(), axis, slabs[i].a, slabs[i].b, objects.size() );
+            /* the next slab re-uses slots: this one's bricks must be evictable before it uploads */
+            static_cast< HipRaycastRenderer& >( renderer.getPlugin() ).synchronize();
+        }
+        if( slabs.empty() )
+            renderer.render( in, ConstCacheObjects(), RENDER_BEGIN | RENDER_END );
+        statistics.nAvailable = hierarchy.size();
+        statistics.nNotAvailable = 0;
+        statistics.nRenderAvailable = bricks;
+        return true;
     }
 
     /* CudaRaycastPipeline.cpp:236-301: render what is resident (or a cached ancestor), upload

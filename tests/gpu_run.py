@@ -36,7 +36,7 @@ class GpuScene:
                     slots=list(sl), free=fs.value)
 
     def render(self, kernel=vrc.KERNEL_AUTO, frac_bits=8, count=True, passes=None, stepping=1,
-               filter_mode=0, variant=0, ray_lod=None):
+               filter_mode=0, variant=0, ray_lod=None, slabs=None):
         L, s = self.L, self.s
         # ray_lod = (screenSpaceError, worldSpacePerPixel): per-ray adaptive LOD over the hierarchy s.nodes
         vrc.check(L, L.vrc_set_ray_lod(self.ctx, 1 if ray_lod else 0, ray_lod[0] if ray_lod else 0.0,
@@ -56,8 +56,20 @@ class GpuScene:
         vrc.check(L, L.vrc_pre_render(self.ctx, view))
         samples = 0
         stats = vrc.Stats()
+        for planes_i, idx in (slabs or []):
+            # one pass per slab of space: its own clip planes and the bricks that reach into it (what
+            # HipRaycastPipeline does for a per-ray LOD hierarchy larger than the atlas), accumulating
+            pl = np.ascontiguousarray(planes_i, dtype=np.float32).reshape(-1, 4)
+            vrc.check(L, L.vrc_update(self.ctx, s.tf.ctypes.data, pl.ctypes.data if len(pl) else None, len(pl)))
+            sub_nodes = (vrc.NodeData * max(1, len(idx)))()
+            for k, i in enumerate(idx):
+                C.memmove(C.byref(sub_nodes, k * C.sizeof(vrc.NodeData)), C.byref(s.nodes, i * C.sizeof(vrc.NodeData)),
+                          C.sizeof(vrc.NodeData))
+            vrc.check(L, L.vrc_render(self.ctx, view, C.cast(sub_nodes, C.POINTER(vrc.NodeData)), len(idx), render, self.pool))
+            vrc.check(L, L.vrc_get_stats(self.ctx, C.byref(stats)))
+            samples += stats.samples
         if passes is None:
-            passes = [(0, s.n_nodes)]
+            passes = [(0, s.n_nodes)] if not slabs else []
         for (a, b) in passes:  # multipass: CudaRaycastPipeline.cpp:149-185
             sub = C.cast(C.byref(s.nodes, a * C.sizeof(vrc.NodeData)), C.POINTER(vrc.NodeData)) if a else nodes
             vrc.check(L, L.vrc_render(self.ctx, view, sub, b - a, render, self.pool))

@@ -712,6 +712,58 @@ def test_ray_lod_matches_oracle(vrc, sse):
             g.render(kernel=vrc.KERNEL_GRID_DDA)  # nested boxes are no partition
 
 
+def _slabs_of(s, axis, cuts, descending):
+    """[(planes, node indices)] front to back: the slabs of space between consecutive `cuts` across `axis`, each with
+    the scene's own planes + its two, and the bricks of s.nodes that reach into it."""
+    out = []
+    pairs = list(zip(cuts[:-1], cuts[1:]))
+    if descending:
+        pairs.reverse()
+    for a, b in pairs:
+        pa, pb = [0.0] * 4, [0.0] * 4
+        pa[axis], pa[3] = 1.0, -a   # kept: n.x + d >= 0 (cuda/Renderer.cu:132-146)
+        pb[axis], pb[3] = -1.0, b
+        planes = [list(p) for p in s.planes] + [pa, pb]
+        idx = [i for i in range(s.n_nodes)
+               if s.nodes[i].aabbMin[axis] + s.nodes[i].aabbSize[axis] > a + 1e-6 and s.nodes[i].aabbMin[axis] < b - 1e-6]
+        out.append((np.asarray(planes, dtype=np.float32), idx))
+    return out
+
+
+@pytest.mark.parametrize("spin,axis,descending", [((0.0, 0.0), 2, True), ((0.4, 0.3), 2, True), ((1.45, 0.1), 0, False)])
+def test_ray_lod_in_slabs_matches_the_oracle(vrc, spin, axis, descending):
+    # per-ray LOD over a hierarchy that does not fit the atlas is rendered in SLABS of space across the view's main axis
+    # (libre_amd/host: HipRaycastPipeline::renderRayLodInSlabs): per slab the bricks of every level that reach into it,
+    # the rays confined to it by two clip planes, front to back into the accumulating pixel buffer.  Kernel against
+    # oracle through the C ABI on the same slabs; and against the single pass, which it equals up to the sampling
+    # restarts at the slab faces.
+    import copy
+    s = _hierarchy(viewport=(120, 96), volume="hash", spin=spin)
+    lod = (1.7, orc.world_space_per_pixel(s))
+    slabs = _slabs_of(s, axis, [-0.5, -0.25, 0.0, 0.25, 0.5], descending)
+    assert all(0 < len(idx) < s.n_nodes for _, idx in slabs)
+    want = np.zeros((s.H, s.W, 4), dtype=np.float32)
+    n_want = 0
+    for planes, idx in slabs:
+        part = copy.copy(s)
+        part.planes = planes
+        part.nodes = (orc.NodeData * len(idx))(*[s.nodes[i] for i in idx])
+        part.n_nodes = len(idx)
+        want, n = orc.oracle_render(part, ray_lod=lod, fb=want)
+        n_want += n
+    whole, n_whole = orc.oracle_render(s, ray_lod=lod)
+    with _gpu(s) as g:
+        got, n_got, st = g.render(ray_lod=lod, slabs=slabs)
+        assert st.kernel_variant == vrc.KERNEL_RAY_LOD
+        _lod_parity(got, want, "slabs across axis %d" % axis)
+        assert abs(n_got - n_want) <= 3e-4 * n_want + 16
+        single, n_single, _ = g.render(ray_lod=lod)
+    # the slab frame is the per-ray LOD frame with extra sampling restarts at three faces
+    scenes.assert_close_frames(got, single, "slabs against the single pass", max_abs=2e-2, mean_abs=1e-3)
+    assert abs(n_got - n_single) <= 0.02 * n_single
+    assert np.abs(want - whole).max() < 2e-2
+
+
 @pytest.mark.parametrize("filter_mode,dtype", [(1, "u8"), (1, "u16"), (0, "u16")])
 def test_ray_lod_per_sample_classification_modes(vrc, filter_mode, dtype):
     s = _hierarchy(viewport=(96, 80), volume="hash", spin=(-0.7, 0.2), dtype=dtype, alpha=0.3)
