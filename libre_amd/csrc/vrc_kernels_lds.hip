@@ -452,6 +452,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
      * brick, so 64 lanes x (steps of the longest ray + cells it can cross) rounds are never reached */
     uint32_t roundBudget = 64u * ( (uint32_t)( 3.5f / stepSize ) + 8u * (uint32_t)( f.gridDim[0] + f.gridDim[1] + f.gridDim[2] ) + 64u );
     bool events = true, anyLack = true; /* wave-uniform: see the head of the loop */
+    uint64_t segMask = 0ull;            /* wave-uniform: the lanes that have a segment (kept as a scalar: in a round
+                                         * without events no ballot is spent on it) */
     for( ;; )
     {
         if( roundBudget-- == 0u )
@@ -490,6 +492,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
                 lack && hasSeg && !( travel > stepSize * (float)( 2 * VRC_LDS_G ) ) );
             refill = idleMask != 0ull || soonMask != 0ull || __builtin_popcountll( lackMask ) >= VRC_LDS_REFILL;
             anyLack = lackMask != 0ull;
+            if( !refill )
+                segMask = __builtin_amdgcn_ballot_w64( hasSeg );
         }
         while( refill )
         {
@@ -621,17 +625,19 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
             promote();
             refill = __builtin_amdgcn_ballot_w64( !done && !walkDone && !hasPend && !hasSeg ) != 0ull;
             anyLack = __builtin_amdgcn_ballot_w64( !done && !walkDone && !hasPend ) != 0ull;
+            segMask = __builtin_amdgcn_ballot_w64( hasSeg );
         }
 
         VRC_LDS_PHASE( 6 )
         /* B: one round: every lane that has a segment takes steps through an LDS box (up to VRC_LDS_PASSES boxes);
          * what no box served takes VRC_LDS_G steps by gathers */
-        if( __builtin_amdgcn_ballot_w64( hasSeg ) == 0ull )
+        if( segMask == 0ull )
             break;
         bool inTodo = hasSeg;
+        bool passEvents = false; /* wave-uniform: a lane crossed the early-exit threshold or ran out of steps in a pass */
         for( int pass = 0; pass < VRC_LDS_PASSES; ++pass )
         {
-            const uint64_t todoMask = __builtin_amdgcn_ballot_w64( inTodo );
+            const uint64_t todoMask = pass == 0 ? segMask : __builtin_amdgcn_ballot_w64( inTodo );
             if( todoMask == 0ull )
                 break;
             /* the lead: the tile centre if it still has steps to take in this round */
@@ -921,7 +927,11 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
              * crosses -- the reference's exit */
             VRC_LDS_PHASE( 4 )
             const bool crossed = part && color.w > VRC_EARLY_EXIT;
-            if( __builtin_amdgcn_ballot_w64( crossed ) != 0ull )
+            /* one ballot for "anything happened to a lane in this pass": in most passes nothing did, and neither the
+             * replay below nor the end-of-round bookkeeping has to look */
+            const bool passEvent = __builtin_amdgcn_ballot_w64( crossed || ( part && !( travel > 0.0f ) ) ) != 0ull;
+            passEvents = passEvents || passEvent;
+            if( passEvent && __builtin_amdgcn_ballot_w64( crossed ) != 0ull )
             {
                 if( crossed )
                 {
@@ -962,7 +972,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
             inTodo = false;
         }
 #endif
-        if( __builtin_amdgcn_ballot_w64( inTodo ) != 0ull )
+        const bool gathers = __builtin_amdgcn_ballot_w64( inTodo ) != 0ull;
+        if( gathers )
         {
             VRC_LDS_STAT( 2, 1 )
             if( inTodo )
@@ -1048,9 +1059,13 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
                 }
             }
         }
+        events = false;
+        if( passEvents || gathers )
         {
             const bool ended = hasSeg && ( done || !( travel > 0.0f ) );
-            events = __builtin_amdgcn_ballot_w64( ended ) != 0ull;
+            const uint64_t endedMask = __builtin_amdgcn_ballot_w64( ended );
+            events = endedMask != 0ull;
+            segMask &= ~endedMask;
             if( ended )
                 hasSeg = false;
         }
