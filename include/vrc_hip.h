@@ -153,7 +153,11 @@ typedef struct
 #define VRC_KERNEL_GRID_DDA 2        /* 3-D DDA over the brick grid; needs a grid-aligned node set */
 #define VRC_KERNEL_LDS 3             /* grid DDA + voxels staged through LDS per wave and round (needs
                                       * overlap >= 1); what AUTO picks for the trilinear filter */
-#define VRC_KERNEL_RAY_LOD 4         /* reported by vrc_get_stats when vrc_set_ray_lod is on; not selectable */
+#define VRC_KERNEL_RAY_LOD 4         /* reported by vrc_get_stats when vrc_set_ray_lod is on; not selectable.  Under
+                                      * per-ray LOD VRC_OPT_KERNEL chooses how the hierarchy walk takes its samples:
+                                      * AUTO = staged through LDS for the trilinear filter on 8-bit bricks (overlap >= 1,
+                                      * VRC_OPT_TF_FRAC_BITS 8), by gathers otherwise; GRID_DDA = gathers; LDS = staged or
+                                      * VRC_EINVAL; vrc_last_kernel names the instance that ran */
 
 /* ---- context ---------------------------------------------------------------------------- */
 /* cuda::Renderer::Renderer() (cuda/Renderer.cu:234-238); device is explicit (fixes Q11) */

@@ -1079,8 +1079,10 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
             return fail( VRC_EHIERARCHY, "vrc_render: per-ray LOD needs a brick hierarchy (every level a regular grid of bricks, one brick per cell)" );
         if( c->optVariant != VRC_VARIANT_CUDARAYCASTER )
             return fail( VRC_EINVAL, "vrc_render: per-ray LOD is defined for the cudaRaycaster variant only" );
-        if( c->optKernel != VRC_KERNEL_AUTO )
-            return fail( VRC_EINVAL, "vrc_render: per-ray LOD has its own kernel; leave VRC_OPT_KERNEL at AUTO" );
+        /* AUTO: the LDS-staged form for the trilinear filter where it applies, else the gather form; GRID_DDA asks for
+         * the gather form, LDS for the staged one */
+        if( c->optKernel == VRC_KERNEL_REFERENCE_ORDER )
+            return fail( VRC_EINVAL, "vrc_render: per-ray LOD walks the hierarchy; VRC_OPT_KERNEL = AUTO, GRID_DDA (gathers) or LDS" );
         if( pool->bigAtlas )
             return fail( VRC_EHIERARCHY, "vrc_render: per-ray LOD is not available in atlases of more than 2^32 voxels" );
     }
@@ -1105,7 +1107,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     }
     if( c->optKernel == VRC_KERNEL_REFERENCE_ORDER )
         useDda = false;
-    else if( c->optKernel == VRC_KERNEL_GRID_DDA && !c->cachedGridOk )
+    else if( c->optKernel == VRC_KERNEL_GRID_DDA && !c->cachedGridOk && !c->rayLod )
         return fail( VRC_EINVAL, "vrc_render: node set is not grid-aligned; GRID_DDA unavailable" );
     /* LDS-staged kernel: brick-grid DDA + unclamped sampler (overlap >= 1).  AUTO takes it for
      * the trilinear filter (eight taps per sample), the gather kernel for point sampling. */
@@ -1113,10 +1115,16 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
      * float -> integer conversion (vrc_kernels_lds.hip: lds_classify): other weight widths use the gather form */
     const bool ldsEligible = c->cachedGridOk && !c->cachedClamp && pool->elemBytes == 1 && !pool->bigAtlas &&
                              ( !linear || c->optTfFracBits == 8 );
-    if( c->optKernel == VRC_KERNEL_LDS && !ldsEligible )
+    if( !c->rayLod && c->optKernel == VRC_KERNEL_LDS && !ldsEligible )
         return fail( VRC_EINVAL, "vrc_render: the LDS kernel needs a grid-aligned node set of 8-bit bricks with overlap >= 1 (trilinear: VRC_OPT_TF_FRAC_BITS = 8)" );
-    const bool useLds = !c->rayLod && !glSuper && ( c->optKernel == VRC_KERNEL_LDS ||
-                                                    ( c->optKernel == VRC_KERNEL_AUTO && linear && ldsEligible ) );
+    /* per-ray LOD: the staged kernel's trilinear form only (samples classified one by one: no table per level) */
+    const bool ldsLodEligible = c->rayLod && linear && !c->cachedClamp && pool->elemBytes == 1 && !pool->bigAtlas &&
+                                c->optTfFracBits == 8;
+    if( c->rayLod && c->optKernel == VRC_KERNEL_LDS && !ldsLodEligible )
+        return fail( VRC_EINVAL, "vrc_render: under per-ray LOD the LDS kernel needs the trilinear filter, 8-bit bricks with overlap >= 1 and VRC_OPT_TF_FRAC_BITS = 8" );
+    const bool useLds = c->rayLod ? ( ldsLodEligible && c->optKernel != VRC_KERNEL_GRID_DDA )
+                                  : !glSuper && ( c->optKernel == VRC_KERNEL_LDS ||
+                                                  ( c->optKernel == VRC_KERNEL_AUTO && linear && ldsEligible ) );
 
     vrc_raycast_args a;
     std::memset( &a, 0, sizeof( a ) );
@@ -1294,9 +1302,9 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         c->optTiming ? c->evPairs[c->evUsed++] : std::pair< hipEvent_t, hipEvent_t >( nullptr, nullptr );
     if( c->optTiming )
         VRC_HIP_CHECK( hipEventRecord( evp.first, c->stream ) );
-    VRC_HIP_CHECK( c->rayLod ? vrc_launch_raycast_raylod( a, c->stream )
-                   : useLds  ? vrc_launch_raycast_lds( a, c->stream )
-                             : vrc_launch_raycast( a, c->stream ) );
+    VRC_HIP_CHECK( useLds      ? vrc_launch_raycast_lds( a, c->stream ) /* (also its per-ray LOD form) */
+                   : c->rayLod ? vrc_launch_raycast_raylod( a, c->stream )
+                               : vrc_launch_raycast( a, c->stream ) );
     if( c->optTiming )
         VRC_HIP_CHECK( hipEventRecord( evp.second, c->stream ) );
     {

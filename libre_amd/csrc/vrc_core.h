@@ -1876,6 +1876,103 @@ VRC_HD vrc_segment vrc_run_segment( const vrc_ray& r, float tA, float tB, float 
     return s;
 }
 
+/* T_0 of the ray: level j is fine enough from T_0 * 2^j on */
+VRC_HD float vrc_ray_lod_base( const vrc_frame& f, const vrc_ray& r )
+{
+    VRC_STRICT_FP
+    return r.tNearPlane * f.lodBase;
+}
+
+/* One hop of the per-ray LOD walk at ray parameter te: the brick the ray is in at te + eps (its index in
+ * `nodes`, copied to n; -1: no level has a brick there), the parameter tp of the run's first sample and tB
+ * where the ray leaves the brick's box (no brick: the finest level's grid cell).  Shared by
+ * vrc_pixel_ray_lod and the LDS-staged kernel (vrc_kernels_lds.hip): same bits in both. */
+VRC_HD int32_t vrc_ray_lod_hop( const vrc_frame& f, const vrc_ray& r, const vrc_dev_node* __restrict__ nodes,
+                                const int32_t* __restrict__ gridTable, float tBase, float te, float t1,
+                                vrc_dev_node& n, float& tp, float& tB )
+{
+    const int K = (int)f.lodLevels;
+    const float o[3] = { r.origin.x, r.origin.y, r.origin.z };
+    const float d[3] = { r.dir.x, r.dir.y, r.dir.z };
+    const float id[3] = { r.invDir.x, r.invDir.y, r.invDir.z };
+    int k = 0;
+    float T = tBase;
+    for( int j = 1; j < K; ++j )
+    {
+        T = T + T; /* T_j, exact */
+        k += T <= te ? 1 : 0;
+    }
+    float p[3];
+    {
+        VRC_STRICT_FP
+        tp = te + f.lodEps;
+        p[0] = o[0] + d[0] * tp;
+        p[1] = o[1] + d[1] * tp;
+        p[2] = o[2] + d[2] * tp;
+    }
+    int32_t node = -1;
+    for( int s = 0; s < K && node < 0; ++s )
+    {
+        const int lv = s < K - k ? k + s : K - 1 - s; /* k..K-1, then k-1..0 */
+        int c[3];
+#pragma unroll
+        for( int a = 0; a < 3; ++a )
+        {
+            VRC_STRICT_FP
+            c[a] = (int)floorf( ( p[a] - f.gridMin[a] ) * f.lodInvCell[lv][a] );
+            c[a] = c[a] < 0 ? 0 : ( c[a] > f.lodDim[lv][a] - 1 ? f.lodDim[lv][a] - 1 : c[a] );
+        }
+        node = gridTable[f.lodTable[lv] + ( c[2] * f.lodDim[lv][1] + c[1] ) * f.lodDim[lv][0] + c[0]];
+    }
+    /* where the ray leaves the brick (no brick here: the finest level's grid cell) */
+    float bmin[3], bmax[3];
+    if( node >= 0 )
+    {
+        n = nodes[node];
+#pragma unroll
+        for( int a = 0; a < 3; ++a )
+        {
+            bmin[a] = n.aabbMin[a];
+            bmax[a] = n.aabbMin[a] + n.aabbSize[a];
+        }
+    }
+    else
+    {
+#pragma unroll
+        for( int a = 0; a < 3; ++a )
+        {
+            VRC_STRICT_FP
+            int c = (int)floorf( ( p[a] - f.gridMin[a] ) * f.invCellSize[a] );
+            c = c < 0 ? 0 : ( c > f.gridDim[a] - 1 ? f.gridDim[a] - 1 : c );
+            bmin[a] = f.gridMin[a] + f.cellSize[a] * (float)c;
+            bmax[a] = f.gridMin[a] + f.cellSize[a] * (float)( c + 1 );
+        }
+    }
+    {
+        VRC_STRICT_FP
+        float tX = ( ( d[0] > 0.0f ? bmax[0] : bmin[0] ) - o[0] ) * id[0];
+        tX = fminf( tX, ( ( d[1] > 0.0f ? bmax[1] : bmin[1] ) - o[1] ) * id[1] );
+        tX = fminf( tX, ( ( d[2] > 0.0f ? bmax[2] : bmin[2] ) - o[2] ) * id[2] );
+        tB = fminf( fmaxf( tX, tp ), t1 ); /* always forward */
+    }
+    return node;
+}
+
+/* the interval of the hierarchy's box a ray crosses (false: none) */
+VRC_HD bool vrc_ray_lod_interval( const vrc_frame& f, const vrc_ray& r, float& t0, float& t1 )
+{
+    const vrc_f3 gmin = { f.gridMin[0], f.gridMin[1], f.gridMin[2] };
+    const vrc_f3 gmax = { f.lodMax[0], f.lodMax[1], f.lodMax[2] };
+    const bool any = vrc_intersect_box( r.origin, r.invDir, gmin, gmax, &t0, &t1 );
+    t0 = fmaxf( fmaxf( t0, r.tNearGlobal ), fmaxf( r.tNearPlane, 0.0f ) );
+    t1 = fminf( t1, r.tFarGlobal );
+    return any && t0 < t1;
+}
+VRC_HD int vrc_ray_lod_max_hops( const vrc_frame& f )
+{
+    return 3 * ( f.gridDim[0] + f.gridDim[1] + f.gridDim[2] ) + 16;
+}
+
 template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP, bool BIG = false >
 VRC_HD void vrc_pixel_ray_lod( const vrc_frame& f, const vrc_dev_node* __restrict__ nodes,
                                const int32_t* __restrict__ gridTable,
@@ -1897,89 +1994,17 @@ VRC_HD void vrc_pixel_ray_lod( const vrc_frame& f, const vrc_dev_node* __restric
     if( color.w > VRC_EARLY_EXIT )
         return;
 
-    const vrc_f3 gmin = { f.gridMin[0], f.gridMin[1], f.gridMin[2] };
-    const vrc_f3 gmax = { f.lodMax[0], f.lodMax[1], f.lodMax[2] };
     float t0, t1;
-    const bool any = vrc_intersect_box( r.origin, r.invDir, gmin, gmax, &t0, &t1 );
-    t0 = fmaxf( fmaxf( t0, r.tNearGlobal ), fmaxf( r.tNearPlane, 0.0f ) );
-    t1 = fminf( t1, r.tFarGlobal );
-    if( any && t0 < t1 )
+    if( vrc_ray_lod_interval( f, r, t0, t1 ) )
     {
-        const int K = (int)f.lodLevels;
-        float tBase;
-        {
-            VRC_STRICT_FP
-            tBase = r.tNearPlane * f.lodBase;
-        }
-        const float o[3] = { r.origin.x, r.origin.y, r.origin.z };
-        const float d[3] = { r.dir.x, r.dir.y, r.dir.z };
-        const float id[3] = { r.invDir.x, r.invDir.y, r.invDir.z };
-        const int maxHops = 3 * ( f.gridDim[0] + f.gridDim[1] + f.gridDim[2] ) + 16;
+        const float tBase = vrc_ray_lod_base( f, r );
+        const int maxHops = vrc_ray_lod_max_hops( f );
         float te = t0;
         for( int hop = 0; hop < maxHops && te < t1; ++hop )
         {
-            int k = 0;
-            float T = tBase;
-            for( int j = 1; j < K; ++j )
-            {
-                T = T + T; /* T_j, exact */
-                k += T <= te ? 1 : 0;
-            }
-            float tp, p[3];
-            {
-                VRC_STRICT_FP
-                tp = te + f.lodEps;
-                p[0] = o[0] + d[0] * tp;
-                p[1] = o[1] + d[1] * tp;
-                p[2] = o[2] + d[2] * tp;
-            }
-            int32_t node = -1;
-            for( int s = 0; s < K && node < 0; ++s )
-            {
-                const int lv = s < K - k ? k + s : K - 1 - s; /* k..K-1, then k-1..0 */
-                int c[3];
-#pragma unroll
-                for( int a = 0; a < 3; ++a )
-                {
-                    VRC_STRICT_FP
-                    c[a] = (int)floorf( ( p[a] - f.gridMin[a] ) * f.lodInvCell[lv][a] );
-                    c[a] = c[a] < 0 ? 0 : ( c[a] > f.lodDim[lv][a] - 1 ? f.lodDim[lv][a] - 1 : c[a] );
-                }
-                node = gridTable[f.lodTable[lv] + ( c[2] * f.lodDim[lv][1] + c[1] ) * f.lodDim[lv][0] + c[0]];
-            }
-            /* where the ray leaves the brick (no brick here: the finest level's grid cell) */
             vrc_dev_node n;
-            float bmin[3], bmax[3];
-            if( node >= 0 )
-            {
-                n = nodes[node];
-#pragma unroll
-                for( int a = 0; a < 3; ++a )
-                {
-                    bmin[a] = n.aabbMin[a];
-                    bmax[a] = n.aabbMin[a] + n.aabbSize[a];
-                }
-            }
-            else
-            {
-#pragma unroll
-                for( int a = 0; a < 3; ++a )
-                {
-                    VRC_STRICT_FP
-                    int c = (int)floorf( ( p[a] - f.gridMin[a] ) * f.invCellSize[a] );
-                    c = c < 0 ? 0 : ( c > f.gridDim[a] - 1 ? f.gridDim[a] - 1 : c );
-                    bmin[a] = f.gridMin[a] + f.cellSize[a] * (float)c;
-                    bmax[a] = f.gridMin[a] + f.cellSize[a] * (float)( c + 1 );
-                }
-            }
-            float tB;
-            {
-                VRC_STRICT_FP
-                float tX = ( ( d[0] > 0.0f ? bmax[0] : bmin[0] ) - o[0] ) * id[0];
-                tX = fminf( tX, ( ( d[1] > 0.0f ? bmax[1] : bmin[1] ) - o[1] ) * id[1] );
-                tX = fminf( tX, ( ( d[2] > 0.0f ? bmax[2] : bmin[2] ) - o[2] ) * id[2] );
-                tB = fminf( fmaxf( tX, tp ), t1 ); /* always forward */
-            }
+            float tp, tB;
+            const int32_t node = vrc_ray_lod_hop( f, r, nodes, gridTable, tBase, te, t1, n, tp, tB );
             if( node >= 0 )
             {
                 const float scale = (float)( 1u << n.level );

@@ -268,7 +268,10 @@ __device__ __forceinline__ float lds_trilerp( const float v[8], uint32_t fx, uin
 
 /* GREY: the transfer function is grey and the frame starts from zero (vrc_raycast_args.greyTable): colours and table
  * entries are (grey, alpha) pairs, bit-identical to the four-float form (vrc_core.h, VRC_MODE_GREY) */
-template < bool COUNT, bool LINEAR, bool GREY = false >
+/* RAYLOD: per-ray adaptive LOD (vrc_pixel_ray_lod in vrc_core.h; trilinear only: samples are classified one by one, so
+ * no per-level table is needed): gridTable holds the per-level cell -> node tables, the walk is the hop of
+ * vrc_ray_lod_hop, and a lane's step and opacity exponent are those of its brick's level */
+template < bool COUNT, bool LINEAR, bool GREY = false, bool RAYLOD = false >
 /* four workgroups per CU: 4 x (4 regions of 8.25 KiB + the table) = 152 of the CU's 160 KiB */
 __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_raycast_lds(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
@@ -364,7 +367,18 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
     float t0 = 0.0f, t1 = 0.0f;
     uint32_t back = 0u;
     bool ddaEnd = false;
-    if( !done )
+    [[maybe_unused]] float te = 0.0f; /* RAYLOD: where the next hop starts */
+    if constexpr( RAYLOD )
+    {
+        if( !done )
+        {
+            if( vrc_ray_lod_interval( f, r, t0, t1 ) )
+                te = t0;
+            else
+                done = true;
+        }
+    }
+    else if( !done )
     {
         const vrc_f3 gmin = { f.gridMin[0], f.gridMin[1], f.gridMin[2] };
         const vrc_f3 gmax = { f.gridMin[0] + f.cellSize[0] * (float)f.gridDim[0],
@@ -426,6 +440,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
     int32_t curNode = -1, pNode = -1;
     uint32_t pfx = 0, pfy = 0, pfz = 0, pfdx = 0, pfdy = 0, pfdz = 0, pSlotBase = 0;
     float pTravel = 0.0f;
+    /* RAYLOD: 2^level of the current and of the next segment's brick (step and opacity exponent scale with it) */
+    [[maybe_unused]] float lscale = 1.0f, pScale = 1.0f;
     /* bricks already handed to the slab test; probe: what the walk does next at its cell (0: the cell
      * itself, 1..6: the cells around an edge / corner the ray leaves through, see vrc_pixel_grid_dda) */
     int32_t recent0 = -1, recent1 = -1, recent2 = -1, recent3 = -1;
@@ -439,7 +455,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
     uint32_t laneSlotBase = 0;
     uint32_t nSamples = 0;
     const float stepSize = f.stepSize;
-    int budget = 8 * ( f.gridDim[0] + f.gridDim[1] + f.gridDim[2] + 3 ); /* exit guarantee */
+    int budget = RAYLOD ? vrc_ray_lod_max_hops( f ) /* as vrc_pixel_ray_lod */
+                        : 8 * ( f.gridDim[0] + f.gridDim[1] + f.gridDim[2] + 3 ); /* exit guarantee */
 
     /* staging role of the lane: 4 row-pairs across (x), 16 down (y) per z-slice */
     const uint32_t sxr = lane & 3u, syp = lane >> 2;
@@ -472,6 +489,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
                     travel = pTravel;
                     curNode = pNode;
                     laneSlotBase = pSlotBase;
+                    if constexpr( RAYLOD )
+                        lscale = pScale;
                     hasSeg = true;
                     hasPend = false;
                 }
@@ -489,7 +508,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
             const uint64_t lackMask = __builtin_amdgcn_ballot_w64( lack );
             const uint64_t idleMask = __builtin_amdgcn_ballot_w64( lack && !hasSeg );
             const uint64_t soonMask = __builtin_amdgcn_ballot_w64(
-                lack && hasSeg && !( travel > stepSize * (float)( 2 * VRC_LDS_G ) ) );
+                lack && hasSeg && !( travel > ( RAYLOD ? stepSize * lscale : stepSize ) * (float)( 2 * VRC_LDS_G ) ) );
             refill = idleMask != 0ull || soonMask != 0ull || __builtin_popcountll( lackMask ) >= VRC_LDS_REFILL;
             anyLack = lackMask != 0ull;
             if( !refill )
@@ -515,7 +534,45 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
             const int stepDir[3] = { r.dir.x > 0.0f ? 1 : -1, r.dir.y > 0.0f ? 1 : -1, r.dir.z > 0.0f ? 1 : -1 };
             const float tDelta[3] = { fw.cellSize[0] * fabsf( r.invDir.x ), fw.cellSize[1] * fabsf( r.invDir.y ),
                                       fw.cellSize[2] * fabsf( r.invDir.z ) };
-            if( !done && !walkDone && !hasPend )
+            if constexpr( RAYLOD )
+            {
+                if( !done && !walkDone && !hasPend )
+                {
+                    /* one hop of vrc_pixel_ray_lod (vrc_core.h): the brick at te, marched to where the ray leaves it */
+                    if( !( te < t1 ) || --budget < 0 )
+                        walkDone = true;
+                    else
+                    {
+                        vrc_dev_node n;
+                        float tp, tB;
+                        const int32_t node = vrc_ray_lod_hop( fw, r, nodes, gridTable, vrc_ray_lod_base( fw, r ), te, t1, n, tp, tB );
+                        if( node >= 0 )
+                        {
+                            const float scale = (float)( 1u << n.level );
+                            const vrc_segment s = vrc_run_segment( r, tp, tB, stepSize * scale );
+                            if( s.dist > 0.0f )
+                            {
+                                const vrc_sampler sm = vrc_make_sampler( n, fw );
+                                const vrc_fixpos p0 = vrc_fixpos_init( sm, s.pos, s.step );
+                                const uint32_t h = LINEAR ? ( 1u << 23 ) : 0u;
+                                pfx = p0.x - h;
+                                pfy = p0.y - h;
+                                pfz = p0.z - h;
+                                pfdx = p0.dx;
+                                pfdy = p0.dy;
+                                pfdz = p0.dz;
+                                pTravel = s.dist;
+                                pNode = node;
+                                pSlotBase = n.slotBase;
+                                pScale = scale;
+                                hasPend = true;
+                            }
+                        }
+                        te = tB;
+                    }
+                }
+            }
+            else if( !done && !walkDone && !hasPend )
             {
                 if( ddaEnd || --budget < 0 )
                     walkDone = true;
@@ -633,6 +690,11 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
          * what no box served takes VRC_LDS_G steps by gathers */
         if( segMask == 0ull )
             break;
+        /* the lane's step along the ray and its classifier: per-ray LOD scales both with the brick's level */
+        const float lstep = RAYLOD ? stepSize * lscale : stepSize;
+        [[maybe_unused]] lds_cls lc = lcls;
+        if constexpr( RAYLOD )
+            lc.kexp = lcls.kexp * lscale;
         bool inTodo = hasSeg;
         bool passEvents = false; /* wave-uniform: a lane crossed the early-exit threshold or ran out of steps in a pass */
         for( int pass = 0; pass < VRC_LDS_PASSES; ++pass )
@@ -835,7 +897,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
                 {
                     float t[8];
                     lds_taps( region + a, region + a + pz, t );
-                    return lds_classify( (const C*)nullptr, tab, lds_trilerp( t, sx_, sy_, sz_ ), lcls );
+                    return lds_classify( (const C*)nullptr, tab, lds_trilerp( t, sx_, sy_, sz_ ), lc );
                 }
                 else
                     return lut[(uint32_t)region[a]];
@@ -867,7 +929,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
                     fx += take ? fdx : 0u;
                     fy += take ? fdy : 0u;
                     fz += take ? fdz : 0u;
-                    travel -= take ? stepSize : 0.0f;
+                    travel -= take ? lstep : 0.0f;
                     if( !FAST )
                         adv += take ? 1u : 0u;
                 }
@@ -880,7 +942,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
                         lds_taps( region + a[s], region + a[s] + pz, t[s] );
 #pragma unroll
                     for( int s = 0; s < BATCH; ++s )
-                        e[s] = lds_classify( (const C*)nullptr, tab, lds_trilerp( t[s], wfx[s], wfy[s], wfz[s] ), lcls );
+                        e[s] = lds_classify( (const C*)nullptr, tab, lds_trilerp( t[s], wfx[s], wfy[s], wfz[s] ), lc );
                 }
                 else
                 {
@@ -905,7 +967,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
                 /* groups of VRC_LDS_G steps that every participating lane takes in full, unrolled ... */
                 uint32_t s0 = 0;
                 while( s0 + VRC_LDS_G <= nMin &&
-                       __builtin_amdgcn_ballot_w64( !( travel > stepSize * (float)( VRC_LDS_G + 1 ) ) ) == 0ull )
+                       __builtin_amdgcn_ballot_w64( !( travel > lstep * (float)( VRC_LDS_G + 1 ) ) ) == 0ull )
                 {
 #pragma unroll
                     for( int b0 = 0; b0 < VRC_LDS_G; b0 += BATCH )
@@ -968,7 +1030,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
         if( inTodo )
         {
             fx += 8u * fdx; fy += 8u * fdy; fz += 8u * fdz;
-            travel -= 8.0f * stepSize;
+            travel -= 8.0f * lstep;
             inTodo = false;
         }
 #endif
@@ -1019,11 +1081,11 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
                             fx += fdx;
                             fy += fdy;
                             fz += fdz;
-                            travel -= stepSize;
+                            travel -= lstep;
                         }
 #pragma unroll
                         for( int s = 0; s < VRC_LDS_GBATCH; ++s )
-                            e[s] = lds_classify( (const C*)nullptr, tab, lds_trilerp( t[s], wfx[s], wfy[s], wfz[s] ), lcls );
+                            e[s] = lds_classify( (const C*)nullptr, tab, lds_trilerp( t[s], wfx[s], wfy[s], wfz[s] ), lc );
                     }
                     else
                     {
@@ -1041,7 +1103,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
                             fx += fdx;
                             fy += fdy;
                             fz += fdz;
-                            travel -= stepSize;
+                            travel -= lstep;
                         }
 #pragma unroll
                         for( int s = 0; s < VRC_LDS_GBATCH; ++s )
@@ -1106,18 +1168,36 @@ hipError_t vrc_launch_raycast_lds( const vrc_raycast_args& a, hipStream_t stream
     const dim3 grid( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_LDS_WAVES - 1u ) / VRC_LDS_WAVES ),
         block( 64u * VRC_LDS_WAVES );
     const bool count = a.sampleCounter != nullptr;
-    vrc_internal_note_kernel( "vrc_k_raycast_lds<%s,%s,%s>", count ? "true" : "false", a.linear ? "true" : "false",
-                              a.greyTable ? "true" : "false" );
-#define VRC_LDS_LAUNCH( COUNT, LINEAR, GREY )                                                         \
-    hipLaunchKernelGGL( ( vrc_k_raycast_lds< COUNT, LINEAR, GREY > ), grid, block, 0, stream, a.frame, \
-                        a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut, a.classifier,           \
+    const bool rayLod = a.frame.lodLevels > 0u; /* set by the host for vrc_set_ray_lod frames only */
+    if( rayLod && ( !a.linear || a.frame.variant != VRC_VARIANT_CUDA || a.frame.lodLevels > VRC_MAX_LOD_LEVELS ) )
+        return hipErrorInvalidValue;
+    if( rayLod )
+        vrc_internal_note_kernel( "vrc_k_raycast_lds<%s,true,%s,true>", count ? "true" : "false", a.greyTable ? "true" : "false" );
+    else
+        vrc_internal_note_kernel( "vrc_k_raycast_lds<%s,%s,%s>", count ? "true" : "false", a.linear ? "true" : "false",
+                                  a.greyTable ? "true" : "false" );
+#define VRC_LDS_LAUNCH_LOD( COUNT, LINEAR, GREY, RAYLOD )                                                      \
+    hipLaunchKernelGGL( ( vrc_k_raycast_lds< COUNT, LINEAR, GREY, RAYLOD > ), grid, block, 0, stream, a.frame, \
+                        a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut, a.classifier,                   \
                         a.pixelBuffer, a.sampleCounter, a.tileOrder, tilesX, nTiles )
+#define VRC_LDS_LAUNCH( COUNT, LINEAR, GREY ) VRC_LDS_LAUNCH_LOD( COUNT, LINEAR, GREY, false )
 #define VRC_LDS_LAUNCH_GREY( COUNT, LINEAR )                        \
     {                                                               \
         if( a.greyTable ) VRC_LDS_LAUNCH( COUNT, LINEAR, true );    \
         else VRC_LDS_LAUNCH( COUNT, LINEAR, false );                \
     }
-    if( a.linear )
+    if( rayLod )
+    {
+        if( a.greyTable )
+        {
+            if( count ) VRC_LDS_LAUNCH_LOD( true, true, true, true ); else VRC_LDS_LAUNCH_LOD( false, true, true, true );
+        }
+        else
+        {
+            if( count ) VRC_LDS_LAUNCH_LOD( true, true, false, true ); else VRC_LDS_LAUNCH_LOD( false, true, false, true );
+        }
+    }
+    else if( a.linear )
     {
         if( count ) VRC_LDS_LAUNCH_GREY( true, true ) else VRC_LDS_LAUNCH_GREY( false, true )
     }
@@ -1127,5 +1207,6 @@ hipError_t vrc_launch_raycast_lds( const vrc_raycast_args& a, hipStream_t stream
     }
 #undef VRC_LDS_LAUNCH_GREY
 #undef VRC_LDS_LAUNCH
+#undef VRC_LDS_LAUNCH_LOD
     return hipGetLastError();
 }

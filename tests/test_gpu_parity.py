@@ -776,6 +776,63 @@ def test_ray_lod_per_sample_classification_modes(vrc, filter_mode, dtype):
         assert abs(n_got - n_want) <= 3e-4 * n_want + 16
 
 
+def _ran(g):
+    return g.L.vrc_last_kernel().decode()
+
+
+@pytest.mark.parametrize("sse", [0.5, 1.3, 2.5, 6.0])
+@pytest.mark.parametrize("tf", ["grey", "rgb"])
+def test_ray_lod_trilinear_staged_through_lds(vrc, sse, tf):
+    # trilinear filter on 8-bit bricks: AUTO stages the voxels through LDS (vrc_k_raycast_lds<.,true,.,true>), GRID_DDA
+    # asks for the gather form (vrc_k_raycast_raylod); both are held to the oracle, and to each other
+    s = _hierarchy(viewport=(160, 120), volume="hash", spin=(0.4, 0.3), alpha=0.3)
+    if tf == "rgb":
+        i = np.arange(256, dtype=np.float32) / np.float32(255.0)
+        s.tf = np.ascontiguousarray(np.stack([i, i * i, np.float32(1.0) - i, np.float32(0.3) * i], axis=1))
+    lod = (sse, orc.world_space_per_pixel(s))
+    want, n_want = orc.oracle_render(s, ray_lod=lod, filter_mode=1)
+    with _gpu(s) as g:
+        staged, n_staged, st = g.render(ray_lod=lod, filter_mode=1)
+        assert st.kernel_variant == vrc.KERNEL_RAY_LOD
+        assert _ran(g).startswith("vrc_k_raycast_lds<true,true,") and _ran(g).endswith(",true>"), _ran(g)
+        gathered, n_gathered, _ = g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_GRID_DDA)
+        assert _ran(g).startswith("vrc_k_raycast_raylod<"), _ran(g)
+        forced, _, _ = g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_LDS)
+        assert (forced == staged).all()
+        uncounted, _, _ = g.render(ray_lod=lod, filter_mode=1, count=False)
+        assert (uncounted == staged).all()
+        with pytest.raises(Exception):
+            g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_REFERENCE_ORDER)
+    _lod_parity(staged, want, "staged sse %g" % sse)
+    _lod_parity(gathered, want, "gathers sse %g" % sse)
+    assert abs(n_staged - n_want) <= 3e-4 * n_want + 16
+    assert abs(n_gathered - n_want) <= 3e-4 * n_want + 16
+
+
+@pytest.mark.parametrize("seed", range(10 * scenes.FUZZ_SCALE))
+def test_ray_lod_trilinear_staged_random_views(vrc, seed):
+    rng = np.random.default_rng(7300 + seed)
+    vox = [int(rng.choice([32, 64, 96])) for _ in range(3)]
+    block = int(rng.choice([16, 32]))
+    vox = [max(v, block) // block * block for v in vox]
+    kw = dict(voxels=tuple(vox), block=block, viewport=(int(rng.integers(40, 200)), int(rng.integers(40, 160))),
+              volume=str(rng.choice(["hash", "mem"])),
+              spin=(float(rng.uniform(-3.1, 3.1)), float(rng.uniform(-1.5, 1.5))),
+              alpha=float(rng.choice([0.05, 0.3, 1.0])))
+    if rng.random() < 0.3:
+        kw["eye"] = (float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-0.4, 0.4)), float(rng.uniform(0.1, 0.9)))
+    if rng.random() < 0.3:
+        kw["planes"] = [[0.0, 0.6, 0.8, 0.2]]
+    s = _hierarchy(**kw)
+    lod = (float(rng.uniform(0.3, 4.0)) * vox[0] / 64.0 * 48.0 / s.H, orc.world_space_per_pixel(s))
+    want, n_want = orc.oracle_render(s, threads=8, ray_lod=lod, filter_mode=1)
+    with _gpu(s) as g:
+        got, n_got, _ = g.render(ray_lod=lod, filter_mode=1)
+        assert _ran(g).startswith("vrc_k_raycast_lds<"), _ran(g)
+    _lod_parity(got, want, "seed %d %r lod %r" % (seed, kw, lod))
+    assert abs(n_got - n_want) <= 3e-4 * n_want + 16
+
+
 def test_ray_lod_small_bound_equals_the_leaf_render(vrc):
     s = _hierarchy(viewport=(128, 96), volume="hash", spin=(0.5, -0.2))
     leaves = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(128, 96), volume="hash", spin=(0.5, -0.2),
