@@ -1113,15 +1113,17 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
      * the trilinear filter (eight taps per sample), the gather kernel for point sampling. */
     /* its trilinear form takes the transfer-function texel and CUDA's 1.8 fixed-point lerp weight out of one
      * float -> integer conversion (vrc_kernels_lds.hip: lds_classify): other weight widths use the gather form */
-    const bool ldsEligible = c->cachedGridOk && !c->cachedClamp && pool->elemBytes == 1 && !pool->bigAtlas &&
+    /* 16-bit voxels: its trilinear form only (a 16-bit density does not index the classified table of the point form) */
+    const bool ldsVoxels = pool->elemBytes == 1 || ( pool->elemBytes == 2 && linear );
+    const bool ldsEligible = c->cachedGridOk && !c->cachedClamp && ldsVoxels && !pool->bigAtlas &&
                              ( !linear || c->optTfFracBits == 8 );
     if( !c->rayLod && c->optKernel == VRC_KERNEL_LDS && !ldsEligible )
-        return fail( VRC_EINVAL, "vrc_render: the LDS kernel needs a grid-aligned node set of 8-bit bricks with overlap >= 1 (trilinear: VRC_OPT_TF_FRAC_BITS = 8)" );
+        return fail( VRC_EINVAL, "vrc_render: the LDS kernel needs a grid-aligned node set of 8-bit bricks (trilinear: 8- or 16-bit, VRC_OPT_TF_FRAC_BITS = 8) with overlap >= 1" );
     /* per-ray LOD: the staged kernel's trilinear form only (samples classified one by one: no table per level) */
-    const bool ldsLodEligible = c->rayLod && linear && !c->cachedClamp && pool->elemBytes == 1 && !pool->bigAtlas &&
+    const bool ldsLodEligible = c->rayLod && linear && !c->cachedClamp && ldsVoxels && !pool->bigAtlas &&
                                 c->optTfFracBits == 8;
     if( c->rayLod && c->optKernel == VRC_KERNEL_LDS && !ldsLodEligible )
-        return fail( VRC_EINVAL, "vrc_render: under per-ray LOD the LDS kernel needs the trilinear filter, 8-bit bricks with overlap >= 1 and VRC_OPT_TF_FRAC_BITS = 8" );
+        return fail( VRC_EINVAL, "vrc_render: under per-ray LOD the LDS kernel needs the trilinear filter, 8- or 16-bit bricks with overlap >= 1 and VRC_OPT_TF_FRAC_BITS = 8" );
     const bool useLds = c->rayLod ? ( ldsLodEligible && c->optKernel != VRC_KERNEL_GRID_DDA )
                                   : !glSuper && ( c->optKernel == VRC_KERNEL_LDS ||
                                                   ( c->optKernel == VRC_KERNEL_AUTO && linear && ldsEligible ) );

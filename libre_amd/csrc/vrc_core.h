@@ -40,6 +40,7 @@
     defined( VRC_LDS_ABLATE_GATHER ) || \
     defined( VRC_LDS_NO_STEP_CAP ) || \
     defined( VRC_LDS_PASSES ) || defined( VRC_LDS_ROWS ) || defined( VRC_LDS_OCC ) || defined( VRC_LDS_STAGE_N ) || \
+    defined( VRC_LDS_ROWS16 ) || defined( VRC_LDS_OCC16 ) || defined( VRC_LDS_STAGE_N16 ) || \
     defined( VRC_LDS_KMAX ) || \
     defined( VRC_LDS_MAX_DZ ) || \
     defined( VRC_LDS_LBATCH ) || \

@@ -70,6 +70,25 @@
 #define VRC_LDS_STAGE_N 11 /* slice loads in flight in one staging batch */
 #endif
 #define VRC_LDS_REGION ( VRC_LDS_PY * VRC_LDS_ROWS )
+/* 16-bit voxels (trilinear only): rows of 32 voxels are 64 bytes, and the CU's 160 KiB of LDS decide how many waves
+ * can hold a box at all.  Measured on the C2 shape with a 16-bit volume (1024^3, 128^3 bricks, 1024^2 pixels, ms per
+ * frame, view along z / spun 30,20 deg; the gather form takes 2.93 / 3.80):
+ *   264 rows, 2 workgroups per CU, 8 slices per staging batch   3.60 / 4.33
+ *   264 rows, 2 per CU, 11 per batch                            3.07 / 4.00
+ *   132 rows, 4 per CU,  5 per batch                            2.80 / 4.44      (7 per batch: 3.02 / 4.69)
+ *   192 rows, 3 per CU,  8 per batch                            2.76 / 3.77
+ *   192 rows, 3 per CU, 11 per batch                            2.38 / 3.74   <- taken
+ * (8-bit voxels: 264 rows at 4 per CU, 1.95 / 2.6.)  Twice the bytes per voxel cost the staged form most of its
+ * advantage: either the boxes or the number of waves that hide each other's staging latency shrink. */
+#ifndef VRC_LDS_ROWS16
+#define VRC_LDS_ROWS16 192u
+#endif
+#ifndef VRC_LDS_OCC16
+#define VRC_LDS_OCC16 3
+#endif
+#ifndef VRC_LDS_STAGE_N16
+#define VRC_LDS_STAGE_N16 11 /* slice loads (of two 16-byte pieces) in flight in one staging batch */
+#endif
 #define VRC_LDS_MAX_DY 32u /* 16 row pairs: one per staging lane group */
 #ifndef VRC_LDS_MAX_DZ
 #define VRC_LDS_MAX_DZ ( 2u * VRC_LDS_STAGE_N ) /* two staging halves */
@@ -150,6 +169,39 @@ __device__ __forceinline__ uint32_t wave_or( uint32_t v )
 
 /* copy N z-slices of the box: per lane one 16-byte piece (two 8-voxel rows) per slice */
 /* between: work that does not depend on the box's voxels, done while the loads are on their way */
+/* 16-bit voxels: the two rows are two 16-byte pieces (offsets, strides and pitches are in voxels) */
+template < int N, typename F >
+__device__ __forceinline__ void lds_stage( const uint16_t* __restrict__ slotPtr, uint32_t partial,
+                                           uint32_t sliceStride, uint32_t z0, uint32_t dz, bool on,
+                                           uint16_t* dst, uint32_t pz, F between )
+{
+    uint4 v0[N], v1[N];
+    if( on )
+    {
+#pragma unroll
+        for( int z = 0; z < N; ++z )
+        {
+            const uint32_t zc = (uint32_t)z < dz ? (uint32_t)z : dz - 1u;
+            const uint32_t zz = z0 + zc;
+            const uint16_t* const zb = slotPtr + ( ( zz >> VRC_MB_SHIFT ) * sliceStride + ( ( zz & 7u ) << 6 ) );
+            v0[z] = *reinterpret_cast< const uint4* >( zb + partial );
+            v1[z] = *reinterpret_cast< const uint4* >( zb + partial + 8u );
+        }
+    }
+    between();
+    if( !on )
+        return;
+#pragma unroll
+    for( int z = 0; z < N; ++z )
+    {
+        if( (uint32_t)z < dz )
+        {
+            /* (component by component: the struct copy kept the arrays in scratch memory) */
+            *reinterpret_cast< uint4* >( dst + z * pz ) = make_uint4( v0[z].x, v0[z].y, v0[z].z, v0[z].w );
+            *reinterpret_cast< uint4* >( dst + z * pz + VRC_LDS_PY ) = make_uint4( v1[z].x, v1[z].y, v1[z].z, v1[z].w );
+        }
+    }
+}
 template < int N, typename F >
 __device__ __forceinline__ void lds_stage( const uint8_t* __restrict__ slotPtr, uint32_t partial,
                                            uint32_t sliceStride, uint32_t z0, uint32_t dz, bool on,
@@ -240,7 +292,8 @@ __device__ __forceinline__ vrc_f4 lds_classify( const vrc_f4*, const float4* tab
  * W and 2^24 - W are exact, so every product and sum is 2^24 (2^48, 2^72) times the one with scaled
  * weights, bit for bit; lds_cls.mult carries the 2^-72 */
 /* p: the sample's voxel in the box, q: the same voxel one slice further */
-__device__ __forceinline__ void lds_taps( const uint8_t* p, const uint8_t* q, float t[8] )
+template < typename V >
+__device__ __forceinline__ void lds_taps( const V* p, const V* q, float t[8] )
 {
     t[0] = (float)p[0];
     t[1] = (float)p[1];
@@ -271,11 +324,12 @@ __device__ __forceinline__ float lds_trilerp( const float v[8], uint32_t fx, uin
 /* RAYLOD: per-ray adaptive LOD (vrc_pixel_ray_lod in vrc_core.h; trilinear only: samples are classified one by one, so
  * no per-level table is needed): gridTable holds the per-level cell -> node tables, the walk is the hop of
  * vrc_ray_lod_hop, and a lane's step and opacity exponent are those of its brick's level */
-template < bool COUNT, bool LINEAR, bool GREY = false, bool RAYLOD = false >
+/* V: the voxel type of the atlas (uint16_t: trilinear only -- a 16-bit density does not index the classified table) */
+template < bool COUNT, bool LINEAR, bool GREY = false, bool RAYLOD = false, typename V = uint8_t >
 /* four workgroups per CU: 4 x (4 regions of 8.25 KiB + the table) = 152 of the CU's 160 KiB */
-__global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_raycast_lds(
+__global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC16 : VRC_LDS_OCC ) void vrc_k_raycast_lds(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
-    const int32_t* __restrict__ gridTable, const uint8_t* __restrict__ atlas,
+    const int32_t* __restrict__ gridTable, const V* __restrict__ atlas,
     const vrc_f4* __restrict__ lutGlobal, const vrc_classifier cls,
     vrc_f4* __restrict__ pixelBuffer, unsigned long long* __restrict__ sampleCounter,
     const uint32_t* __restrict__ tileOrder, const uint32_t tilesX, const uint32_t nTiles )
@@ -288,7 +342,9 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
     constexpr uint32_t TAB_ENTRIES = LINEAR ? ( GREY ? VRC_TFP_ENTRIES : VRC_TFP_ENTRIES + 1u ) : 1u;
     __shared__ C lut[LINEAR ? 1u : VRC_TFP_ENTRIES];
     __shared__ __attribute__( ( aligned( 16 ) ) ) float4 tab[TAB_ENTRIES];
-    __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t regions[VRC_LDS_WAVES][VRC_LDS_REGION];
+    static_assert( sizeof( V ) == 1 || LINEAR, "16-bit voxels are classified sample by sample" );
+    constexpr uint32_t ROWS = sizeof( V ) == 2 ? VRC_LDS_ROWS16 : VRC_LDS_ROWS;
+    __shared__ __attribute__( ( aligned( 16 ) ) ) V regions[VRC_LDS_WAVES][VRC_LDS_PY * ROWS];
 
     if constexpr( LINEAR )
     {
@@ -323,7 +379,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
     const uint32_t tilesY = nTiles / tilesX;
     if( slot >= vrc_schedule_slots( tilesX, tilesY ) )
         return;
-    uint8_t* const region = regions[wave];
+    V* const region = regions[wave];
 #if defined( VRC_LDS_TIMING )
     unsigned long long phaseAcc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, phaseT0 = __builtin_readcyclecounter();
     int phaseCur = 6;
@@ -707,7 +763,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
             const uint32_t lead = ( todoMask >> 15 ) & 1ull ? 15u
                                   : ( ( todoMask >> 48 ) & 1ull ? 48u : (uint32_t)__builtin_ctzll( todoMask ) );
             const int32_t brick = __builtin_amdgcn_readlane( curNode, lead );
-            const uint8_t* const slotPtr = atlas + (uint32_t)__builtin_amdgcn_readlane( (int)laneSlotBase, lead );
+            const V* const slotPtr = atlas + (uint32_t)__builtin_amdgcn_readlane( (int)laneSlotBase, lead );
             constexpr uint32_t EXT = LINEAR ? 1u : 0u; /* the taps of a sample reach one voxel further */
 
             /* ---- the box: where the lanes ARE, extended along the march ------------------------------------
@@ -742,7 +798,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
                 /* does a box fit the region: pieces of 8 voxels in x, row pairs in y */
                 auto fits = [&]( uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, uint32_t z0, uint32_t z1 ) {
                     const uint32_t dx = ( x1 | 7u ) - ( x0 & ~7u ) + 1u, dy = ( y1 | 1u ) - ( y0 & ~1u ) + 1u, dz = z1 - z0 + 1u;
-                    return dx <= VRC_LDS_PY && dy <= VRC_LDS_MAX_DY && dz <= VRC_LDS_MAX_DZ && dy * dz <= VRC_LDS_ROWS;
+                    return dx <= VRC_LDS_PY && dy <= VRC_LDS_MAX_DY && dz <= VRC_LDS_MAX_DZ && dy * dz <= ROWS;
                 };
                 /* the samples as they are do not fit (lanes far apart): give up the voxels furthest from the
                  * lead's sample, one slab at a time; the lanes that needed them are left for the next pass */
@@ -855,11 +911,20 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
                 const uint32_t partial =
                     ( ( y >> VRC_MB_SHIFT ) * f.sbx + ( x >> VRC_MB_SHIFT ) ) * VRC_MB_VOXELS +
                     ( ( y & 7u ) << 3 );
-                uint8_t* const dst = region + ldsLane;
+                V* const dst = region + ldsLane;
                 /* every slice load of a batch is issued before the first LDS write; slices
                  * past the box repeat its last slice (branch-free, same cache lines) */
                 /* the lanes' step counts are worked out while the loads are on their way */
-                if( box.dz <= 8u )
+                if constexpr( sizeof( V ) == 2 )
+                {
+                    /* batches of VRC_LDS_STAGE_N16 slices: twice the registers per slice in flight */
+                    constexpr uint32_t S = VRC_LDS_STAGE_N16;
+                    lds_stage< (int)S >( slotPtr, partial, sliceStride, box.z0, box.dz < S ? box.dz : S, on, dst, pz, countSteps );
+                    for( uint32_t z = S; z < box.dz; z += S )
+                        lds_stage< (int)S >( slotPtr, partial, sliceStride, box.z0 + z, box.dz - z < S ? box.dz - z : S, on,
+                                             dst + z * pz, pz, []() {} );
+                }
+                else if( box.dz <= 8u )
                     lds_stage< 8 >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst, pz, countSteps );
                 else if( box.dz <= (uint32_t)VRC_LDS_STAGE_N )
                     lds_stage< VRC_LDS_STAGE_N >( slotPtr, partial, sliceStride, box.z0, box.dz, on, dst, pz, countSteps );
@@ -1158,55 +1223,52 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, VRC_LDS_OCC ) void vrc_k_rayca
     }
 }
 
-hipError_t vrc_launch_raycast_lds( const vrc_raycast_args& a, hipStream_t stream )
+namespace
+{
+template < bool LINEAR, bool RAYLOD, typename V >
+hipError_t launch_lds( const vrc_raycast_args& a, hipStream_t stream )
 {
     const uint32_t tilesX = ( a.frame.width + 7u ) / 8u;
     const uint32_t tilesY = ( a.frame.height + 7u ) / 8u;
     const uint32_t nTiles = tilesX * tilesY;
-    if( nTiles == 0 )
-        return hipSuccess;
     const dim3 grid( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_LDS_WAVES - 1u ) / VRC_LDS_WAVES ),
         block( 64u * VRC_LDS_WAVES );
     const bool count = a.sampleCounter != nullptr;
-    const bool rayLod = a.frame.lodLevels > 0u; /* set by the host for vrc_set_ray_lod frames only */
-    if( rayLod && ( !a.linear || a.frame.variant != VRC_VARIANT_CUDA || a.frame.lodLevels > VRC_MAX_LOD_LEVELS ) )
-        return hipErrorInvalidValue;
-    if( rayLod )
-        vrc_internal_note_kernel( "vrc_k_raycast_lds<%s,true,%s,true>", count ? "true" : "false", a.greyTable ? "true" : "false" );
-    else
-        vrc_internal_note_kernel( "vrc_k_raycast_lds<%s,%s,%s>", count ? "true" : "false", a.linear ? "true" : "false",
-                                  a.greyTable ? "true" : "false" );
-#define VRC_LDS_LAUNCH_LOD( COUNT, LINEAR, GREY, RAYLOD )                                                      \
-    hipLaunchKernelGGL( ( vrc_k_raycast_lds< COUNT, LINEAR, GREY, RAYLOD > ), grid, block, 0, stream, a.frame, \
-                        a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut, a.classifier,                   \
-                        a.pixelBuffer, a.sampleCounter, a.tileOrder, tilesX, nTiles )
-#define VRC_LDS_LAUNCH( COUNT, LINEAR, GREY ) VRC_LDS_LAUNCH_LOD( COUNT, LINEAR, GREY, false )
-#define VRC_LDS_LAUNCH_GREY( COUNT, LINEAR )                        \
-    {                                                               \
-        if( a.greyTable ) VRC_LDS_LAUNCH( COUNT, LINEAR, true );    \
-        else VRC_LDS_LAUNCH( COUNT, LINEAR, false );                \
-    }
-    if( rayLod )
+    /* the instance as rocprofv3 prints it (defaulted template arguments are printed too) */
+    vrc_internal_note_kernel( "vrc_k_raycast_lds<%s,%s,%s,%s,%s>", count ? "true" : "false", LINEAR ? "true" : "false",
+                              a.greyTable ? "true" : "false", RAYLOD ? "true" : "false",
+                              sizeof( V ) == 1 ? "unsigned char" : "unsigned short" );
+#define VRC_LDS_LAUNCH( COUNT, GREY )                                                                             \
+    hipLaunchKernelGGL( ( vrc_k_raycast_lds< COUNT, LINEAR, GREY, RAYLOD, V > ), grid, block, 0, stream, a.frame, \
+                        a.nodes, a.gridTable, (const V*)a.atlas, a.lut, a.classifier, a.pixelBuffer,              \
+                        a.sampleCounter, a.tileOrder, tilesX, nTiles )
+    if( a.greyTable )
     {
-        if( a.greyTable )
-        {
-            if( count ) VRC_LDS_LAUNCH_LOD( true, true, true, true ); else VRC_LDS_LAUNCH_LOD( false, true, true, true );
-        }
-        else
-        {
-            if( count ) VRC_LDS_LAUNCH_LOD( true, true, false, true ); else VRC_LDS_LAUNCH_LOD( false, true, false, true );
-        }
-    }
-    else if( a.linear )
-    {
-        if( count ) VRC_LDS_LAUNCH_GREY( true, true ) else VRC_LDS_LAUNCH_GREY( false, true )
+        if( count ) VRC_LDS_LAUNCH( true, true ); else VRC_LDS_LAUNCH( false, true );
     }
     else
     {
-        if( count ) VRC_LDS_LAUNCH_GREY( true, false ) else VRC_LDS_LAUNCH_GREY( false, false )
+        if( count ) VRC_LDS_LAUNCH( true, false ); else VRC_LDS_LAUNCH( false, false );
     }
-#undef VRC_LDS_LAUNCH_GREY
 #undef VRC_LDS_LAUNCH
-#undef VRC_LDS_LAUNCH_LOD
     return hipGetLastError();
+}
+}
+
+hipError_t vrc_launch_raycast_lds( const vrc_raycast_args& a, hipStream_t stream )
+{
+    if( a.frame.width == 0u || a.frame.height == 0u )
+        return hipSuccess;
+    const bool rayLod = a.frame.lodLevels > 0u; /* set by the host for vrc_set_ray_lod frames only */
+    /* point sampling reads the 257-entry classified table: 8-bit voxels, one level */
+    if( ( a.elemBytes != 1u && a.elemBytes != 2u ) || ( !a.linear && ( rayLod || a.elemBytes != 1u ) ) || a.bigAtlas || a.clamp ||
+        !a.gridTable )
+        return hipErrorInvalidValue;
+    if( rayLod && ( a.frame.variant != VRC_VARIANT_CUDA || a.frame.lodLevels > VRC_MAX_LOD_LEVELS ) )
+        return hipErrorInvalidValue;
+    if( !a.linear )
+        return launch_lds< false, false, uint8_t >( a, stream );
+    if( a.elemBytes == 2u )
+        return rayLod ? launch_lds< true, true, uint16_t >( a, stream ) : launch_lds< true, false, uint16_t >( a, stream );
+    return rayLod ? launch_lds< true, true, uint8_t >( a, stream ) : launch_lds< true, false, uint8_t >( a, stream );
 }

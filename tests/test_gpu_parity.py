@@ -169,6 +169,33 @@ def test_lds_kernel_refuses_clamped_sampler(vrc):
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
 
 
+@pytest.mark.parametrize("case", ["axis", "x", "oblique", "near_y", "diagonal", "c3_shape", "c3_shape_opaque"])
+def test_lds_staged_trilinear_uint16(vrc, case):
+    # 16-bit voxels through the LDS-staged trilinear kernel: views along each axis of a small-brick volume and the
+    # 136^3-slot shape of BASELINE C3's bricks, against the gather form (same samples: same count, same frame up to
+    # the contraction of multiply-adds) and the oracle
+    spins = dict(axis=(0.0, 0.0), x=(1.5708, 0.0), oblique=(-1.5, 0.3), near_y=(0.3, 1.45), diagonal=(0.7854, 0.7854))
+    if case.startswith("c3_shape"):
+        s = orc.build_scene(voxels=(256, 256, 256), block=128, viewport=(256, 256), volume="hash", spin=(0.5236, 0.349),
+                            alpha=1.0 if case.endswith("opaque") else 0.3, dtype="u16")
+    else:
+        s = orc.build_scene(voxels=(96, 80, 112), block=16, viewport=(160, 128), volume="hash", spin=spins[case], dtype="u16")
+    want_lin, n_want_lin = orc.oracle_render(s, threads=16, filter_mode=1)
+    with _gpu(s) as g:
+        lin, n_lin, st = g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_LDS and g.L.vrc_last_kernel().decode().endswith(",false,unsigned short>")
+        gat, n_gat, st = g.render(kernel=vrc.KERNEL_GRID_DDA, filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_GRID_DDA
+        vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 0))
+        four, n_four, _ = g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
+    scenes.assert_parity(lin, want_lin, "u16 staged trilinear, " + case)
+    scenes.assert_parity(gat, want_lin, "u16 gathered trilinear, " + case)
+    assert abs(n_lin - n_want_lin) <= 2e-4 * n_want_lin + 8
+    assert abs(n_lin - n_gat) <= 2e-4 * n_gat + 8
+    assert np.abs(lin - gat).max() <= (2e-3 if case.endswith("opaque") else 2e-5)
+    assert n_four == n_lin and (four == lin).all()  # the four-float form of the staged kernel: the same bits
+
+
 @pytest.mark.parametrize("name", ["hash64_spin_u16", "hash64_ert_u16", "mem_ragged_u16"])
 def test_uint16_extension_parity(vrc, name):
     # 16-bit voxels: point sampled and trilinear, classified per sample through the data range
@@ -189,7 +216,16 @@ def test_uint16_extension_parity(vrc, name):
             scenes.assert_parity(lin, want_lin, name + " trilinear k%d" % k)
             assert abs(n_got - n_lin) <= 2e-4 * n_lin + 8
         with pytest.raises(Exception):
-            g.render(kernel=vrc.KERNEL_LDS)  # the LDS kernel is 8-bit only
+            g.render(kernel=vrc.KERNEL_LDS)  # point sampling through LDS reads the classified table: 8-bit only
+        # the trilinear filter is staged through LDS for 16-bit voxels too (what AUTO picks)
+        staged, n_got, st = g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_LDS and g.L.vrc_last_kernel().decode().endswith(",false,unsigned short>")
+        scenes.assert_parity(staged, want_lin, name + " trilinear, staged")
+        assert abs(n_got - n_lin) <= 2e-4 * n_lin + 8
+        auto, _, st = g.render(filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_LDS and (auto == staged).all()
+        uncounted, _, _ = g.render(filter_mode=vrc.FILTER_TRILINEAR, count=False)
+        assert (uncounted == staged).all()
 
 
 def test_unsupported_voxel_types_are_refused(vrc):
@@ -518,6 +554,9 @@ def test_random_views_uint16_and_multipass(vrc, seed):
             assert abs(n_got - n16) <= 3e-4 * n16 + 16
             got, _, _ = g.render(kernel=k, filter_mode=vrc.FILTER_TRILINEAR)
             _fuzz_parity(got, want16_lin, "seed %d u16 trilinear k%d %r" % (seed, k, kw))
+        got, _, st = g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_LDS
+        _fuzz_parity(got, want16_lin, "seed %d u16 trilinear staged %r" % (seed, kw))
     s = orc.build_scene(**kw)
     want, n_want = orc.oracle_render(s, threads=8)
     cuts = sorted(set(int(c) for c in rng.integers(1, max(2, s.n_nodes), size=3)) | {0, s.n_nodes})
@@ -781,11 +820,12 @@ def _ran(g):
 
 
 @pytest.mark.parametrize("sse", [0.5, 1.3, 2.5, 6.0])
-@pytest.mark.parametrize("tf", ["grey", "rgb"])
+@pytest.mark.parametrize("tf", ["grey", "rgb", "grey_u16"])
 def test_ray_lod_trilinear_staged_through_lds(vrc, sse, tf):
     # trilinear filter on 8-bit bricks: AUTO stages the voxels through LDS (vrc_k_raycast_lds<.,true,.,true>), GRID_DDA
     # asks for the gather form (vrc_k_raycast_raylod); both are held to the oracle, and to each other
-    s = _hierarchy(viewport=(160, 120), volume="hash", spin=(0.4, 0.3), alpha=0.3)
+    voxel = "unsigned short" if tf == "grey_u16" else "unsigned char"
+    s = _hierarchy(viewport=(160, 120), volume="hash", spin=(0.4, 0.3), alpha=0.3, dtype="u16" if tf == "grey_u16" else "u8")
     if tf == "rgb":
         i = np.arange(256, dtype=np.float32) / np.float32(255.0)
         s.tf = np.ascontiguousarray(np.stack([i, i * i, np.float32(1.0) - i, np.float32(0.3) * i], axis=1))
@@ -794,7 +834,7 @@ def test_ray_lod_trilinear_staged_through_lds(vrc, sse, tf):
     with _gpu(s) as g:
         staged, n_staged, st = g.render(ray_lod=lod, filter_mode=1)
         assert st.kernel_variant == vrc.KERNEL_RAY_LOD
-        assert _ran(g).startswith("vrc_k_raycast_lds<true,true,") and _ran(g).endswith(",true>"), _ran(g)
+        assert _ran(g).startswith("vrc_k_raycast_lds<true,true,") and _ran(g).endswith(",true,%s>" % voxel), _ran(g)
         gathered, n_gathered, _ = g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_GRID_DDA)
         assert _ran(g).startswith("vrc_k_raycast_raylod<"), _ran(g)
         forced, _, _ = g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_LDS)
