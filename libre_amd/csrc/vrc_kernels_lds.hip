@@ -986,7 +986,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
                 {
                     const bool take = FAST ? true : ( s0 + (uint32_t)s < nSteps );
                     act[s] = FAST ? true : ( take && travel > 0.0f );
-                    const uint32_t av = ( fz >> 24 ) * pz + ( fy >> 24 ) * VRC_LDS_PY + ( fx >> 24 ) - bias;
+                    /* (slice < 256, pitch <= 1024: a 24-bit multiply-add instead of the quarter-rate 32-bit multiply) */
+                    const uint32_t av = vrc_mul24( fz >> 24, pz ) + ( ( fy >> 24 ) * VRC_LDS_PY + ( fx >> 24 ) ) - bias;
                     a[s] = take ? av : 0u; /* a step the lane does not take may lie outside the box: it reads offset 0 */
                     wfx[s] = fx;
                     wfy[s] = fy;
@@ -1072,7 +1073,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
                     {
                         if( !fin && s < cnt )
                         {
-                            const uint32_t a = ( rz >> 24 ) * pz + ( ry >> 24 ) * VRC_LDS_PY + ( rx >> 24 ) - bias;
+                            const uint32_t a = vrc_mul24( rz >> 24, pz ) + ( ( ry >> 24 ) * VRC_LDS_PY + ( rx >> 24 ) ) - bias;
                             vrc_composite( color, sampleLds( a, rx, ry, rz ) );
                             if( COUNT )
                                 nSamples += 1u;

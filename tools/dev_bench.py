@@ -69,8 +69,8 @@ def main():
         kernels = [vrc.KERNEL_GRID_DDA] + ([vrc.KERNEL_REFERENCE_ORDER] if a.ref_order else [])
         if a.kernels:
             kernels = a.kernels
-        if lod:
-            kernels = [vrc.KERNEL_AUTO]
+        if lod and not a.kernels:
+            kernels = [vrc.KERNEL_AUTO]  # (under per-ray LOD: 0 = staged where it applies, 2 = gathers)
         for k, flt, parts in [(k, flt, parts) for flt in a.filters for k in kernels for parts in a.ert_parts]:
             vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_KERNEL, k))
             vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_FILTER, flt))
