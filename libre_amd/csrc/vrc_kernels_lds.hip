@@ -155,8 +155,11 @@ namespace
 /* wave64 OR: four DPP steps inside each row of 16 lanes, two row broadcasts, result read from lane 63 */
 __device__ __forceinline__ uint32_t wave_or( uint32_t v )
 {
+    /* old = 0 (the identity of OR) with bound_ctrl: the compiler folds each step into ONE v_or_b32_dpp; with old = v
+     * it emitted a copy, a v_mov_b32_dpp and the OR -- 18 instructions per reduction instead of 6, four reductions per
+     * pass */
 #define VRC_DPP_STEP( CTRL, ROWMASK ) \
-    v |= (uint32_t)__builtin_amdgcn_update_dpp( (int)v, (int)v, CTRL, ROWMASK, 0xF, false );
+    v |= (uint32_t)__builtin_amdgcn_update_dpp( 0, (int)v, CTRL, ROWMASK, 0xF, true );
     VRC_DPP_STEP( 0xB1, 0xF )  /* quad_perm [1,0,3,2] */
     VRC_DPP_STEP( 0x4E, 0xF )  /* quad_perm [2,3,0,1] */
     VRC_DPP_STEP( 0x141, 0xF ) /* row_half_mirror */
@@ -167,6 +170,13 @@ __device__ __forceinline__ uint32_t wave_or( uint32_t v )
     return (uint32_t)__builtin_amdgcn_readlane( (int)v, 63 );
 }
 
+/* the staging loads: pointers into global memory, spelled out -- a slice's base goes through an empty asm (below), which
+ * hides from the compiler where it points */
+typedef uint32_t lds_u32x4 __attribute__( ( ext_vector_type( 4 ) ) );
+typedef __attribute__( ( address_space( 1 ) ) ) const lds_u32x4 lds_g_u32x4;
+typedef __attribute__( ( address_space( 1 ) ) ) const uint8_t lds_g_u8;
+typedef __attribute__( ( address_space( 1 ) ) ) const uint16_t lds_g_u16;
+
 /* copy N z-slices of the box: per lane one 16-byte piece (two 8-voxel rows) per slice */
 /* between: work that does not depend on the box's voxels, done while the loads are on their way */
 /* 16-bit voxels: the two rows are two 16-byte pieces (offsets, strides and pitches are in voxels) */
@@ -175,17 +185,20 @@ __device__ __forceinline__ void lds_stage( const uint16_t* __restrict__ slotPtr,
                                            uint32_t sliceStride, uint32_t z0, uint32_t dz, bool on,
                                            uint16_t* dst, uint32_t pz, F between )
 {
-    uint4 v0[N], v1[N];
+    lds_u32x4 v0[N], v1[N];
     if( on )
     {
+        uint32_t pl = partial;
 #pragma unroll
         for( int z = 0; z < N; ++z )
         {
             const uint32_t zc = (uint32_t)z < dz ? (uint32_t)z : dz - 1u;
             const uint32_t zz = z0 + zc;
-            const uint16_t* const zb = slotPtr + ( ( zz >> VRC_MB_SHIFT ) * sliceStride + ( ( zz & 7u ) << 6 ) );
-            v0[z] = *reinterpret_cast< const uint4* >( zb + partial );
-            v1[z] = *reinterpret_cast< const uint4* >( zb + partial + 8u );
+            const uint16_t* zb = slotPtr + ( ( zz >> VRC_MB_SHIFT ) * sliceStride + ( ( zz & 7u ) << 6 ) );
+            asm volatile( "" : "+s"( zb ), "+v"( pl ) ); /* see the 8-bit form */
+            lds_g_u16* const g = (lds_g_u16*)zb;
+            v0[z] = *(lds_g_u32x4*)( g + pl );
+            v1[z] = *(lds_g_u32x4*)( g + pl + 8u );
         }
     }
     between();
@@ -207,16 +220,23 @@ __device__ __forceinline__ void lds_stage( const uint8_t* __restrict__ slotPtr, 
                                            uint32_t sliceStride, uint32_t z0, uint32_t dz, bool on,
                                            uint8_t* dst, uint32_t pz, F between )
 {
-    uint4 v[N];
+    lds_u32x4 v[N];
     if( on )
     {
+        uint32_t pl = partial;
 #pragma unroll
         for( int z = 0; z < N; ++z )
         {
             const uint32_t zc = (uint32_t)z < dz ? (uint32_t)z : dz - 1u;
             const uint32_t zz = z0 + zc;
-            const uint8_t* const zb = slotPtr + ( ( zz >> VRC_MB_SHIFT ) * sliceStride + ( ( zz & 7u ) << 6 ) );
-            v[z] = *reinterpret_cast< const uint4* >( zb + partial );
+            const uint8_t* zb = slotPtr + ( ( zz >> VRC_MB_SHIFT ) * sliceStride + ( ( zz & 7u ) << 6 ) );
+            /* the slice's base is wave-uniform: kept in a scalar register pair (the empty asm stops the compiler from
+             * re-associating it into slotPtr + partial + slice offset, a 64-bit vector addition per slice), so that the
+             * load takes the scalar base + 32-bit lane offset form */
+            /* (and the lane's offset goes through it too, one value from slice to slice: it is widened to 64 bits after
+             * the asm, where the instruction selector can see that it is a 32-bit offset) */
+            asm volatile( "" : "+s"( zb ), "+v"( pl ) );
+            v[z] = *(lds_g_u32x4*)( (lds_g_u8*)zb + pl );
         }
     }
     between();
@@ -995,6 +1015,11 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
                     fx += take ? fdx : 0u;
                     fy += take ? fdy : 0u;
                     fz += take ? fdz : 0u;
+                    /* the positions advance by one addition per step: left alone the compiler turns the eight steps of an
+                     * unrolled group into p + k d with the multiples 2d .. 7d set up before every group loop -- eighteen
+                     * instructions per pass, six of them quarter-rate 32-bit multiplies, and as many registers */
+                    if( FAST )
+                        asm volatile( "" : "+v"( fx ), "+v"( fy ), "+v"( fz ) );
                     travel -= take ? lstep : 0.0f;
                     if( !FAST )
                         adv += take ? 1u : 0u;
@@ -1139,7 +1164,13 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
                             for( int c = 0; c < 8; ++c )
                             {
                                 const uint32_t idx = ax[c & 1] + ay[( c >> 1 ) & 1] + az[c >> 2];
-                                t[s][c] = (float)atlas[act[s] ? idx : 0u];
+                                /* scalar base + 32-bit lane offset form of the load: the offset goes through an empty asm
+                                 * so that the instruction selector sees a 32-bit value being widened (a select of
+                                 * 64-bit values otherwise: one 64-bit vector addition per gather) */
+                                typedef __attribute__( ( address_space( 1 ) ) ) const V lds_g_v;
+                                uint32_t off = act[s] ? idx : 0u;
+                                asm( "" : "+v"( off ) );
+                                t[s][c] = (float)( (lds_g_v*)atlas )[off];
                             }
                             wfx[s] = fx;
                             wfy[s] = fy;
