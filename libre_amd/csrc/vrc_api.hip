@@ -1115,10 +1115,11 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
      * float -> integer conversion (vrc_kernels_lds.hip: lds_classify): other weight widths use the gather form */
     /* 16-bit voxels: its trilinear form only (a 16-bit density does not index the classified table of the point form) */
     const bool ldsVoxels = pool->elemBytes == 1 || ( pool->elemBytes == 2 && linear );
-    const bool ldsEligible = c->cachedGridOk && !c->cachedClamp && ldsVoxels && !pool->bigAtlas &&
+    /* atlases of more than 2^32 voxels (64-bit slot bases): its trilinear form only */
+    const bool ldsEligible = c->cachedGridOk && !c->cachedClamp && ldsVoxels && ( !pool->bigAtlas || linear ) &&
                              ( !linear || c->optTfFracBits == 8 );
     if( !c->rayLod && c->optKernel == VRC_KERNEL_LDS && !ldsEligible )
-        return fail( VRC_EINVAL, "vrc_render: the LDS kernel needs a grid-aligned node set of 8-bit bricks (trilinear: 8- or 16-bit, VRC_OPT_TF_FRAC_BITS = 8) with overlap >= 1" );
+        return fail( VRC_EINVAL, "vrc_render: the LDS kernel needs a grid-aligned node set of 8-bit bricks in an atlas of at most 2^32 voxels (trilinear: 8- or 16-bit, any atlas, VRC_OPT_TF_FRAC_BITS = 8) with overlap >= 1" );
     /* per-ray LOD: the staged kernel's trilinear form only (samples classified one by one: no table per level) */
     const bool ldsLodEligible = c->rayLod && linear && !c->cachedClamp && ldsVoxels && !pool->bigAtlas &&
                                 c->optTfFracBits == 8;

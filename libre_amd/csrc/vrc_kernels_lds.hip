@@ -345,7 +345,8 @@ __device__ __forceinline__ float lds_trilerp( const float v[8], uint32_t fx, uin
  * no per-level table is needed): gridTable holds the per-level cell -> node tables, the walk is the hop of
  * vrc_ray_lod_hop, and a lane's step and opacity exponent are those of its brick's level */
 /* V: the voxel type of the atlas (uint16_t: trilinear only -- a 16-bit density does not index the classified table) */
-template < bool COUNT, bool LINEAR, bool GREY = false, bool RAYLOD = false, typename V = uint8_t >
+/* BIG: an atlas of more than 2^32 voxels -- a brick's slot base has 64 bits (trilinear only, like the 16-bit form) */
+template < bool COUNT, bool LINEAR, bool GREY = false, bool RAYLOD = false, typename V = uint8_t, bool BIG = false >
 /* four workgroups per CU: 4 x (4 regions of 8.25 KiB + the table) = 152 of the CU's 160 KiB */
 __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC16 : VRC_LDS_OCC ) void vrc_k_raycast_lds(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
@@ -363,6 +364,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
     __shared__ C lut[LINEAR ? 1u : VRC_TFP_ENTRIES];
     __shared__ __attribute__( ( aligned( 16 ) ) ) float4 tab[TAB_ENTRIES];
     static_assert( sizeof( V ) == 1 || LINEAR, "16-bit voxels are classified sample by sample" );
+    static_assert( !BIG || ( LINEAR && !RAYLOD ), "64-bit slot bases: the trilinear form only" );
     constexpr uint32_t ROWS = sizeof( V ) == 2 ? VRC_LDS_ROWS16 : VRC_LDS_ROWS;
     __shared__ __attribute__( ( aligned( 16 ) ) ) V regions[VRC_LDS_WAVES][VRC_LDS_PY * ROWS];
 
@@ -515,6 +517,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
     bool hasSeg = false, hasPend = false, walkDone = done;
     int32_t curNode = -1, pNode = -1;
     uint32_t pfx = 0, pfy = 0, pfz = 0, pfdx = 0, pfdy = 0, pfdz = 0, pSlotBase = 0;
+    [[maybe_unused]] uint32_t pSlotHi = 0, laneSlotHi = 0; /* BIG: the high halves of the slot bases */
     float pTravel = 0.0f;
     /* RAYLOD: 2^level of the current and of the next segment's brick (step and opacity exponent scale with it) */
     [[maybe_unused]] float lscale = 1.0f, pScale = 1.0f;
@@ -565,6 +568,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
                     travel = pTravel;
                     curNode = pNode;
                     laneSlotBase = pSlotBase;
+                    if constexpr( BIG )
+                        laneSlotHi = pSlotHi;
                     if constexpr( RAYLOD )
                         lscale = pScale;
                     hasSeg = true;
@@ -640,6 +645,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
                                 pTravel = s.dist;
                                 pNode = node;
                                 pSlotBase = n.slotBase;
+                                if constexpr( BIG )
+                                    pSlotHi = n.slotBaseHi;
                                 pScale = scale;
                                 hasPend = true;
                             }
@@ -744,6 +751,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
                                 pTravel = s.dist;
                                 pNode = node;
                                 pSlotBase = n.slotBase;
+                                if constexpr( BIG )
+                                    pSlotHi = n.slotBaseHi;
                                 hasPend = true;
                             }
                         }
@@ -783,7 +792,9 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
             const uint32_t lead = ( todoMask >> 15 ) & 1ull ? 15u
                                   : ( ( todoMask >> 48 ) & 1ull ? 48u : (uint32_t)__builtin_ctzll( todoMask ) );
             const int32_t brick = __builtin_amdgcn_readlane( curNode, lead );
-            const V* const slotPtr = atlas + (uint32_t)__builtin_amdgcn_readlane( (int)laneSlotBase, lead );
+            const V* slotPtr = atlas + (uint32_t)__builtin_amdgcn_readlane( (int)laneSlotBase, lead );
+            if constexpr( BIG )
+                slotPtr += (uint64_t)(uint32_t)__builtin_amdgcn_readlane( (int)laneSlotHi, lead ) << 32;
             constexpr uint32_t EXT = LINEAR ? 1u : 0u; /* the taps of a sample reach one voxel further */
 
             /* ---- the box: where the lanes ARE, extended along the march ------------------------------------
@@ -1158,7 +1169,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
                                 const uint32_t cx = ux + (uint32_t)i, cy = uy + (uint32_t)i, cz = uz + (uint32_t)i;
                                 ax[i] = vrc_mul24( cx >> VRC_MB_SHIFT, 504u ) + cx;
                                 ay[i] = vrc_mul24( cy >> VRC_MB_SHIFT, cyy ) + ( cy << 3 );
-                                az[i] = vrc_mul24( cz >> VRC_MB_SHIFT, czz ) + ( cz << 6 ) + laneSlotBase;
+                                az[i] = vrc_mul24( cz >> VRC_MB_SHIFT, czz ) + ( cz << 6 ) + ( BIG ? 0u : laneSlotBase );
                             }
 #pragma unroll
                             for( int c = 0; c < 8; ++c )
@@ -1170,7 +1181,10 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
                                 typedef __attribute__( ( address_space( 1 ) ) ) const V lds_g_v;
                                 uint32_t off = act[s] ? idx : 0u;
                                 asm( "" : "+v"( off ) );
-                                t[s][c] = (float)( (lds_g_v*)atlas )[off];
+                                if constexpr( BIG ) /* the lane's own slot: a 64-bit base per lane */
+                                    t[s][c] = (float)( (lds_g_v*)( atlas + ( ( (uint64_t)laneSlotHi << 32 ) | laneSlotBase ) ) )[off];
+                                else
+                                    t[s][c] = (float)( (lds_g_v*)atlas )[off];
                             }
                             wfx[s] = fx;
                             wfy[s] = fy;
@@ -1257,7 +1271,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
 
 namespace
 {
-template < bool LINEAR, bool RAYLOD, typename V >
+template < bool LINEAR, bool RAYLOD, typename V, bool BIG = false >
 hipError_t launch_lds( const vrc_raycast_args& a, hipStream_t stream )
 {
     const uint32_t tilesX = ( a.frame.width + 7u ) / 8u;
@@ -1267,11 +1281,11 @@ hipError_t launch_lds( const vrc_raycast_args& a, hipStream_t stream )
         block( 64u * VRC_LDS_WAVES );
     const bool count = a.sampleCounter != nullptr;
     /* the instance as rocprofv3 prints it (defaulted template arguments are printed too) */
-    vrc_internal_note_kernel( "vrc_k_raycast_lds<%s,%s,%s,%s,%s>", count ? "true" : "false", LINEAR ? "true" : "false",
+    vrc_internal_note_kernel( "vrc_k_raycast_lds<%s,%s,%s,%s,%s,%s>", count ? "true" : "false", LINEAR ? "true" : "false",
                               a.greyTable ? "true" : "false", RAYLOD ? "true" : "false",
-                              sizeof( V ) == 1 ? "unsigned char" : "unsigned short" );
+                              sizeof( V ) == 1 ? "unsigned char" : "unsigned short", BIG ? "true" : "false" );
 #define VRC_LDS_LAUNCH( COUNT, GREY )                                                                             \
-    hipLaunchKernelGGL( ( vrc_k_raycast_lds< COUNT, LINEAR, GREY, RAYLOD, V > ), grid, block, 0, stream, a.frame, \
+    hipLaunchKernelGGL( ( vrc_k_raycast_lds< COUNT, LINEAR, GREY, RAYLOD, V, BIG > ), grid, block, 0, stream, a.frame, \
                         a.nodes, a.gridTable, (const V*)a.atlas, a.lut, a.classifier, a.pixelBuffer,              \
                         a.sampleCounter, a.tileOrder, tilesX, nTiles )
     if( a.greyTable )
@@ -1293,13 +1307,17 @@ hipError_t vrc_launch_raycast_lds( const vrc_raycast_args& a, hipStream_t stream
         return hipSuccess;
     const bool rayLod = a.frame.lodLevels > 0u; /* set by the host for vrc_set_ray_lod frames only */
     /* point sampling reads the 257-entry classified table: 8-bit voxels, one level */
-    if( ( a.elemBytes != 1u && a.elemBytes != 2u ) || ( !a.linear && ( rayLod || a.elemBytes != 1u ) ) || a.bigAtlas || a.clamp ||
-        !a.gridTable )
+    /* atlases of more than 2^32 voxels: the trilinear form without per-ray LOD */
+    if( ( a.elemBytes != 1u && a.elemBytes != 2u ) || ( !a.linear && ( rayLod || a.elemBytes != 1u ) ) ||
+        ( a.bigAtlas && ( !a.linear || rayLod ) ) || a.clamp || !a.gridTable )
         return hipErrorInvalidValue;
     if( rayLod && ( a.frame.variant != VRC_VARIANT_CUDA || a.frame.lodLevels > VRC_MAX_LOD_LEVELS ) )
         return hipErrorInvalidValue;
     if( !a.linear )
         return launch_lds< false, false, uint8_t >( a, stream );
+    if( a.bigAtlas )
+        return a.elemBytes == 2u ? launch_lds< true, false, uint16_t, true >( a, stream )
+                                 : launch_lds< true, false, uint8_t, true >( a, stream );
     if( a.elemBytes == 2u )
         return rayLod ? launch_lds< true, true, uint16_t >( a, stream ) : launch_lds< true, false, uint16_t >( a, stream );
     return rayLod ? launch_lds< true, true, uint8_t >( a, stream ) : launch_lds< true, false, uint8_t >( a, stream );

@@ -183,7 +183,7 @@ def test_lds_staged_trilinear_uint16(vrc, case):
     want_lin, n_want_lin = orc.oracle_render(s, threads=16, filter_mode=1)
     with _gpu(s) as g:
         lin, n_lin, st = g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
-        assert st.kernel_variant == vrc.KERNEL_LDS and g.L.vrc_last_kernel().decode().endswith(",false,unsigned short>")
+        assert st.kernel_variant == vrc.KERNEL_LDS and g.L.vrc_last_kernel().decode().endswith(",false,unsigned short,false>")
         gat, n_gat, st = g.render(kernel=vrc.KERNEL_GRID_DDA, filter_mode=vrc.FILTER_TRILINEAR)
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
         vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 0))
@@ -219,7 +219,7 @@ def test_uint16_extension_parity(vrc, name):
             g.render(kernel=vrc.KERNEL_LDS)  # point sampling through LDS reads the classified table: 8-bit only
         # the trilinear filter is staged through LDS for 16-bit voxels too (what AUTO picks)
         staged, n_got, st = g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
-        assert st.kernel_variant == vrc.KERNEL_LDS and g.L.vrc_last_kernel().decode().endswith(",false,unsigned short>")
+        assert st.kernel_variant == vrc.KERNEL_LDS and g.L.vrc_last_kernel().decode().endswith(",false,unsigned short,false>")
         scenes.assert_parity(staged, want_lin, name + " trilinear, staged")
         assert abs(n_got - n_lin) <= 2e-4 * n_lin + 8
         auto, _, st = g.render(filter_mode=vrc.FILTER_TRILINEAR)
@@ -834,7 +834,7 @@ def test_ray_lod_trilinear_staged_through_lds(vrc, sse, tf):
     with _gpu(s) as g:
         staged, n_staged, st = g.render(ray_lod=lod, filter_mode=1)
         assert st.kernel_variant == vrc.KERNEL_RAY_LOD
-        assert _ran(g).startswith("vrc_k_raycast_lds<true,true,") and _ran(g).endswith(",true,%s>" % voxel), _ran(g)
+        assert _ran(g).startswith("vrc_k_raycast_lds<true,true,") and _ran(g).endswith(",true,%s,false>" % voxel), _ran(g)
         gathered, n_gathered, _ = g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_GRID_DDA)
         assert _ran(g).startswith("vrc_k_raycast_raylod<"), _ran(g)
         forced, _, _ = g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_LDS)
@@ -950,6 +950,7 @@ def test_atlas_of_more_than_2_pow_32_voxels(vrc):
     with _gpu(s) as g:
         want, n_want, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, stepping=0)
         want_lin, _, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, filter_mode=vrc.FILTER_TRILINEAR)
+        want_lds, n_lds, _ = g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
         want_ref, _, _ = g.render(kernel=vrc.KERNEL_REFERENCE_ORDER, stepping=0)
     L = vrc.load_library()
     ctx, pool = C.c_void_p(), C.c_void_p()
@@ -1013,12 +1014,17 @@ def test_atlas_of_more_than_2_pow_32_voxels(vrc):
         assert (got == want).all()
         got, st = frame(vrc.KERNEL_REFERENCE_ORDER, vrc.FILTER_NEAREST)
         assert (got == want_ref).all()
-        got, st = frame(vrc.KERNEL_AUTO, vrc.FILTER_TRILINEAR)  # LDS kernel not offered: gather form
+        got, st = frame(vrc.KERNEL_GRID_DDA, vrc.FILTER_TRILINEAR)  # the gather form
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
         assert np.abs(got - want_lin).max() <= 1e-6
+        # the trilinear filter is staged through LDS here too (64-bit slot bases): the frame of the small pool, bit for bit
+        got, st = frame(vrc.KERNEL_AUTO, vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_LDS and L.vrc_last_kernel().decode().endswith(",false,unsigned char,true>")
+        assert (got == want_lds).all() and st.samples == n_lds
         assert L.vrc_set_option(ctx, vrc.OPT_KERNEL, vrc.KERNEL_LDS) == 0
+        vrc.check(L, L.vrc_set_option(ctx, vrc.OPT_FILTER, vrc.FILTER_NEAREST))
         vrc.check(L, L.vrc_pre_render(ctx, view))
-        assert L.vrc_render(ctx, view, nodes, s.n_nodes, render, pool) != 0  # refused, loudly
+        assert L.vrc_render(ctx, view, nodes, s.n_nodes, render, pool) != 0  # its point-sampling form: refused, loudly
     finally:
         if pool:
             L.vrc_pool_destroy(pool)
