@@ -1260,6 +1260,22 @@ VRC_HD float vrc_trilerp( const float v[8], float wx, float wy, float wz )
     return c0 * uz + c1 * wz;
 }
 
+/* one voxel by its element index.  On the device the index goes through an empty asm and the pointer is typed as
+ * global memory: the load then takes the scalar base + 32-bit lane offset form where the base is wave-uniform and
+ * the voxels are bytes; written as atlas[valid ? e : 0u] the compiler widened a select of 64-bit values and spent a
+ * 64-bit vector addition per gather (eight per trilinear sample). */
+template < typename ATLAS_T >
+VRC_HD ATLAS_T vrc_gather( const ATLAS_T* __restrict__ atlas, uint32_t e )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+    typedef __attribute__( ( address_space( 1 ) ) ) const ATLAS_T g_t;
+    asm( "" : "+v"( e ) );
+    return ( (g_t*)atlas )[e];
+#else
+    return atlas[e];
+#endif
+}
+
 /* gather form of the trilinear march: eight byte gathers per sample, groups of
  * VRC_LGROUP samples, general branch-free form throughout (a sample the reference loop would
  * not reach reads element 0 and is blended with weight 0).  Sample positions follow the
@@ -1308,7 +1324,7 @@ VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n,
                 for( int c = 0; c < 8; ++c )
                 {
                     const uint32_t e = t[k].ax[c & 1] + t[k].ay[( c >> 1 ) & 1] + t[k].az[c >> 2];
-                    v[k][c] = (float)atlas[valid[k] ? e : 0u];
+                    v[k][c] = (float)vrc_gather( atlas, valid[k] ? e : 0u );
                 }
 #pragma unroll
             for( int k = 0; k < VRC_LGROUP; ++k )
@@ -1327,7 +1343,7 @@ VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n,
             vrc_group_indices< CLAMP, VRC_LGROUP >( sm, pos, s.step, idx );
 #pragma unroll
             for( int k = 0; k < VRC_LGROUP; ++k )
-                d[k] = (float)atlas[valid[k] ? idx[k] : 0u];
+                d[k] = (float)vrc_gather( atlas, valid[k] ? idx[k] : 0u );
         }
 #pragma unroll
         for( int k = 0; k < VRC_LGROUP; ++k )
