@@ -45,7 +45,7 @@
     defined( VRC_LDS_MAX_DZ ) || \
     defined( VRC_LDS_LBATCH ) || \
     defined( VRC_LDS_GBATCH ) || \
-    defined( VRC_LDS_G ) || \
+    defined( VRC_LDS_G ) || defined( VRC_LDS_GF ) || \
     defined( VRC_LDS_WAVES ) || \
     defined( VRC_LDS_REFILL ) || \
     defined( VRC_GROUP ) || \

@@ -105,6 +105,9 @@
 #ifndef VRC_LDS_G
 #define VRC_LDS_G 8
 #endif
+#ifndef VRC_LDS_GF
+#define VRC_LDS_GF VRC_LDS_G /* steps of one unrolled group of the march (developer builds: smaller groups with deeper boxes) */
+#endif
 #ifndef VRC_LDS_REFILL
 #define VRC_LDS_REFILL 8
 #endif
@@ -782,6 +785,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
             lc.kexp = lcls.kexp * lscale;
         bool inTodo = hasSeg;
         bool passEvents = false; /* wave-uniform: a lane crossed the early-exit threshold or ran out of steps in a pass */
+        [[maybe_unused]] uint32_t roundSteps = VRC_LDS_G; /* steps the left-over lanes take: as many as the box's lanes took */
         for( int pass = 0; pass < VRC_LDS_PASSES; ++pass )
         {
             const uint64_t todoMask = pass == 0 ? segMask : __builtin_amdgcn_ballot_w64( inTodo );
@@ -926,9 +930,9 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
 #if !defined( VRC_LDS_NO_STEP_CAP )
                 /* a level tile (its lanes within a step of each other) takes whole fast groups and leaves the odd
                  * step to the next pass: the general batches that would take it cost a third of a fast group */
-                if( nMax - nMin <= 1u && nMin >= VRC_LDS_G )
+                if( nMax - nMin <= 1u && nMin >= VRC_LDS_GF )
                 {
-                    nMax = nMin - nMin % VRC_LDS_G;
+                    nMax = nMin - nMin % VRC_LDS_GF;
                     nSteps = nSteps < nMax ? nSteps : nMax;
                 }
 #endif
@@ -967,6 +971,9 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
                     lds_stage< VRC_LDS_STAGE_N >( slotPtr, partial, sliceStride, box.z0 + h, box.dz - h, on, dst + h * pz, pz, []() {} );
                 }
             }
+#if VRC_LDS_GF != VRC_LDS_G
+            roundSteps = nMax > roundSteps ? nMax : roundSteps;
+#endif
             VRC_LDS_STAT( 0, 1 )
 #if defined( VRC_LDS_STATS )
             if( pass == 0 )
@@ -1068,15 +1075,15 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
             {
                 /* groups of VRC_LDS_G steps that every participating lane takes in full, unrolled ... */
                 uint32_t s0 = 0;
-                while( s0 + VRC_LDS_G <= nMin &&
-                       __builtin_amdgcn_ballot_w64( !( travel > lstep * (float)( VRC_LDS_G + 1 ) ) ) == 0ull )
+                while( s0 + VRC_LDS_GF <= nMin &&
+                       __builtin_amdgcn_ballot_w64( !( travel > lstep * (float)( VRC_LDS_GF + 1 ) ) ) == 0ull )
                 {
 #pragma unroll
-                    for( int b0 = 0; b0 < VRC_LDS_G; b0 += BATCH )
+                    for( int b0 = 0; b0 < VRC_LDS_GF; b0 += BATCH )
                         batch( std::true_type(), 0u );
-                    s0 += VRC_LDS_G;
-                    cnt += VRC_LDS_G;
-                    adv += VRC_LDS_G;
+                    s0 += VRC_LDS_GF;
+                    cnt += VRC_LDS_GF;
+                    adv += VRC_LDS_GF;
                 }
                 /* ... and the rest, batch by batch, each lane as far as it goes */
 #pragma unroll 1
@@ -1148,8 +1155,13 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
 #ifndef VRC_LDS_GBATCH
 #define VRC_LDS_GBATCH 2
 #endif
+#if VRC_LDS_GF != VRC_LDS_G
+#pragma unroll 1
+                for( uint32_t s0 = 0; s0 < roundSteps; s0 += VRC_LDS_GBATCH )
+#else
 #pragma unroll
                 for( int s0 = 0; s0 < VRC_LDS_G; s0 += VRC_LDS_GBATCH )
+#endif
                 {
                     bool act[VRC_LDS_GBATCH];
                     C e[VRC_LDS_GBATCH];
