@@ -38,7 +38,7 @@
     defined( VRC_LDS_STATS ) || \
     defined( VRC_LDS_TIMING ) || \
     defined( VRC_LDS_ABLATE_GATHER ) || \
-    defined( VRC_LDS_NO_STEP_CAP ) || \
+    defined( VRC_LDS_NO_STEP_CAP ) || defined( VRC_LDS_LOAD_ALL ) || \
     defined( VRC_LDS_PASSES ) || defined( VRC_LDS_ROWS ) || defined( VRC_LDS_OCC ) || defined( VRC_LDS_STAGE_N ) || \
     defined( VRC_LDS_ROWS16 ) || defined( VRC_LDS_OCC16 ) || defined( VRC_LDS_STAGE_N16 ) || \
     defined( VRC_LDS_KMAX ) || \

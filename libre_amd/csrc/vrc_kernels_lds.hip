@@ -224,8 +224,12 @@ __device__ __forceinline__ void lds_stage( const uint8_t* __restrict__ slotPtr, 
                                            uint8_t* dst, uint32_t pz, F between )
 {
     lds_u32x4 v[N];
+#if defined( VRC_LDS_LOAD_ALL ) /* developer build: lanes that stage nothing load too (the caller clamps their piece) */
+    {
+#else
     if( on )
     {
+#endif
         uint32_t pl = partial;
 #pragma unroll
         for( int z = 0; z < N; ++z )
@@ -533,6 +537,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
      * (one register: the trilinear form is short of them) */
     uint32_t walk = (uint32_t)( ( 0x7F68544032201000ull >> ( back * 8u ) ) & 0x7Fu );
     uint32_t fx = 0, fy = 0, fz = 0, fdx = 0, fdy = 0, fdz = 0; /* 8.24 slot-local voxel */
+    float rdx = 0.0f, rdy = 0.0f, rdz = 0.0f;                   /* 1 / |fd|: mag = 0 gives inf */
     float travel = 0.0f;
     uint32_t laneSlotBase = 0;
     uint32_t nSamples = 0;
@@ -568,6 +573,10 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
                 {
                     fx = pfx; fy = pfy; fz = pfz;
                     fdx = pfdx; fdy = pfdy; fdz = pfdz;
+                    /* 1 / |step| per axis for the step counts of a pass: once per segment, not once per pass */
+                    rdx = __builtin_amdgcn_rcpf( (float)(uint32_t)( (int32_t)fdx < 0 ? -(int32_t)fdx : (int32_t)fdx ) );
+                    rdy = __builtin_amdgcn_rcpf( (float)(uint32_t)( (int32_t)fdy < 0 ? -(int32_t)fdy : (int32_t)fdy ) );
+                    rdz = __builtin_amdgcn_rcpf( (float)(uint32_t)( (int32_t)fdz < 0 ? -(int32_t)fdz : (int32_t)fdz ) );
                     travel = pTravel;
                     curNode = pNode;
                     laneSlotBase = pSlotBase;
@@ -893,6 +902,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
                 const uint32_t lo[3] = { box.x0, box.y0, box.z0 };
                 const uint32_t hi[3] = { box.x0 + box.dx - 1u - EXT, box.y0 + box.dy - 1u - EXT, box.z0 + box.dz - 1u - EXT };
                 const uint32_t p[3] = { fx, fy, fz }, d[3] = { fdx, fdy, fdz };
+                const float rd[3] = { rdx, rdy, rdz };
                 float nf = (float)VRC_LDS_NMAX;
                 bool inside = cand;
 #pragma unroll
@@ -903,8 +913,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
                     const int32_t sd = (int32_t)d[a];
                     /* distance to the face the lane moves towards, in 2^-24 voxels; voxel hi is left at (hi+1) << 24 */
                     const uint32_t dist = sd < 0 ? p[a] - ( lo[a] << 24 ) : ( ( hi[a] + 1u ) << 24 ) - 1u - p[a];
-                    const uint32_t mag = (uint32_t)( sd < 0 ? -sd : sd );
-                    const float q = (float)dist * __builtin_amdgcn_rcpf( (float)mag ); /* mag = 0: inf */
+                    const float q = (float)dist * rd[a]; /* no movement along the axis: inf */
                     nf = fminf( nf, q );
                 }
                 uint32_t n = inside ? (uint32_t)nf + 1u : 0u; /* steps 0 .. floor(q) */
@@ -941,7 +950,12 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
             VRC_LDS_PHASE( 2 )
             /* ---- stage the box: atlas (micro-blocked) -> LDS (linear) --------------------- */
             {
+#if defined( VRC_LDS_LOAD_ALL )
+                const uint32_t x = box.x0 + ( sxr * 8u < box.dx ? sxr * 8u : box.dx - 8u ),
+                               y = box.y0 + ( syp * 2u < box.dy ? syp * 2u : box.dy - 2u );
+#else
                 const uint32_t x = box.x0 + sxr * 8u, y = box.y0 + syp * 2u;
+#endif
                 const bool on = sxr * 8u < box.dx && syp * 2u < box.dy;
                 const uint32_t partial =
                     ( ( y >> VRC_MB_SHIFT ) * f.sbx + ( x >> VRC_MB_SHIFT ) ) * VRC_MB_VOXELS +
