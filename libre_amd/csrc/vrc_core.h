@@ -35,7 +35,7 @@
     defined( VRC_ADDR_TABLES ) || \
     defined( VRC_TEST_BIAS_ENTRY ) || \
     defined( VRC_DEV_KNOBS ) || \
-    defined( VRC_LDS_STATS ) || \
+    defined( VRC_LDS_STATS ) || defined( VRC_LDS_STATS2 ) || \
     defined( VRC_LDS_TIMING ) || \
     defined( VRC_LDS_ABLATE_GATHER ) || \
     defined( VRC_LDS_NO_STEP_CAP ) || defined( VRC_LDS_LOAD_ALL ) || \

@@ -996,8 +996,10 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
                 const uint64_t m4_ = __builtin_amdgcn_ballot_w64( part );
                 VRC_LDS_STAT( 1, __builtin_popcountll( todoMask ) )
                 VRC_LDS_STAT( 4, __builtin_popcountll( m1_ ) )
+#if !defined( VRC_LDS_STATS2 )
                 VRC_LDS_STAT( 5, box.dy )
                 VRC_LDS_STAT( 6, box.dz )
+#endif
                 VRC_LDS_STAT( 7, __builtin_popcountll( m4_ ) )
             }
 #endif
@@ -1098,11 +1100,19 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
                     s0 += VRC_LDS_GF;
                     cnt += VRC_LDS_GF;
                     adv += VRC_LDS_GF;
+#if defined( VRC_LDS_STATS2 ) /* developer build: unrolled groups / general batches instead of the box shape */
+                    VRC_LDS_STAT( 5, 1 )
+#endif
                 }
                 /* ... and the rest, batch by batch, each lane as far as it goes */
 #pragma unroll 1
                 for( ; s0 < nMax; s0 += BATCH )
+                {
                     batch( std::false_type(), s0 );
+#if defined( VRC_LDS_STATS2 )
+                    VRC_LDS_STAT( 6, 1 )
+#endif
+                }
                 if( COUNT )
                     nSamples += cnt;
             }

@@ -42,6 +42,8 @@ with GpuScene(s) as g:
     r = max(passes, 1)  # one pass per round in the product build
     print("first pass of a round, lanes: with steps to take %.1f, in the lead's brick %.1f, in the box %.1f; "
           "mean box %.1f rows x %.1f slices" % (todo0 / r, brick0 / r, part0 / r, dy0 / r, dz0 / r))
+    if os.environ.get("VRC_STATS2"):  # -DVRC_LDS_STATS2: slots 5 and 6 count unrolled groups and general batches (as lane 0 saw them)
+        print("unrolled groups %d (%.2f per pass), general batches %d (%.2f per pass)" % (dy0, dy0 / r, dz0, dz0 / r))
     tot = float(sum(pout)) or 1.0
     names = ["walks", "box", "stage (incl. load wait)", "march", "ERT check/replay", "gather path", "round bookkeeping", "set-up/other"]
     print("wave cycles by phase: " + ", ".join("%s %.1f%%" % (nm, 100.0 * v / tot) for nm, v in zip(names, pout)))
