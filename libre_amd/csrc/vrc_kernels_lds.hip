@@ -77,7 +77,8 @@
  *   264 rows, 2 per CU, 11 per batch                            3.07 / 4.00
  *   132 rows, 4 per CU,  5 per batch                            2.80 / 4.44      (7 per batch: 3.02 / 4.69)
  *   192 rows, 3 per CU,  8 per batch                            2.76 / 3.77
- *   192 rows, 3 per CU, 11 per batch                            2.38 / 3.74   <- taken
+ *   192 rows, 3 per CU, 11 per batch                            2.38 / 3.74
+ *   192 rows, 3 per CU, 10 per batch (no register spills)       2.37 / 3.53   <- taken   (9 per batch: 2.56 / 3.59)
  * (8-bit voxels: 264 rows at 4 per CU, 1.95 / 2.6.)  Twice the bytes per voxel cost the staged form most of its
  * advantage: either the boxes or the number of waves that hide each other's staging latency shrink. */
 #ifndef VRC_LDS_ROWS16
@@ -87,7 +88,7 @@
 #define VRC_LDS_OCC16 3
 #endif
 #ifndef VRC_LDS_STAGE_N16
-#define VRC_LDS_STAGE_N16 11 /* slice loads (of two 16-byte pieces) in flight in one staging batch */
+#define VRC_LDS_STAGE_N16 10 /* slice loads (of two 16-byte pieces) in flight in one staging batch */
 #endif
 #define VRC_LDS_MAX_DY 32u /* 16 row pairs: one per staging lane group */
 #ifndef VRC_LDS_MAX_DZ
