@@ -1113,8 +1113,12 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
      * the trilinear filter (eight taps per sample), the gather kernel for point sampling. */
     /* its trilinear form takes the transfer-function texel and CUDA's 1.8 fixed-point lerp weight out of one
      * float -> integer conversion (vrc_kernels_lds.hip: lds_classify): other weight widths use the gather form */
+    /* slot-local positions in 8.24 fixed point (fixed-point stepping, the per-axis address tables, the LDS kernel's boxes)
+     * need every slot dimension to fit eight bits; pool creation bounds a slot's VOLUME only (2^24 voxels), so a flat
+     * or long brick can exceed it: such pools march with float positions */
+    const bool slotsFit8Bits = pool->slotDim[0] <= 248u && pool->slotDim[1] <= 248u && pool->slotDim[2] <= 248u;
     /* 16-bit voxels: its trilinear form only (a 16-bit density does not index the classified table of the point form) */
-    const bool ldsVoxels = pool->elemBytes == 1 || ( pool->elemBytes == 2 && linear );
+    const bool ldsVoxels = slotsFit8Bits && ( pool->elemBytes == 1 || ( pool->elemBytes == 2 && linear ) );
     /* atlases of more than 2^32 voxels (64-bit slot bases): its trilinear form only */
     const bool ldsEligible = c->cachedGridOk && !c->cachedClamp && ldsVoxels && ( !pool->bigAtlas || linear ) &&
                              ( !linear || c->optTfFracBits == 8 );
@@ -1221,7 +1225,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     a.sampleCounter = c->optCount ? c->dCounter : nullptr;
     a.clamp = c->cachedClamp;
     a.gridDda = useDda;
-    a.fixedStepping = c->optStepping != 0;
+    a.fixedStepping = c->optStepping != 0 && slotsFit8Bits;
     a.linear = linear;
     a.elemBytes = pool->elemBytes;
     a.bigAtlas = pool->bigAtlas;
@@ -1232,7 +1236,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
      * (iii) the table-driven point-sampling walk kernel. */
     a.depthSplit = false;
     if( c->optDepthSplit && useDda && !useLds && !c->rayLod && !linear && pool->elemBytes == 1 && !pool->bigAtlas &&
-        !c->cachedClamp && c->optStepping != 0 && f.clearFirst )
+        !c->cachedClamp && c->optStepping != 0 && slotsFit8Bits && f.clearFirst )
     {
         const double nMax = 1.7320508 * (double)render->samplesPerRay +
                             3.0 * ( f.gridDim[0] + f.gridDim[1] + f.gridDim[2] ) + 8.0;
@@ -1248,7 +1252,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     a.rayList = nullptr;
     /* (the same predicate as the launcher's, vrc_launch_raycast: what vrc_get_ray_counts reports is what ran) */
     if( c->optErtParts > 1 && !a.depthSplit && useDda && !useLds && !c->rayLod && !linear && pool->elemBytes == 1 &&
-        !pool->bigAtlas && !c->cachedClamp && c->optStepping != 0 && c->fbW < 65536u && c->fbH < 65536u &&
+        !pool->bigAtlas && !c->cachedClamp && c->optStepping != 0 && slotsFit8Bits && c->fbW < 65536u && c->fbH < 65536u &&
         VRC_TILE_W == 8u )
     {
         const size_t pixels = (size_t)c->fbW * c->fbH;

@@ -1031,6 +1031,67 @@ def test_atlas_of_more_than_2_pow_32_voxels(vrc):
         L.vrc_ctx_destroy(ctx)
 
 
+def test_slot_longer_than_255_voxels_marches_with_float_positions(vrc):
+    # pool creation bounds a slot's volume (2^24 voxels), not its edges: a 300 x 16 x 16 brick (overlap 1) has slot-local
+    # coordinates that do not fit the 8.24 fixed-point positions of VRC_OPT_STEPPING = 1, the address tables and the LDS
+    # kernel's boxes.  Such pools march with float positions whatever the option says (same frame, bit for bit), the
+    # trilinear filter takes the gather form and the LDS kernel is refused
+    s = orc.build_scene(voxels=(64, 64, 64), block=64, viewport=(128, 96), spin=(0.5, 0.3), alpha=0.3)  # camera only
+    rng = np.random.default_rng(77)
+    interior, ov = (300, 16, 16), 1
+    size = tuple(d + 2 * ov for d in interior)
+    brick = rng.integers(0, 256, size=(size[2], size[1], size[0]), dtype=np.uint8)
+    L = vrc.load_library()
+    ctx, pool = C.c_void_p(), C.c_void_p()
+    vrc.check(L, L.vrc_ctx_create(0, C.byref(ctx)))
+    try:
+        vrc.check(L, L.vrc_pool_create(ctx, 1, 0, 0, 1, vrc.u32x3(*size), 64 << 20, C.byref(pool)))
+        sb, ab, fs = C.c_size_t(), C.c_size_t(), C.c_uint32()
+        ad, sl = vrc.u32x3(), vrc.u32x3()
+        vrc.check(L, L.vrc_pool_info(pool, C.byref(sb), ad, C.byref(ab), sl, C.byref(fs)))
+        slot = vrc.f32x3()
+        vrc.check(L, L.vrc_pool_copy_to_slot(pool, brick.ctypes.data, vrc.u32x3(*size), slot))
+        node = (vrc.NodeData * 1)()
+        for a in range(3):
+            node[0].textureMin[a] = slot[a] + ov / ad[a]        # CudaTextureObject.cpp:61-84
+            node[0].textureSize[a] = interior[a] / ad[a]
+            node[0].aabbSize[a] = interior[a] / 300.0
+            node[0].aabbMin[a] = -0.5 * interior[a] / 300.0
+        view = C.cast(C.byref(s.view), C.POINTER(vrc.ViewData))
+        render = C.cast(C.byref(s.render), C.POINTER(vrc.RenderData))
+        vrc.check(L, L.vrc_update(ctx, s.tf.ctypes.data, None, 0))
+        vrc.check(L, L.vrc_set_option(ctx, vrc.OPT_COUNT_SAMPLES, 1))
+
+        def frame(kernel, flt, stepping):
+            vrc.check(L, L.vrc_set_option(ctx, vrc.OPT_KERNEL, kernel))
+            vrc.check(L, L.vrc_set_option(ctx, vrc.OPT_FILTER, flt))
+            vrc.check(L, L.vrc_set_option(ctx, vrc.OPT_STEPPING, stepping))
+            vrc.check(L, L.vrc_pre_render(ctx, view))
+            vrc.check(L, L.vrc_render(ctx, view, node, 1, render, pool))
+            fb = np.zeros((s.H, s.W, 4), dtype=np.float32)
+            vrc.check(L, L.vrc_post_render(ctx, fb.ctypes.data))
+            st = vrc.Stats()
+            vrc.check(L, L.vrc_get_stats(ctx, C.byref(st)))
+            return fb, st
+
+        for kernel in (vrc.KERNEL_REFERENCE_ORDER, vrc.KERNEL_GRID_DDA):
+            flt_frame, st0 = frame(kernel, vrc.FILTER_NEAREST, 0)
+            fix_frame, st1 = frame(kernel, vrc.FILTER_NEAREST, 1)
+            assert flt_frame[..., 3].max() > 0.2 and st0.samples > 2000
+            assert (fix_frame == flt_frame).all() and st1.samples == st0.samples, kernel
+        lin0, st = frame(vrc.KERNEL_AUTO, vrc.FILTER_TRILINEAR, 0)
+        assert st.kernel_variant == vrc.KERNEL_GRID_DDA  # not the LDS kernel
+        lin1, _ = frame(vrc.KERNEL_AUTO, vrc.FILTER_TRILINEAR, 1)
+        assert (lin1 == lin0).all()
+        assert L.vrc_set_option(ctx, vrc.OPT_KERNEL, vrc.KERNEL_LDS) == 0
+        vrc.check(L, L.vrc_pre_render(ctx, view))
+        assert L.vrc_render(ctx, view, node, 1, render, pool) != 0
+    finally:
+        if pool:
+            L.vrc_pool_destroy(pool)
+        L.vrc_ctx_destroy(ctx)
+
+
 def test_ray_lod_matches_the_committed_frames(vrc):
     # tests/golden/frames_ray_lod.npz: the per-ray LOD definition pinned between rounds (regular tree at two
     # error bounds, the ragged UVF fixture)
