@@ -44,6 +44,18 @@
  * Requires overlap >= 1 (no clamped sampler), slot dims <= 248, a grid-aligned node set and
  * the CUDA lerp-weight width (VRC_OPT_TF_FRAC_BITS = 8) for the trilinear form;
  * vrc_api.hip / the launcher fall back to the gather kernels otherwise.
+ *
+ * Forms of the trilinear kernel (template arguments): 16-bit voxels (V: rows of 64 bytes, three
+ * workgroups per CU), atlases of more than 2^32 voxels (BIG: 64-bit slot bases) and per-ray adaptive
+ * LOD (RAYLOD: the grid walk replaced by the hierarchy hop of vrc_pixel_ray_lod, step and opacity
+ * exponent per lane).  Point sampling through LDS exists for 8-bit voxels only (it reads the
+ * classified table) and is a measured alternative, not what AUTO picks.
+ *
+ * The kernel is bound by vector issue (profiles/r3_rocprofv3_lds_trilinear_summary.txt: ~120 wave
+ * instructions per 64-sample step, 60 of them the sample), so several constructs below are spelled
+ * for the instruction they compile to: DPP reductions with old = 0, loads through pointers typed
+ * address_space(1) behind an empty asm (scalar base + 32-bit lane offset), 24-bit multiplies,
+ * position updates kept as additions.
  */
 #include "vrc_internal.h"
 
