@@ -172,13 +172,24 @@ MAX_ABS_CAP = 6e-3
 # kernel, inside the per-pixel rule; such frames get the looser cap below, the budget-use and bias checks as is.
 MAX_ABS_CAP_OPAQUE = 3e-2
 OPAQUE_ALPHA = 0.2  # the fuzz draws 0.05, 0.3 or 1.0
+# What makes one flipped sample large is its classified opacity, 1 - (1 - alpha)^(maxSamplesPerRay / samplesPerRay)
+# (cuda/Renderer.cu:83-93): a nearly transparent transfer function marched in coarse steps is as "opaque" per sample as
+# alpha 0.3 at the default step.  The x40 soak of round 3 (seed 361: alpha 0.05, 97 samples per ray, the eye inside a
+# volume of 16^3 bricks) had a frame mean of 5.8e-4 with 93 % of its pixels over E0, pixel by pixel inside the rule and
+# the same frame from all three kernel forms: from inside the volume the ray parameters are small, the brick-entry
+# sample's side of the face hangs on the last rounding, and a multiply-add contracted on the device decides it the other
+# way in about half of the bricks.  The looser caps therefore go by the largest classified opacity of one sample:
+STRONG_SAMPLE = 1e-2  # alpha 0.05 at 512 samples per ray: 3.2e-3; alpha 0.3 at 512: 2.2e-2; alpha 0.05 at 97: 1.7e-2
 MEAN_ABS_CAP = 3e-4
 # (opaque transfer functions again: the same soak run, seed 29 of the uint16 fuzz -- alpha 0.3, 97 samples per ray,
 # the eye inside the volume -- had a frame mean of 5.6e-4 with 76 % of its pixels over E0, pixel by pixel inside the rule)
 MEAN_ABS_CAP_OPAQUE = 1.5e-3
-NEEDS_BUDGET_OPAQUE = 0.9
+NEEDS_BUDGET_OPAQUE = 0.95
 MEAN_E0 = 2e-5
-BUDGET_USE = 0.3
+# (x40 soak of round 3, seed 1056: 97 samples per ray through a 96-voxel volume seen 0.3 degrees off an axis -- the samples
+# march in step with the voxel grid and hover at voxel faces for long stretches; 0.306 of the budget, 54 % of the
+# pixels over E0, bias 0.24, the same frame from every kernel form.  A gross-error stop has to clear that.)
+BUDGET_USE = 0.5
 NEEDS_BUDGET = 0.7
 
 
@@ -204,7 +215,11 @@ def assert_parity(got, want, what="", budget=None, e0=E0, allow_frac=0.0, caps=T
         needs = float((d > e0).mean())
         problems = []
         scene = getattr(orc, "_LAST_SCENE", None)
-        opaque = scene is not None and float(np.asarray(scene.tf).reshape(-1, 4)[:, 3].max()) > OPAQUE_ALPHA
+        opaque = False
+        if scene is not None:
+            a_max = min(float(np.asarray(scene.tf).reshape(-1, 4)[:, 3].max()), 255.0 / 256.0)
+            k = float(scene.render.maxSamplesPerRay) / float(max(1, scene.render.samplesPerRay))
+            opaque = a_max > OPAQUE_ALPHA or 1.0 - (1.0 - a_max) ** k > STRONG_SAMPLE
         cap = MAX_ABS_CAP_OPAQUE if opaque else MAX_ABS_CAP
         if allow_frac == 0.0 and mx > cap:
             problems.append("max|d| %.3g > %.3g" % (mx, cap))
