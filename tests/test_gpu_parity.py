@@ -1112,6 +1112,32 @@ def test_ray_lod_matches_the_committed_frames(vrc):
         assert abs(n_got - n_want) <= 3e-4 * n_want + 16
 
 
+def test_ray_lod_trilinear_on_the_pinned_hierarchies(vrc):
+    # the hierarchies of tests/golden/frames_ray_lod.npz (a regular tree at two error bounds, the ragged UVF fixture
+    # whose levels do not align) with the trilinear filter: staged through LDS where the bricks have an overlap, by
+    # gathers otherwise, both against the oracle
+    import importlib.util
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden_ray_lod", os.path.join(gdir, "make_golden_ray_lod.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    staged_cases = 0
+    for name, s, sse in gen.cases():
+        lod = (sse, orc.world_space_per_pixel(s))
+        want, n_want = orc.oracle_render(s, threads=8, ray_lod=lod, filter_mode=1)
+        with _gpu(s) as g:
+            auto, n_auto, st = g.render(ray_lod=lod, filter_mode=1)
+            assert st.kernel_variant == vrc.KERNEL_RAY_LOD
+            staged = _ran(g).startswith("vrc_k_raycast_lds<")
+            staged_cases += staged
+            gathered, n_gathered, _ = g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_GRID_DDA)
+            assert _ran(g).startswith("vrc_k_raycast_raylod<")
+        _lod_parity(auto, want, name + " trilinear, " + ("staged" if staged else "gathers (AUTO)"))
+        _lod_parity(gathered, want, name + " trilinear, gathers")
+        assert abs(n_auto - n_want) <= 3e-4 * n_want + 16 and abs(n_gathered - n_want) <= 3e-4 * n_want + 16
+    assert staged_cases >= 1
+
+
 def test_more_bricks_than_the_reference_node_table_holds(vrc):
     # quirk Q8: the reference kernel's node table has 16384 entries and no bounds check (cuda/Renderer.cu:237,
     # 261-264); here the table is sized to the list: 32768 bricks of 8^3 voxels, both brick enumerations
