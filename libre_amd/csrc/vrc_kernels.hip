@@ -684,6 +684,7 @@ static hipError_t launch_split( const vrc_raycast_args& a, hipStream_t stream )
     const uint32_t tilesX = ( a.frame.width + 7u ) / 8u, tilesY = ( a.frame.height + 7u ) / 8u;
     if( tilesX * tilesY == 0 )
         return hipSuccess;
+    vrc_internal_note_kernel( "vrc_k_raycast_split<%s,%d>", COUNT ? "true" : "false", (int)GROUP );
     hipLaunchKernelGGL( ( vrc_k_raycast_split< COUNT, GROUP > ), dim3( vrc_schedule_slots( tilesX, tilesY ) / 4u ),
                         dim3( 512 ), 0, stream, a.frame, a.nodes, a.gridTable, (const uint8_t*)a.atlas, a.lut,
                         a.classifier, a.pixelBuffer, a.sampleCounter, a.tileOrder, tilesX, tilesX * tilesY,

@@ -1268,6 +1268,39 @@ def test_depth_split_composites_the_same_samples(vrc):
         assert n_split == n_want
 
 
+def test_depth_split_at_the_opacity_bound(vrc):
+    # the split is taken only where early ray termination cannot occur: (1 - largest classified alpha)^(most samples of
+    # a ray) above 1 - 0.999 with a margin of 0.01 in the logarithm (the kernel accumulates in float, round-2 advisor
+    # finding).  Transfer functions just inside the bound, between the bound with and without the margin, and just
+    # outside: the first renders with the split kernel (same samples), the other two with the plain kernel, bit for bit
+    import math
+    kw = dict(scenes.SCENES["hash64_spin"])
+    probe = orc.build_scene(**kw)
+    spr, grid = probe.render.samplesPerRay, 64 // 16
+    n_max = 1.7320508 * spr + 3.0 * (3 * grid) + 8.0
+
+    def alpha_at(log_bound):  # the transfer-function opacity whose classified alpha sits exactly at the bound
+        m = 1.0 - math.exp(log_bound / n_max)
+        return 1.0 - (1.0 - m) ** (spr / 32.0)
+
+    with_margin, without = alpha_at(math.log(1.0 - 0.999) + 0.01), alpha_at(math.log(1.0 - 0.999))
+    assert 0.05 < with_margin < without < 0.2
+    for alpha, split_expected in ((0.99 * with_margin, True), (0.5 * (with_margin + without), False), (1.01 * without, False)):
+        s = orc.build_scene(**dict(kw, alpha=alpha))
+        with _gpu(s) as g:
+            plain, n_plain, _ = g.render()
+            assert _ran(g).startswith("vrc_k_raycast<")
+            vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_DEPTH_SPLIT, 1))
+            frame, n_frame, _ = g.render()
+            assert _ran(g).startswith("vrc_k_raycast_split<") == split_expected, (alpha, _ran(g))
+            assert n_frame == n_plain
+            if split_expected:
+                assert np.abs(frame - plain).max() <= 2e-6
+                assert plain[..., 3].max() < 0.999  # no ray near the threshold: the bound is conservative
+            else:
+                assert (frame == plain).all()
+
+
 def _ray_counts(g):
     from libre_amd import vrc
     counts = (C.c_uint32 * 8)()
