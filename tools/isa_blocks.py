@@ -34,6 +34,10 @@ def main():
         if not s or s.startswith(";") or s.startswith("."):
             continue
         cur[1].append(s.split(";")[0].strip())
+        # a branch ends the basic block even where no label follows (the fall-through part gets the name + "'")
+        if cur[1][-1].split()[0].startswith(("s_cbranch", "s_branch", "s_endpgm")):
+            blocks.append(cur)
+            cur = [cur[0].rstrip("'") + "'", []]
     blocks.append(cur)
     tot = {}
     for name, ins in blocks:
