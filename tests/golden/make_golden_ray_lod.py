@@ -27,8 +27,12 @@ def main():
         fb, n = orc.oracle_render(s, threads=8, ray_lod=(sse, orc.world_space_per_pixel(s)))
         out[name] = fb.astype(np.float32)
         out[name + "__samples"] = np.array([n], dtype=np.uint64)
+        # the trilinear filter on the same hierarchies (round 3: the LDS-staged kernel renders these)
+        fb, n = orc.oracle_render(s, threads=8, ray_lod=(sse, orc.world_space_per_pixel(s)), filter_mode=1)
+        out[name + "__trilinear"] = fb.astype(np.float32)
+        out[name + "__trilinear_samples"] = np.array([n], dtype=np.uint64)
     np.savez_compressed(os.path.join(HERE, "frames_ray_lod.npz"), **out)
-    print("wrote", len(out) // 2, "frames")
+    print("wrote", len(out) // 2, "frames")  # (point-sampled and trilinear per case)
 
 
 if __name__ == "__main__":

@@ -1122,9 +1122,11 @@ def test_ray_lod_trilinear_on_the_pinned_hierarchies(vrc):
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
     staged_cases = 0
+    golden_lod = np.load(os.path.join(gdir, "frames_ray_lod.npz"))
     for name, s, sse in gen.cases():
         lod = (sse, orc.world_space_per_pixel(s))
         want, n_want = orc.oracle_render(s, threads=8, ray_lod=lod, filter_mode=1)
+        assert np.allclose(want, golden_lod[name + "__trilinear"], atol=1e-6) and n_want == int(golden_lod[name + "__trilinear_samples"][0])
         with _gpu(s) as g:
             auto, n_auto, st = g.render(ray_lod=lod, filter_mode=1)
             assert st.kernel_variant == vrc.KERNEL_RAY_LOD

@@ -244,5 +244,9 @@ def test_oracle_still_matches_the_committed_ray_lod_frames():
         assert np.allclose(fb, golden[name], atol=1e-6), name
         got, n_got, ok = orc.harness_render_ray_lod(s, lod, kernel=3)
         scenes.assert_parity(got, golden[name], name + " host build vs golden", budget=orc.budget_of(fb))
+        # ... and with the trilinear filter (the frames the LDS-staged kernel is held to on the GPU)
+        fb, n = orc.oracle_render(s, threads=8, ray_lod=lod, filter_mode=1)
+        assert n == int(golden[name + "__trilinear_samples"][0]), name
+        assert np.allclose(fb, golden[name + "__trilinear"], atol=1e-6), name
         n_cases += 1
     assert n_cases == 3
