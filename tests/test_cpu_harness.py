@@ -309,6 +309,33 @@ def test_glraycaster_supersampling_matches_its_oracle(name, spp):
     scenes.assert_parity(got1, want1, "%s gl spp 1" % name)
 
 
+def test_oracle_still_matches_the_committed_frames():
+    # tests/golden/frames.npz (tests/golden/make_golden.py): the oracle's frames of the named scenes -- the cudaRaycaster
+    # rules, the glRaycaster twin with and without its jittered supersampling, the trilinear filter -- pinned between
+    # rounds; runs without a GPU (tests/test_gpu_parity.py repeats the first part on the GPU box)
+    import importlib.util
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(gdir, "make_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    golden = np.load(os.path.join(gdir, "frames.npz"))
+    n_frames = 0
+    for name in sorted(scenes.SCENES):
+        fb, n = orc.oracle_render(scenes.get(name), threads=4)
+        assert n == int(golden[name + "__samples"][0]), name
+        assert np.allclose(fb, golden[name], atol=1e-6), name
+        n_frames += 1
+    fb, n = orc.oracle_render(scenes.nucleon_scene(), threads=4)
+    assert n == int(golden["nucleon__samples"][0]) and np.allclose(fb, golden["nucleon"], atol=1e-6)
+    for name, key, kw in gen.variants():
+        fb, n = orc.oracle_render(gen.variant_scene(name, kw), threads=4, **{k: v for k, v in kw.items() if k != "spp"})
+        assert n == int(golden[name + "__" + key + "_samples"][0]), (name, key)
+        assert np.allclose(fb, golden[name + "__" + key], atol=1e-6), (name, key)
+        n_frames += 1
+    assert 2 * (n_frames + 1) == len(golden.files)
+
+
 def test_the_two_reference_variants_differ():
     s = scenes.get("hash64_spin")
     cuda, _ = orc.oracle_render(s, threads=4)
