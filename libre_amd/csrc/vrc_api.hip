@@ -827,6 +827,9 @@ int vrc_pre_render( vrc_ctx* c, const vrc_view_data* view )
     const uint32_t h = c->rowMap.empty() ? view->glViewport[3] : (uint32_t)c->rowMap.size();
     if( w == 0 || h == 0 || view->glViewport[3] == 0 )
         return fail( VRC_EINVAL, "vrc_pre_render: empty viewport" );
+    /* pixels are indexed in 32 bits (y * width + x) */
+    if( (uint64_t)w * h > 0xFFFFFFFFull )
+        return fail( VRC_EINVAL, "vrc_pre_render: a pixel buffer of 2^32 pixels or more" );
     for( uint32_t r : c->rowMap )
         if( r >= view->glViewport[3] )
             return fail( VRC_EINVAL, "vrc_pre_render: row map entry outside the frame" );

@@ -228,6 +228,24 @@ def test_uint16_extension_parity(vrc, name):
         assert (uncounted == staged).all()
 
 
+def test_pixel_buffers_of_2_pow_32_pixels_are_refused(vrc):
+    # pixels are indexed in 32 bits; a 70000 x 70000 viewport (78 GB of RGBA32F would fit this GPU) is refused before
+    # anything is allocated
+    s = scenes.get("hash64_spin")
+    L = vrc.load_library()
+    ctx = C.c_void_p()
+    vrc.check(L, L.vrc_ctx_create(0, C.byref(ctx)))
+    try:
+        view = vrc.ViewData.from_buffer_copy(bytes(s.view))
+        view.glViewport[2], view.glViewport[3] = 70000, 70000
+        assert L.vrc_pre_render(ctx, C.byref(view)) != 0
+        assert b"2^32" in L.vrc_last_error()
+        view.glViewport[2], view.glViewport[3] = s.W, s.H
+        vrc.check(L, L.vrc_pre_render(ctx, C.byref(view)))
+    finally:
+        L.vrc_ctx_destroy(ctx)
+
+
 def test_unsupported_voxel_types_are_refused(vrc):
     L = vrc.load_library()
     ctx = C.c_void_p()
