@@ -47,7 +47,7 @@
     defined( VRC_LDS_GBATCH ) || \
     defined( VRC_LDS_G ) || defined( VRC_LDS_GF ) || \
     defined( VRC_LDS_WAVES ) || \
-    defined( VRC_LDS_REFILL ) || \
+    defined( VRC_LDS_REFILL ) || defined( VRC_LDS_SOON ) || \
     defined( VRC_GROUP ) || \
     defined( VRC_GREY_GROUP ) || \
     defined( VRC_GREY_PAD_KB ) || \

@@ -122,7 +122,14 @@
 #define VRC_LDS_GF VRC_LDS_G /* steps of one unrolled group of the march (developer builds: smaller groups with deeper boxes) */
 #endif
 #ifndef VRC_LDS_REFILL
-#define VRC_LDS_REFILL 8
+#define VRC_LDS_REFILL 64 /* lanes without a next segment that trigger a walk by their number alone: 64 = never -- a walk
+                           * runs when a lane is idle or about to need its next segment (measured on C2, ms per frame
+                           * along z / off axis, mem and noise: 8: 1.82 / 2.48, 1.87 / 2.58; 16: 1.80 / 2.54, 1.82 / 2.53;
+                           * 32: 1.77 / 2.42, 1.79 / 2.44; 64: 1.77 / 2.41, 1.78 / 2.43 -- the walk's ~220 instructions are
+                           * the whole wave's, so the fewer the better) */
+#endif
+#ifndef VRC_LDS_SOON
+#define VRC_LDS_SOON ( 2 * VRC_LDS_G ) /* a lane whose segment ends within this many steps needs its next one now */
 #endif
 #ifndef VRC_LDS_PASSES
 #define VRC_LDS_PASSES 1 /* boxes per round before the remaining lanes fall back to gathers (measured on C2, round 3: 1: 2.38 ms, 2: 2.61, 3: 2.81) */
@@ -614,7 +621,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
             const uint64_t lackMask = __builtin_amdgcn_ballot_w64( lack );
             const uint64_t idleMask = __builtin_amdgcn_ballot_w64( lack && !hasSeg );
             const uint64_t soonMask = __builtin_amdgcn_ballot_w64(
-                lack && hasSeg && !( travel > ( RAYLOD ? stepSize * lscale : stepSize ) * (float)( 2 * VRC_LDS_G ) ) );
+                lack && hasSeg && !( travel > ( RAYLOD ? stepSize * lscale : stepSize ) * (float)( VRC_LDS_SOON ) ) );
             refill = idleMask != 0ull || soonMask != 0ull || __builtin_popcountll( lackMask ) >= VRC_LDS_REFILL;
             anyLack = lackMask != 0ull;
             if( !refill )
