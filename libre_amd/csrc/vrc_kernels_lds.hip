@@ -51,7 +51,7 @@
  * exponent per lane).  Point sampling through LDS exists for 8-bit voxels only (it reads the
  * classified table) and is a measured alternative, not what AUTO picks.
  *
- * The kernel is bound by vector issue (profiles/r3_rocprofv3_lds_trilinear_summary.txt: ~120 wave
+ * The kernel is bound by vector issue (profiles/r3_rocprofv3_lds_trilinear_summary.txt: ~114 wave
  * instructions per 64-sample step, 60 of them the sample), so several constructs below are spelled
  * for the instruction they compile to: DPP reductions with old = 0, loads through pointers typed
  * address_space(1) behind an empty asm (scalar base + 32-bit lane offset), 24-bit multiplies,
