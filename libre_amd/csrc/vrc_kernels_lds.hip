@@ -583,9 +583,9 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
         if( roundBudget-- == 0u )
             break;
         /* A: walks.  A lane without a NEXT segment walks its DDA to the next brick it samples -- while it still marches
-         * its current one.  The walk (ray/box set-up, ~500 instructions) is shared by the wave, so walks are batched:
-         * one runs when VRC_LDS_REFILL lanes lack a next segment, when such a lane's current segment ends within the
-         * coming round, or when a lane has nothing to march at all. */
+         * its current one.  The walk (ray/box set-up, ~220 vector instructions) is the whole wave's, so walks are batched:
+         * one runs when a lane that lacks a next segment is within VRC_LDS_SOON steps of the end of its current one, or
+         * has nothing to march at all (and when VRC_LDS_REFILL lanes lack one: 64 = that trigger is off, see there). */
         auto promote = [&]() {
             if( !done && !hasSeg )
             {
