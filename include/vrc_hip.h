@@ -84,7 +84,7 @@ typedef struct
 } vrc_stats;
 
 /* ---- options (vrc_set_option) ---------------------------------------------------------- */
-#define VRC_OPT_KERNEL 1          /* VRC_KERNEL_AUTO (default) | _REFERENCE_ORDER | _GRID_DDA | _LDS */
+#define VRC_OPT_KERNEL 1          /* VRC_KERNEL_AUTO (default) | _REFERENCE_ORDER | _GRID_DDA | _LDS | _PACKED */
 #define VRC_OPT_FILTER 2          /* VRC_FILTER_NEAREST (reference parity, default) | VRC_FILTER_TRILINEAR */
 #define VRC_OPT_TF_FRAC_BITS 3    /* 8 (default, CUDA 1.8 fixed-point lerp weight) | 0 exact float */
 #define VRC_OPT_COUNT_SAMPLES 4   /* 0 (default) | 1: count composited samples (slower kernel) */
@@ -153,6 +153,15 @@ typedef struct
 #define VRC_KERNEL_GRID_DDA 2        /* 3-D DDA over the brick grid; needs a grid-aligned node set */
 #define VRC_KERNEL_LDS 3             /* grid DDA + voxels staged through LDS per wave and round (needs
                                       * overlap >= 1); what AUTO picks for the trilinear filter */
+#define VRC_KERNEL_PACKED 5          /* the trilinear filter through the pool's tap-packed atlas: a second atlas, 4.5 times
+                                      * the bytes, whose 32-bit texel at (x,y,z) holds the 2x2 neighbourhood across x,
+                                      * v[x,y,z] | v[x,y+1,z] << 8 | v[x,y,z+1] << 16 | v[x,y+1,z+1] << 24, laid out so that
+                                      * the texels at x and x + 1 are always neighbours in memory; allocated and filled on
+                                      * first use and kept up to date by every later upload: the eight taps of a sample
+                                      * are ONE 8-byte gather.  Needs VRC_FILTER_TRILINEAR, 8-bit bricks with overlap >= 1,
+                                      * an atlas of at most 2^32 voxels, VRC_OPT_TF_FRAC_BITS = 8, VRC_OPT_STEPPING = 1
+                                      * (VRC_EINVAL otherwise) and the device memory (VRC_ENOMEM).  Same sample
+                                      * positions, weights and arithmetic as the LDS-staged form */
 #define VRC_KERNEL_RAY_LOD 4         /* reported by vrc_get_stats when vrc_set_ray_lod is on; not selectable.  Under
                                       * per-ray LOD VRC_OPT_KERNEL chooses how the hierarchy walk takes its samples:
                                       * AUTO = staged through LDS for the trilinear filter on 8-bit bricks (overlap >= 1,
@@ -300,7 +309,7 @@ const char* vrc_last_error( void );
  * them), "" before the first: lets a benchmark check that a profile it quotes is a profile of what it ran */
 const char* vrc_last_kernel( void );
 /* ABI version of this header */
-#define VRC_ABI_VERSION 3 /* 3: vrc_gather_tiles takes the frame height */
+#define VRC_ABI_VERSION 4 /* 3: vrc_gather_tiles takes the frame height; 4: VRC_KERNEL_PACKED */
 /* = VRC_ABI_VERSION for the product build; -VRC_ABI_VERSION for a developer build of the library (compiled with
  * -DVRC_DEV_BUILD: experiment switches, statistics, ablations that render wrong pixels on purpose) */
 int vrc_abi_version( void );

@@ -56,6 +56,12 @@ struct vrc_pool
     size_t slotBytes = 0, atlasBytes = 0;
     void* dAtlas = nullptr;
     bool bigAtlas = false; /* more than 2^32 voxels */
+    /* tap-packed atlas of the trilinear filter (vrc_core.h): same slots, a 32-bit texel per voxel in blocks of 9 x 8 x 8.
+     * Allocated and filled from the byte atlas the first time a render asks for it (pool_enable_packed); from then
+     * on every upload packs its slot too.  Guarded by `mutex`. */
+    void* dPacked = nullptr;
+    bool packedOn = false;
+    bool packedFailed = false; /* the allocation was refused once: not tried again */
 
     std::mutex mutex; /* free list + staging ring index + upload event + render fences */
     /* slot position + "was in use before" flag: a released slot may still be read by a march
@@ -308,7 +314,7 @@ int vrc_set_option( vrc_ctx* c, int option, int64_t value )
     switch( option )
     {
     case VRC_OPT_KERNEL:
-        if( value < VRC_KERNEL_AUTO || value > VRC_KERNEL_LDS )
+        if( value < VRC_KERNEL_AUTO || ( value > VRC_KERNEL_LDS && value != VRC_KERNEL_PACKED ) )
             return fail( VRC_EINVAL, "vrc_set_option: bad kernel variant" );
         c->optKernel = value;
         return VRC_OK;
@@ -506,6 +512,7 @@ void vrc_pool_destroy( vrc_pool* p )
     for( auto& f : p->renderFences )
         (void)hipEventDestroy( f.event );
     if( p->uploadStream ) (void)hipStreamDestroy( p->uploadStream );
+    if( p->dPacked ) (void)hipFree( p->dPacked );
     if( p->dAtlas ) (void)hipFree( p->dAtlas );
     delete p;
 }
@@ -601,17 +608,23 @@ static int pool_upload( vrc_pool* p, const void* src, bool srcIsDevice, const ui
             const uint64_t base = vrc_slot_base( lay, o[0] / p->slotDim[0], o[1] / p->slotDim[1],
                                                  o[2] / p->slotDim[2] );
             uint8_t* const slotPtr = (uint8_t*)p->dAtlas + (size_t)base * p->elemBytes;
-            e = vrc_launch_repack_brick( devSrc, slotPtr, p->elemBytes, size, p->slotDim, p->uploadStream );
-        }
-        if( e == hipSuccess )
-            e = hipEventRecord( st.done, p->uploadStream );
-        st.used = true;
-        if( e == hipSuccess )
-        {
+            /* the writes of one upload are queued as a unit (pool_enable_packed packs every slot written before it
+             * was called; every upload after it packs its own) */
             std::lock_guard< std::mutex > lock( p->mutex );
-            e = hipEventRecord( p->lastUpload, p->uploadStream );
-            p->hasUpload = true;
+            e = vrc_launch_repack_brick( devSrc, slotPtr, p->elemBytes, size, p->slotDim, p->uploadStream );
+            if( e == hipSuccess && p->packedOn )
+                e = vrc_launch_pack_slots( p->dAtlas, p->dPacked, base,
+                                           (uint64_t)p->slotDim[0] * p->slotDim[1] * p->slotDim[2], p->slotDim,
+                                           p->uploadStream );
+            if( e == hipSuccess )
+                e = hipEventRecord( st.done, p->uploadStream );
+            if( e == hipSuccess )
+            {
+                e = hipEventRecord( p->lastUpload, p->uploadStream );
+                p->hasUpload = true;
+            }
         }
+        st.used = true;
     }
     if( e != hipSuccess )
     {
@@ -630,6 +643,51 @@ static int pool_upload( vrc_pool* p, const void* src, bool srcIsDevice, const ui
     slotOut[1] = slot[1];
     slotOut[2] = slot[2];
     return VRC_OK;
+}
+
+/* The tap-packed atlas of the trilinear filter, on first use: 4.5 times the byte atlas, filled from it on the upload
+ * stream behind every upload queued so far.  false (and no error) when the pool cannot have one: 16-bit voxels, more
+ * than 2^32 voxels, or not enough device memory (tried once). */
+static bool pool_packed_possible( const vrc_pool* p )
+{
+    return p->elemBytes == 1 && !p->bigAtlas && VRC_LAYOUT == 0;
+}
+static bool pool_enable_packed( vrc_pool* p )
+{
+    std::lock_guard< std::mutex > lock( p->mutex );
+    if( p->packedOn )
+        return true;
+    if( p->packedFailed || !pool_packed_possible( p ) )
+        return false;
+    const size_t bytes = (size_t)vrc_packed_elems( p->atlasBytes ) * 4u;
+    size_t freeMem = 0, totalMem = 0;
+    hipError_t e = hipMemGetInfo( &freeMem, &totalMem );
+    /* leave a margin for the caller's frame buffers and staging */
+    if( e == hipSuccess && bytes + ( 256u << 20 ) > freeMem )
+        e = hipErrorOutOfMemory;
+    if( e == hipSuccess )
+        e = hipMalloc( &p->dPacked, bytes );
+    if( e == hipSuccess )
+        e = vrc_launch_pack_slots( p->dAtlas, p->dPacked, 0u, p->atlasBytes, p->slotDim, p->uploadStream );
+    if( e == hipSuccess )
+    {
+        e = hipEventRecord( p->lastUpload, p->uploadStream );
+        p->hasUpload = true;
+    }
+    if( e != hipSuccess )
+    {
+        (void)hipGetLastError();
+        if( p->dPacked )
+        {
+            (void)hipStreamSynchronize( p->uploadStream );
+            (void)hipFree( p->dPacked );
+        }
+        p->dPacked = nullptr;
+        p->packedFailed = true;
+        return false;
+    }
+    p->packedOn = true;
+    return true;
 }
 
 int vrc_pool_copy_to_slot( vrc_pool* p, const void* hostBrick, const uint32_t size[3],
@@ -1132,8 +1190,23 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
                                 c->optTfFracBits == 8;
     if( c->rayLod && c->optKernel == VRC_KERNEL_LDS && !ldsLodEligible )
         return fail( VRC_EINVAL, "vrc_render: under per-ray LOD the LDS kernel needs the trilinear filter, 8- or 16-bit bricks with overlap >= 1 and VRC_OPT_TF_FRAC_BITS = 8" );
+    /* tap-packed atlas (VRC_KERNEL_PACKED; vrc_core.h): the trilinear filter as two dword gathers per sample.  Needs what
+     * its positions and its classifier need -- 8-bit bricks with overlap >= 1 in slots of at most 248 voxels a side, an
+     * atlas of at most 2^32 voxels, VRC_OPT_TF_FRAC_BITS = 8 -- and 4.5 times the atlas in device memory; either brick
+     * enumeration (grid walk where the node set is grid-aligned, else the reference-order loop) */
+    const bool packedEligible = linear && !c->rayLod && !glSuper && !c->cachedClamp && slotsFit8Bits &&
+                                pool_packed_possible( pool ) && c->optTfFracBits == 8 && c->optStepping != 0;
+    bool usePacked = false;
+    if( c->optKernel == VRC_KERNEL_PACKED )
+    {
+        if( !packedEligible )
+            return fail( VRC_EINVAL, "vrc_render: the packed kernel needs the trilinear filter on 8-bit bricks with overlap >= 1 (slots of at most 248 voxels a side, an atlas of at most 2^32 voxels), VRC_OPT_TF_FRAC_BITS = 8, fixed-point stepping, no per-ray LOD" );
+        if( !pool_enable_packed( pool ) )
+            return fail( VRC_ENOMEM, "vrc_render: no device memory for the tap-packed atlas (4.5 times the brick atlas)" );
+        usePacked = true;
+    }
     const bool useLds = c->rayLod ? ( ldsLodEligible && c->optKernel != VRC_KERNEL_GRID_DDA )
-                                  : !glSuper && ( c->optKernel == VRC_KERNEL_LDS ||
+                                  : !glSuper && !usePacked && ( c->optKernel == VRC_KERNEL_LDS ||
                                                   ( c->optKernel == VRC_KERNEL_AUTO && linear && ldsEligible ) );
 
     vrc_raycast_args a;
@@ -1222,7 +1295,8 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
 
     a.nodes = c->dNodes;
     a.gridTable = ( useDda || c->rayLod ) ? c->dGrid : nullptr;
-    a.atlas = pool->dAtlas;
+    a.atlas = usePacked ? pool->dPacked : pool->dAtlas;
+    a.packed = usePacked;
     a.lut = c->dLut;
     a.pixelBuffer = ctx_fb( c );
     a.sampleCounter = c->optCount ? c->dCounter : nullptr;
@@ -1338,6 +1412,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     c->stats.kernel_variant =
         c->rayLod ? VRC_KERNEL_RAY_LOD
         : useLds  ? VRC_KERNEL_LDS
+        : usePacked ? VRC_KERNEL_PACKED
                   : ( useDda ? VRC_KERNEL_GRID_DDA : VRC_KERNEL_REFERENCE_ORDER );
     for( int i = 0; i < 3; ++i )
         c->stats.grid_dims[i] = ( useDda || c->rayLod ) ? (uint32_t)f.gridDim[i] : 0u;

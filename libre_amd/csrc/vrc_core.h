@@ -53,6 +53,7 @@
     defined( VRC_GREY_PAD_KB ) || \
     defined( VRC_TAIL_GROUP ) || \
     defined( VRC_LGROUP ) || \
+    defined( VRC_PGROUP ) || defined( VRC_PACKED_WAVES ) || defined( VRC_PACKED_ABLATE ) || \
     defined( VRC_SPLIT_GROUP ) || \
     defined( VRC_SMALL_GROUP ) || \
     defined( VRC_SMALL_LAUNCH_TILES ) || \
@@ -1360,6 +1361,316 @@ VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n,
 }
 
 /* ------------------------------------------------------------------------------------------
+ * EXTENSION, tap-packed form of the trilinear filter (round 4).  The filter the north star names is one sampler
+ * enum in the reference (cuda/TexturePool.cu:163-170, cudaFilterModePoint -> Linear) and free in its hardware; here
+ * the eight taps were eight byte gathers (above) or a staged box in LDS (vrc_kernels_lds.hip), both bound by the
+ * instructions and cache look-ups around the sample while HBM idles.  This form spends memory instead: next to the
+ * byte atlas the pool keeps a second atlas whose 32-bit texel at (x,y,z) holds the 2x2 neighbourhood ACROSS x,
+ *     T(x,y,z) = v[x,y,z] | v[x,y+1,z] << 8 | v[x,y,z+1] << 16 | v[x,y+1,z+1] << 24,
+ * and in which T(x,y,z) and T(x+1,y,z) are ALWAYS neighbours in memory: the texels lie in blocks of 8x8x8 whose
+ * x-rows carry a ninth texel, a copy of the next block's first (9/8 x 4 = 4.5 times the bytes of the byte atlas;
+ * written by vrc_k_pack_slots when a brick is uploaded; the slot's overlap >= 1 supplies the +1 neighbours).  The
+ * eight taps of a sample are then ONE 8-byte gather -- global_load_dwordx2 at a 4-byte-aligned address, T(x0,y0,z0)
+ * and T(x0+1,y0,z0) -- eight byte -> float conversions straight out of the two registers and the seven
+ * interpolations: no box, no staging, no walk batching, the same work for every view direction, and a quarter of
+ * the vector-L1 tag look-ups of eight byte gathers (the unit that bounds every gather form of this kernel: a
+ * look-up per 64-byte line per quad of lanes).
+ *
+ * Sample positions, weights, interpolation and classification are the staged kernel's, operation for operation
+ * (8.24 fixed-point positions from vrc_fixpos_init minus half a voxel, 24-bit weights used unscaled, x then y then
+ * z, the transfer function through CUDA's 1.8 fixed-point weight out of one float -> integer conversion), so the
+ * two forms composite the same numbers.
+ * ---------------------------------------------------------------------------------------- */
+/* slot-local element order of the packed atlas: offset = PX(x) + PY(y) + PZ(z) with blocks of 9 x 8 x 8 texels
+ * (x fastest, blocks x-fastest inside the slot); position 8 of a row holds the texel at 8 * (block + 1), clamped to
+ * the slot's last column.  Slots are 9/8 of the byte atlas's slots, in the same order. */
+#define VRC_PK_ROW 9u
+#define VRC_PK_SLICE ( VRC_PK_ROW * VRC_MB )
+#define VRC_PK_BLOCK ( VRC_PK_SLICE * VRC_MB ) /* 576 texels */
+VRC_HD uint32_t vrc_pk_x( uint32_t u ) { return ( u & 7u ) + VRC_PK_BLOCK * ( u >> 3 ); }
+VRC_HD uint32_t vrc_pk_y( uint32_t u, uint32_t sbx ) { return VRC_PK_ROW * ( u & 7u ) + VRC_PK_BLOCK * sbx * ( u >> 3 ); }
+VRC_HD uint32_t vrc_pk_z( uint32_t u, uint32_t sbx, uint32_t sby ) { return VRC_PK_SLICE * ( u & 7u ) + VRC_PK_BLOCK * sbx * sby * ( u >> 3 ); }
+VRC_HD uint32_t vrc_packed_local_index( uint32_t x, uint32_t y, uint32_t z, uint32_t sbx, uint32_t sby )
+{
+    return vrc_pk_x( x ) + vrc_pk_y( y, sbx ) + vrc_pk_z( z, sbx, sby );
+}
+/* texels of a packed slot / element offset of the packed slot that belongs to the byte slot at element slotBase
+ * (byte slots are whole blocks of 512) */
+VRC_HD uint64_t vrc_packed_elems( uint64_t byteElems ) { return byteElems / VRC_MB_VOXELS * VRC_PK_BLOCK; }
+
+VRC_HD uint32_t vrc_pack_taps( uint32_t v00, uint32_t v10, uint32_t v01, uint32_t v11 )
+{
+    /* (y0,z0), (y1,z0), (y0,z1), (y1,z1) at one x */
+    return v00 | ( v10 << 8 ) | ( v01 << 16 ) | ( v11 << 24 );
+}
+
+/* classifier of a trilinear sample that arrives scaled by 2^72 (three unscaled 24-bit weights): the oracle's
+ * orc_tf_fetch + composite (cuda/ColorMap.cu:40-45, cuda/Renderer.cu:83-93) with the transfer-function texel pair
+ * and CUDA's 1.8 fixed-point lerp weight taken out of ONE float -> integer conversion: tq = xB * 256 + 256.5 with
+ * xB = u * 256 - 0.5 the texel coordinate; texel pair (tq >> 8, + 1) of the padded table, weight (tq & 255) / 256
+ * rounded to nearest as the hardware does.  VRC_OPT_TF_FRAC_BITS = 8 only. */
+struct vrc_cls8
+{
+    float mult, add, kexp;
+};
+VRC_HD vrc_cls8 vrc_make_cls8( const vrc_classifier& c )
+{
+    vrc_cls8 k;
+    k.mult = c.mult * 256.0f * 0x1p-72f;
+    k.add = c.add * 256.0f + 256.5f;
+    k.kexp = c.alphaCorrection;
+    return k;
+}
+/* entries of the classifier's table: per texel j of the padded transfer function tfp (VRC_TFP_ENTRIES entries)
+ * (colour_j, 1 - alpha_j) / 256 -- the weights are used as integers 0..256 -- one texel more than tfp has: a
+ * sample at the upper clamp reads the pair (257, 258) with weights (256, 0).  Grey transfer function: texels j and
+ * j + 1 side by side, (g_j, 1 - a_j, g_j+1, 1 - a_j+1) / 256, one 16-byte read per sample. */
+#define VRC_CLS8_ENTRIES ( VRC_TFP_ENTRIES + 1u )
+VRC_HD vrc_f4 vrc_cls8_entry( const vrc_f4* tfp, uint32_t i, bool grey )
+{
+    const float sc = 1.0f / 256.0f;
+    const vrc_f4 e0 = tfp[i < VRC_TFP_ENTRIES - 1u ? i : VRC_TFP_ENTRIES - 1u];
+    const vrc_f4 e1 = tfp[i + 1u < VRC_TFP_ENTRIES - 1u ? i + 1u : VRC_TFP_ENTRIES - 1u];
+    vrc_f4 t;
+    if( grey )
+    {
+        t.x = e0.x * sc; t.y = ( 1.0f - e0.w ) * sc; t.z = e1.x * sc; t.w = ( 1.0f - e1.w ) * sc;
+    }
+    else
+    {
+        t.x = e0.x * sc; t.y = e0.y * sc; t.z = e0.z * sc; t.w = ( 1.0f - e0.w ) * sc;
+    }
+    return t;
+}
+VRC_HD float vrc_alpha8( float corr, float kexp )
+{
+    /* 1 - min(a, 255/256) = max(1 - a, 1/256) (Renderer.cu:88); pow as exp2(k log2 x) on the device */
+    corr = fmaxf( corr, 1.0f / 256.0f );
+#if defined( __HIP_DEVICE_COMPILE__ )
+    return 1.0f - __builtin_amdgcn_exp2f( kexp * __builtin_amdgcn_logf( corr ) );
+#else
+    return 1.0f - powf( corr, kexp );
+#endif
+}
+VRC_HD uint32_t vrc_cls8_texel( float d, const vrc_cls8& k )
+{
+    float tq = __builtin_fmaf( d, k.mult, k.add );
+#if defined( __HIP_DEVICE_COMPILE__ )
+    tq = __builtin_amdgcn_fmed3f( tq, 0.5f, 65792.25f );
+#else
+    tq = fminf( fmaxf( tq, 0.5f ), 65792.25f );
+#endif
+    return (uint32_t)tq;
+}
+VRC_HD vrc_f2 vrc_classify8( const vrc_f2*, const vrc_f4* tab, float d, const vrc_cls8& k )
+{
+    const uint32_t u = vrc_cls8_texel( d, k );
+    const float a = (float)( u & 255u ), b = 256.0f - a;
+    const vrc_f4 t = *reinterpret_cast< const vrc_f4* >( reinterpret_cast< const char* >( tab ) + ( ( u >> 4 ) & 0xFFFF0u ) );
+    const float alpha = vrc_alpha8( __builtin_fmaf( a, t.w, b * t.y ), k.kexp );
+    vrc_f2 e;
+    e.x = __builtin_fmaf( a, t.z, b * t.x ) * alpha;
+    e.w = alpha;
+    return e;
+}
+VRC_HD vrc_f4 vrc_classify8( const vrc_f4*, const vrc_f4* tab, float d, const vrc_cls8& k )
+{
+    const uint32_t u = vrc_cls8_texel( d, k );
+    const float a = (float)( u & 255u ), b = 256.0f - a;
+    const vrc_f4* const p = reinterpret_cast< const vrc_f4* >( reinterpret_cast< const char* >( tab ) + ( ( u >> 4 ) & 0xFFFF0u ) );
+    const vrc_f4 t0 = p[0], t1 = p[1];
+    const float alpha = vrc_alpha8( __builtin_fmaf( a, t1.w, b * t0.w ), k.kexp );
+    vrc_f4 e;
+    e.x = __builtin_fmaf( a, t1.x, b * t0.x ) * alpha;
+    e.y = __builtin_fmaf( a, t1.y, b * t0.y ) * alpha;
+    e.z = __builtin_fmaf( a, t1.z, b * t0.z ) * alpha;
+    e.w = alpha;
+    return e;
+}
+
+/* the interpolated density of a sample, times 2^72: texels T0 = T(x0,y0,z0) and T1 = T(x0+1,y0,z0), weights = the 24
+ * fraction bits of the sample's 8.24 coordinates, NOT scaled by 2^-24 -- W and 2^24 - W are exact, so every product
+ * and sum is 2^24 (2^48, 2^72) times the one with scaled weights, bit for bit; vrc_cls8.mult carries the 2^-72.
+ * The oracle's order: x, then y, then z; a * (1 - w) + b * w. */
+VRC_HD float vrc_trilerp_packed( uint32_t T0, uint32_t T1, uint32_t fx, uint32_t fy, uint32_t fz )
+{
+    const float wx = (float)( fx & 0xFFFFFFu ), wy = (float)( fy & 0xFFFFFFu ), wz = (float)( fz & 0xFFFFFFu );
+    const float ux = 16777216.0f - wx, uy = 16777216.0f - wy, uz = 16777216.0f - wz;
+    const float c00 = __builtin_fmaf( (float)( T1 & 255u ), wx, (float)( T0 & 255u ) * ux );                  /* y0 z0 */
+    const float c10 = __builtin_fmaf( (float)( ( T1 >> 8 ) & 255u ), wx, (float)( ( T0 >> 8 ) & 255u ) * ux );   /* y1 z0 */
+    const float c01 = __builtin_fmaf( (float)( ( T1 >> 16 ) & 255u ), wx, (float)( ( T0 >> 16 ) & 255u ) * ux ); /* y0 z1 */
+    const float c11 = __builtin_fmaf( (float)( T1 >> 24 ), wx, (float)( T0 >> 24 ) * ux );                    /* y1 z1 */
+    const float c0 = __builtin_fmaf( c10, wy, c00 * uy );
+    const float c1 = __builtin_fmaf( c11, wy, c01 * uy );
+    return __builtin_fmaf( c1, wz, c0 * uz );
+}
+
+/* texel pair at a byte offset of the lane's packed slot: one 8-byte load at a 4-byte-aligned address.  On the
+ * device the pointer is typed as global memory and as a two-dword vector of 4-byte alignment, so the compiler emits
+ * one global_load_dwordx2 (multi-dword loads need dword alignment only). */
+struct vrc_texel_pair
+{
+    uint32_t t0, t1;
+};
+VRC_HD vrc_texel_pair vrc_packed_load( const uint8_t* slot, uint32_t byteOffset )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+    typedef uint32_t u32x2_a4 __attribute__( ( ext_vector_type( 2 ), aligned( 4 ) ) );
+    typedef __attribute__( ( address_space( 1 ) ) ) const u32x2_a4 g_t;
+    const u32x2_a4 v = *reinterpret_cast< g_t* >( (uintptr_t)( slot + byteOffset ) );
+    return vrc_texel_pair{ v.x, v.y };
+#else
+    const uint32_t* const p = reinterpret_cast< const uint32_t* >( slot + byteOffset );
+    return vrc_texel_pair{ p[0], p[1] };
+#endif
+}
+
+/* byte offsets (slot-local) of the texel pairs of the next N samples; p advances by N steps.  Device: the per-axis
+ * parts from the tables in LDS (filled by the kernel with 4 * vrc_pk_x / y / z). */
+template < int N >
+VRC_HD void vrc_packed_offsets( const vrc_sampler& s, vrc_fixpos& p, uint32_t* off )
+{
+#if defined( __HIP_DEVICE_COMPILE__ ) && defined( VRC_ADDR_TABLES )
+    (void)s;
+#pragma unroll
+    for( int k = 0; k < N; ++k )
+    {
+        const char* const t = reinterpret_cast< const char* >( vrc_addr_tab );
+        const uint32_t tx = *reinterpret_cast< const uint32_t* >( t + ( ( p.x >> 22 ) & 0x3FCu ) );
+        const uint32_t ty = *reinterpret_cast< const uint32_t* >( t + 1024 + ( ( p.y >> 22 ) & 0x3FCu ) );
+        const uint32_t tz = *reinterpret_cast< const uint32_t* >( t + 2048 + ( ( p.z >> 22 ) & 0x3FCu ) );
+        off[k] = tx + ty + tz;
+        p.x += p.dx;
+        p.y += p.dy;
+        p.z += p.dz;
+        asm( "" : "+v"( p.x ), "+v"( p.y ), "+v"( p.z ) ); /* keep the additions (vrc_group_indices_fixed) */
+    }
+#else
+    const uint32_t sbx = ( s.cyy + 64u ) / VRC_MB_VOXELS, sby = ( s.czz + 512u ) / ( sbx * VRC_MB_VOXELS );
+#pragma unroll
+    for( int k = 0; k < N; ++k )
+    {
+        off[k] = 4u * vrc_packed_local_index( p.x >> 24, p.y >> 24, p.z >> 24, sbx, sby );
+        p.x += p.dx;
+        p.y += p.dy;
+        p.z += p.dz;
+    }
+#endif
+}
+
+#ifndef VRC_PGROUP
+#define VRC_PGROUP 4
+#endif
+
+/* March one brick segment through the packed atlas (Renderer.cu:206-223 with the trilinear fetch).  Organised as
+ * vrc_march_segment_as: whole groups without per-sample tests while more than GROUP steps remain, the early-exit
+ * test once per group with an exact replay, a general tail.  tab: vrc_cls8_entry table.  E: vrc_f4, or vrc_f2
+ * for a grey transfer function (vrc_raycast_args.greyTable). */
+template < bool COUNT, int GROUP, typename E >
+VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n, vrc_segment s,
+                                      const uint32_t* __restrict__ packed, const vrc_f4* tab, const vrc_cls8& kc,
+                                      E& color, uint32_t& nSamples, float levelStep )
+{
+    const float stepSize = levelStep > 0.0f ? levelStep : f.stepSize;
+    float travel = s.dist;
+    if( !( travel > 0.0f ) )
+        return false;
+    const vrc_sampler sm = vrc_make_sampler( n, f );
+    /* the lane's packed slot: 9/8 of the byte slot's element offset, 4 bytes per texel (64 bits: a packed atlas passes
+     * 4 GiB at a byte atlas of 0.9 Gi voxels) */
+    const uint8_t* const slot = reinterpret_cast< const uint8_t* >( packed ) + vrc_packed_elems( n.slotBase ) * 4u;
+    vrc_fixpos fp = vrc_fixpos_init( sm, s.pos, s.step );
+    /* texel centres at i + 0.5: the integer part of (coordinate - 0.5) is the lower tap, its fraction the weight */
+    fp.x -= 1u << 23;
+    fp.y -= 1u << 23;
+    fp.z -= 1u << 23;
+    bool done = false;
+    const float guard = stepSize * (float)( GROUP + 1 );
+    while( travel > guard )
+    {
+        uint32_t off[GROUP];
+        vrc_texel_pair t[GROUP];
+        vrc_fixpos q = fp; /* the group's first sample: the weights are taken again from here after the loads */
+        vrc_packed_offsets< GROUP >( sm, fp, off );
+#pragma unroll
+        for( int k = 0; k < GROUP; ++k )
+        {
+#if defined( VRC_PACKED_ABLATE ) /* timing experiment only: no fetch */
+            t[k] = vrc_texel_pair{ off[k] * 0x01010101u, off[k] * 0x00010101u };
+#else
+            t[k] = vrc_packed_load( slot, off[k] );
+#endif
+        }
+#pragma unroll
+        for( int k = 0; k < GROUP; ++k )
+            travel -= stepSize; /* same sequential subtraction as the reference */
+        E e[GROUP];
+#pragma unroll
+        for( int k = 0; k < GROUP; ++k )
+        {
+            e[k] = vrc_classify8( (const E*)nullptr, tab, vrc_trilerp_packed( t[k].t0, t[k].t1, q.x, q.y, q.z ), kc );
+            q.x += q.dx;
+            q.y += q.dy;
+            q.z += q.dz;
+        }
+        const E saved = color;
+#pragma unroll
+        for( int k = 0; k < GROUP; ++k )
+            vrc_composite( color, e[k] );
+        if( COUNT )
+            nSamples += GROUP;
+        if( color.w > VRC_EARLY_EXIT )
+        {
+            /* crossed inside this group: replay it with the reference's per-sample exit */
+            color = saved;
+            if( COUNT )
+                nSamples -= GROUP;
+#pragma unroll
+            for( int k = 0; k < GROUP; ++k )
+            {
+                vrc_composite( color, e[k], done );
+                if( COUNT )
+                    nSamples += done ? 0u : 1u;
+                done = done || ( color.w > VRC_EARLY_EXIT );
+            }
+            return true;
+        }
+    }
+    constexpr int TAILG = GROUP >= 4 ? GROUP / 2 : 1;
+    while( travel > 0.0f && !done )
+    {
+        uint32_t off[TAILG], cnt = 0;
+        vrc_texel_pair t[TAILG];
+        vrc_fixpos q = fp;
+        vrc_packed_offsets< TAILG >( sm, fp, off );
+#pragma unroll
+        for( int k = 0; k < TAILG; ++k )
+        {
+            const bool v = travel > 0.0f;
+            cnt += v ? 1u : 0u;
+            /* a step the reference does not take reads the slot's first texels and blends nothing */
+            t[k] = vrc_packed_load( slot, v ? off[k] : 0u );
+            travel -= stepSize;
+        }
+#pragma unroll
+        for( int k = 0; k < TAILG; ++k )
+        {
+            const E z = {};
+            const E c = vrc_classify8( (const E*)nullptr, tab, vrc_trilerp_packed( t[k].t0, t[k].t1, q.x, q.y, q.z ), kc );
+            const bool active = ( (uint32_t)k < cnt ) && !done;
+            vrc_composite( color, (uint32_t)k < cnt ? c : z, done );
+            if( COUNT )
+                nSamples += active ? 1u : 0u;
+            done = done || ( color.w > VRC_EARLY_EXIT );
+            q.x += q.dx;
+            q.y += q.dy;
+            q.z += q.dz;
+        }
+    }
+    return done;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Reference-order pixel: the O(nodeCount) loop of Renderer.cu:172-227, nodes in host order.
  * ---------------------------------------------------------------------------------------- */
 /* MODE: how a sample is fetched and classified.
@@ -1373,6 +1684,9 @@ VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n,
 #define VRC_MODE_TABLE 0
 #define VRC_MODE_TRILINEAR 1
 #define VRC_MODE_POINT 2
+#define VRC_MODE_PACKED 5      /* trilinear through the tap-packed atlas (vrc_march_segment_packed): ATLAS_T = uint32_t,
+                                * lut = the vrc_cls8_entry table */
+#define VRC_MODE_PACKED_GREY 6 /* the same for a grey transfer function: (grey, alpha) colours, paired table entries */
 
 /* BIG: the atlas holds more than 2^32 voxels.  Offsets inside a slot stay 32-bit; the slot's
  * 64-bit base moves into the lane's atlas pointer (one 64-bit add per gather instead of a 32-bit
@@ -1391,7 +1705,22 @@ VRC_HD bool vrc_march_brick( const vrc_frame& f, const vrc_dev_node& n, const vr
         return vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, false >( f, local, s, slot, lut, cls,
                                                                                 color, nSamples, levelStep );
     }
-    if constexpr( MODE == VRC_MODE_GREY )
+    if constexpr( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY )
+    {
+        static_assert( sizeof( ATLAS_T ) == 4 && !CLAMP && !BIG, "the packed atlas: 32-bit texels, overlap >= 1, 32-bit slot bases" );
+        const vrc_cls8 kc = vrc_make_cls8( cls );
+        if constexpr( MODE == VRC_MODE_PACKED_GREY )
+        {
+            vrc_f2 c = { color.x, color.w };
+            const bool done = vrc_march_segment_packed< COUNT, GROUP, vrc_f2 >( f, n, s, atlas, lut, kc, c, nSamples, levelStep );
+            color.x = color.y = color.z = c.x;
+            color.w = c.w;
+            return done;
+        }
+        else
+            return vrc_march_segment_packed< COUNT, GROUP, vrc_f4 >( f, n, s, atlas, lut, kc, color, nSamples, levelStep );
+    }
+    else if constexpr( MODE == VRC_MODE_GREY )
         return vrc_march_segment< CLAMP, COUNT, FIXED, ATLAS_T, GROUP, true >( f, n, s, atlas, lut, color, nSamples,
                                                                              levelStep );
     else if constexpr( MODE == VRC_MODE_POINT_GREY )

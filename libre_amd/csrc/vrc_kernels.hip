@@ -280,6 +280,49 @@ hipError_t vrc_launch_read_region( const void* atlas, void* dst, uint32_t elemBy
     return hipGetLastError();
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * tap-packed atlas (vrc_core.h, "tap-packed form of the trilinear filter"): texel (x,y,z) of a slot =
+ * v[x,y,z] | v[x,y+1,z] << 8 | v[x,y,z+1] << 16 | v[x,y+1,z+1] << 24 of the byte slot, in blocks of 9 x 8 x 8 texels
+ * whose ninth column repeats the next block's first (neighbours and the copy clamped at the slot's last voxel: never
+ * read with a weight -- a sample's lower tap is at most slotDim - 2 with overlap >= 1).  One thread per packed texel,
+ * coalesced 4-byte stores; the byte reads hit L1/L2.
+ * ---------------------------------------------------------------------------------------- */
+__global__ __launch_bounds__( 256 ) void vrc_k_pack_slots( const uint8_t* __restrict__ atlas, uint32_t* __restrict__ packed,
+                                                           uint64_t firstBlock, uint64_t nBlocks, uint32_t slotBlocks,
+                                                           uint32_t sdx, uint32_t sdy, uint32_t sdz, uint32_t sbx, uint32_t sby )
+{
+    const uint64_t n = nBlocks * VRC_PK_BLOCK;
+    for( uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x )
+    {
+        const uint64_t blk = firstBlock + i / VRC_PK_BLOCK; /* block of the atlas = block of its slot, slots in order */
+        const uint32_t in = (uint32_t)( i % VRC_PK_BLOCK );
+        const uint64_t slotIndex = blk / slotBlocks;
+        const uint32_t b = (uint32_t)( blk - slotIndex * slotBlocks );
+        const uint32_t ix = in % VRC_PK_ROW, iy = ( in / VRC_PK_ROW ) & 7u, iz = in / VRC_PK_SLICE;
+        uint32_t x = ( b % sbx ) * 8u + ix;
+        const uint32_t y = ( ( b / sbx ) % sby ) * 8u + iy, z = ( b / ( sbx * sby ) ) * 8u + iz;
+        x = x < sdx ? x : sdx - 1u;
+        const uint32_t y1 = y + 1u < sdy ? y + 1u : y, z1 = z + 1u < sdz ? z + 1u : z;
+        const uint8_t* const slot = atlas + slotIndex * ( (uint64_t)slotBlocks * VRC_MB_VOXELS );
+        packed[blk * VRC_PK_BLOCK + in] =
+            vrc_pack_taps( slot[vrc_slot_local_index( x, y, z, sbx, sby )], slot[vrc_slot_local_index( x, y1, z, sbx, sby )],
+                           slot[vrc_slot_local_index( x, y, z1, sbx, sby )], slot[vrc_slot_local_index( x, y1, z1, sbx, sby )] );
+    }
+}
+
+hipError_t vrc_launch_pack_slots( const void* atlas, void* packed, uint64_t firstElem, uint64_t nElems,
+                                  const uint32_t slotDim[3], hipStream_t stream )
+{
+    if( nElems == 0 )
+        return hipSuccess;
+    const uint32_t slotBlocks = ( slotDim[0] >> VRC_MB_SHIFT ) * ( slotDim[1] >> VRC_MB_SHIFT ) * ( slotDim[2] >> VRC_MB_SHIFT );
+    hipLaunchKernelGGL( vrc_k_pack_slots, dim3( grid_for( (size_t)( nElems / VRC_MB_VOXELS * VRC_PK_BLOCK ), 256 ) ), dim3( 256 ),
+                        0, stream, (const uint8_t*)atlas, (uint32_t*)packed, firstElem / VRC_MB_VOXELS, nElems / VRC_MB_VOXELS,
+                        slotBlocks, slotDim[0], slotDim[1], slotDim[2], slotDim[0] >> VRC_MB_SHIFT, slotDim[1] >> VRC_MB_SHIFT );
+    return hipGetLastError();
+}
+
 /* ------------------------------------------------------------------------------------------
  * tile schedule: order the 8x8 tiles by estimated work, heaviest first: cost = chord of the
  * tile-centre ray through the (clipped) volume box, counting sort over 256 cost buckets in
@@ -421,7 +464,11 @@ template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLA
 /* waves per SIMD: 5 for the table-driven point-sampling instances (48 VGPRs); the per-sample classification modes,
  * the float position chain, the clamped sampler and 64-bit slot bases need more registers than 5 waves leave (they
  * spilled at 5: the trilinear gather form ran 5.3 instead of 2.9 ms) */
-__global__ __launch_bounds__( VRC_WG_THREADS, GROUP > VRC_GREY_GROUP ? 2
+#ifndef VRC_PACKED_WAVES
+#define VRC_PACKED_WAVES 4
+#endif
+__global__ __launch_bounds__( VRC_WG_THREADS, ( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY ) ? VRC_PACKED_WAVES
+                                              : GROUP > VRC_GREY_GROUP ? 2
                                               : ( ( ( MODE == VRC_MODE_TABLE && GROUP <= 8 ) || MODE == VRC_MODE_GREY ) && FIXED && !CLAMP && !BIG
                                                       ? VRC_MIN_WAVES
                                                       : ( GROUP > 8 ? 2 : 4 ) ) ) void vrc_k_raycast(
@@ -433,11 +480,17 @@ __global__ __launch_bounds__( VRC_WG_THREADS, GROUP > VRC_GREY_GROUP ? 2
 {
     /* classified table (257 entries) or, for the per-sample classification modes, the padded
      * transfer function (258) */
-    __shared__ vrc_f4 lut[VRC_TFP_ENTRIES];
+    __shared__ vrc_f4 lut[VRC_CLS8_ENTRIES];
     __shared__ uint16_t vrc_tile_cand[DDA ? 1u : VRC_WAVES_PER_WG * VRC_TILE_CANDIDATES];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
-    if( MODE == VRC_MODE_GREY || MODE == VRC_MODE_POINT_GREY )
+    if( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY )
+    {
+        /* the packed march's classifier table (vrc_cls8_entry) from the padded transfer function */
+        for( uint32_t i = tid; i < VRC_CLS8_ENTRIES; i += VRC_WG_THREADS )
+            lut[i] = vrc_cls8_entry( lutGlobal, i, MODE == VRC_MODE_PACKED_GREY );
+    }
+    else if( MODE == VRC_MODE_GREY || MODE == VRC_MODE_POINT_GREY )
     {
         /* grey table: (rgb * alpha', alpha') as two floats per entry, 257 entries -- or, for the per-sample
          * classification of 16-bit voxels, the 258 entries of the padded transfer function as (grey, alpha) */
@@ -458,7 +511,17 @@ __global__ __launch_bounds__( VRC_WG_THREADS, GROUP > VRC_GREY_GROUP ? 2
             lut[256u + tid] = lutGlobal[256u + tid];
     }
 #if defined( VRC_ADDR_TABLES )
-    if( FIXED )
+    if( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY )
+    {
+        /* per-axis BYTE offsets of the packed atlas's texels (vrc_core.h: vrc_pk_x / y / z) */
+        for( uint32_t u = tid; u < 256u; u += VRC_WG_THREADS )
+        {
+            vrc_addr_tab[u] = 4u * vrc_pk_x( u );
+            vrc_addr_tab[256u + u] = 4u * vrc_pk_y( u, f.sbx );
+            vrc_addr_tab[512u + u] = 4u * vrc_pk_z( u, f.sbx, f.sby );
+        }
+    }
+    else if( FIXED )
     {
         const vrc_lay lay = vrc_make_lay( f.sbx, f.sby );
 #pragma unroll
@@ -582,7 +645,8 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
         ( MODE == VRC_MODE_GREY && GROUP <= VRC_GREY_GROUP && VRC_WAVES_PER_WG == 4u ) ? VRC_GREY_PAD_KB * 1024u : 0u;
     vrc_internal_note_kernel( "vrc_k_raycast<%s,%s,%s,%s,%d,%s,%d,%s>", DDA ? "true" : "false", CLAMP ? "true" : "false",
                               COUNT ? "true" : "false", FIXED ? "true" : "false", (int)MODE,
-                              sizeof( ATLAS_T ) == 1 ? "unsigned char" : "unsigned short", (int)GROUP, BIG ? "true" : "false" );
+                              sizeof( ATLAS_T ) == 1 ? "unsigned char" : ( sizeof( ATLAS_T ) == 2 ? "unsigned short" : "unsigned int" ),
+                              (int)GROUP, BIG ? "true" : "false" );
     hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG > ),
                         dim3( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_WAVES_PER_WG - 1u ) / VRC_WAVES_PER_WG ),
                         dim3( VRC_WG_THREADS ), ldsPad, stream, a.frame, a.nodes, a.gridTable,
@@ -926,9 +990,28 @@ static hipError_t launch_big( const vrc_raycast_args& a, bool count, hipStream_t
     }
 }
 
+/* trilinear through the tap-packed atlas (a.atlas = the packed atlas; the host offers it for 8-bit bricks with
+ * overlap >= 1, slots of at most 248 voxels a side, atlases of at most 2^32 voxels, VRC_OPT_TF_FRAC_BITS = 8) */
+template < int MODE >
+static hipError_t launch_packed( const vrc_raycast_args& a, bool count, hipStream_t stream )
+{
+    if( a.gridDda )
+        return count ? launch_variant< true, false, true, true, MODE, uint32_t, VRC_PGROUP >( a, stream )
+                     : launch_variant< true, false, false, true, MODE, uint32_t, VRC_PGROUP >( a, stream );
+    return count ? launch_variant< false, false, true, true, MODE, uint32_t, VRC_PGROUP >( a, stream )
+                 : launch_variant< false, false, false, true, MODE, uint32_t, VRC_PGROUP >( a, stream );
+}
+
 hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
 {
     const bool count = a.sampleCounter != nullptr;
+    if( a.packed )
+    {
+        if( !a.linear || a.elemBytes != 1 || a.bigAtlas || a.clamp )
+            return hipErrorInvalidValue;
+        return a.greyTable ? launch_packed< VRC_MODE_PACKED_GREY >( a, count, stream )
+                           : launch_packed< VRC_MODE_PACKED >( a, count, stream );
+    }
     if( a.bigAtlas )
     {
         if( a.elemBytes == 2 )

@@ -13,7 +13,9 @@ VRC_OK, VRC_EINVAL, VRC_EHIP, VRC_EFULL, VRC_ENOMEM, VRC_EUNSUPPORTED, VRC_EHIER
 OPT_KERNEL, OPT_FILTER, OPT_TF_FRAC_BITS, OPT_COUNT_SAMPLES, OPT_TILE_ORDER, OPT_STEPPING, OPT_VARIANT, OPT_KERNEL_USED, OPT_KERNEL_TIMING, OPT_DEPTH_SPLIT, OPT_ERT_COMPACTION, OPT_GREY_TABLE = range(1, 13)
 VARIANT_CUDARAYCASTER, VARIANT_GLRAYCASTER = 0, 1
 FILTER_NEAREST, FILTER_TRILINEAR = 0, 1
-KERNEL_AUTO, KERNEL_REFERENCE_ORDER, KERNEL_GRID_DDA, KERNEL_LDS, KERNEL_RAY_LOD = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_REFERENCE_ORDER, KERNEL_GRID_DDA, KERNEL_LDS, KERNEL_RAY_LOD, KERNEL_PACKED = 0, 1, 2, 3, 4, 5
+
+ABI_VERSION = 4  # VRC_ABI_VERSION of include/vrc_hip.h this binding was written against
 
 f32x3 = C.c_float * 3
 u32x3 = C.c_uint32 * 3
@@ -85,6 +87,10 @@ def load_library(path=None):
     L.vrc_abi_version.restype = C.c_int
     L.vrc_is_dev_build.restype = C.c_int
     L.vrc_last_kernel.restype = C.c_char_p
+    # a developer build (-DVRC_DEV_BUILD) reports the negated version
+    if abs(L.vrc_abi_version()) != ABI_VERSION:
+        raise RuntimeError("%s has ABI version %d, this binding needs %d: rebuild it (__graft_entry__.build())"
+                           % (p, L.vrc_abi_version(), ABI_VERSION))
     L.vrc_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.vrc_ctx_destroy.argtypes = [vp]
     L.vrc_ctx_destroy.restype = None

@@ -100,8 +100,42 @@ static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3]
 
     /* kernel: 1 reference order, 2 grid DDA, 3/4 the same with fixed-point stepping (u8 only),
      * 5/6 the same with the trilinear filter, 7/8 point sampling with per-sample
-     * classification (the only point-sampling form for 16-bit voxels) */
-    const bool dda = !rayLod && ( kernel == 2 || kernel == 4 || kernel == 6 || kernel == 8 );
+     * classification (the only point-sampling form for 16-bit voxels), 9/10 the trilinear filter through the
+     * tap-packed atlas (u8, overlap >= 1, fracBits 8), 11/12 the same with the (grey, alpha) colours of a grey
+     * transfer function */
+    const bool dda = !rayLod && ( kernel == 2 || kernel == 4 || kernel == 6 || kernel == 8 || kernel == 10 || kernel == 12 );
+    const bool packedKernel = kernel >= 9 && kernel <= 12;
+    if( packedKernel && ( rayLod || voxelBytes != 1 || t.clamp || fracBits != 8 ) )
+        return 5;
+    /* the tap-packed atlas as vrc_k_pack_slots writes it: blocks of 9 x 8 x 8 texels, the ninth column a copy of the
+     * next block's first, neighbours and the copy clamped at the slot's last voxel */
+    std::vector< uint32_t > packed( packedKernel ? (size_t)vrc_packed_elems( nVoxels ) : 0 );
+    if( packedKernel )
+    {
+        const uint32_t sbx = slotDim[0] / 8u, sby = slotDim[1] / 8u;
+        const uint64_t slotVoxels = (uint64_t)slotDim[0] * slotDim[1] * slotDim[2];
+        for( uint32_t k = 0; k < geom.slots[2]; ++k )
+            for( uint32_t j = 0; j < geom.slots[1]; ++j )
+                for( uint32_t i = 0; i < geom.slots[0]; ++i )
+                {
+                    const uint64_t base = vrc_slot_base( lay, i, j, k ); /* of the byte slot */
+                    const uint8_t* const slot = atlas.data() + base;
+                    uint32_t* const out = packed.data() + vrc_packed_elems( base );
+                    (void)slotVoxels;
+                    for( uint32_t z = 0; z < slotDim[2]; ++z )
+                        for( uint32_t y = 0; y < slotDim[1]; ++y )
+                            for( uint32_t bx = 0; bx < sbx; ++bx )
+                                for( uint32_t ix = 0; ix < 9u; ++ix )
+                                {
+                                    uint32_t x = bx * 8u + ix;
+                                    x = x < slotDim[0] ? x : slotDim[0] - 1u;
+                                    const uint32_t y1 = y + 1u < slotDim[1] ? y + 1u : y, z1 = z + 1u < slotDim[2] ? z + 1u : z;
+                                    out[vrc_packed_local_index( bx * 8u, y, z, sbx, sby ) + ix] =
+                                        vrc_pack_taps( slot[vrc_slot_local_index( x, y, z, sbx, sby )], slot[vrc_slot_local_index( x, y1, z, sbx, sby )],
+                                                       slot[vrc_slot_local_index( x, y, z1, sbx, sby )], slot[vrc_slot_local_index( x, y1, z1, sbx, sby )] );
+                                }
+                }
+    }
     const int mode = ( kernel == 5 || kernel == 6 ) ? VRC_MODE_TRILINEAR
                      : ( ( kernel == 7 || kernel == 8 ) ? VRC_MODE_POINT : VRC_MODE_TABLE );
     const bool fixed = ( kernel == 3 || kernel == 4 ) && !t.clamp;
@@ -117,6 +151,13 @@ static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3]
         tfp[k] = vrc_f4{ tf[i * 4], tf[i * 4 + 1], tf[i * 4 + 2], tf[i * 4 + 3] };
     }
     const vrc_f4* table = mode != VRC_MODE_TABLE ? tfp.data() : lut.data();
+    std::vector< vrc_f4 > cls8( VRC_CLS8_ENTRIES );
+    if( packedKernel )
+    {
+        for( uint32_t k = 0; k < VRC_CLS8_ENTRIES; ++k )
+            cls8[k] = vrc_cls8_entry( tfp.data(), k, kernel >= 11 );
+        table = cls8.data();
+    }
     uint64_t total = 0;
     vrc_f4* pb = reinterpret_cast< vrc_f4* >( pixelBuffer );
     for( uint32_t py = 0; py < H; ++py )
@@ -137,7 +178,14 @@ static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3]
         if( t.clamp ) vrc_pixel_ray_lod< true, true, false, MODE, T >( ARGS_DDA( A ) );              \
         else vrc_pixel_ray_lod< false, true, FIXED, MODE, T >( ARGS_DDA( A ) );                      \
     }
-            if( rayLod )
+            if( packedKernel )
+            {
+                if( kernel == 9 ) vrc_pixel_reference_order< false, true, true, VRC_MODE_PACKED, uint32_t, VRC_PGROUP >( ARGS_REF( packed.data() ) );
+                else if( kernel == 10 ) vrc_pixel_grid_dda< false, true, true, VRC_MODE_PACKED, uint32_t, VRC_PGROUP >( ARGS_DDA( packed.data() ) );
+                else if( kernel == 11 ) vrc_pixel_reference_order< false, true, true, VRC_MODE_PACKED_GREY, uint32_t, VRC_PGROUP >( ARGS_REF( packed.data() ) );
+                else vrc_pixel_grid_dda< false, true, true, VRC_MODE_PACKED_GREY, uint32_t, VRC_PGROUP >( ARGS_DDA( packed.data() ) );
+            }
+            else if( rayLod )
             {
                 if( mode == VRC_MODE_TRILINEAR && voxelBytes == 1 ) RAYLOD( false, VRC_MODE_TRILINEAR, uint8_t, atlas.data() )
                 else if( mode == VRC_MODE_TRILINEAR ) RAYLOD( false, VRC_MODE_TRILINEAR, uint16_t, atlas16.data() )

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in declared:
         assert hasattr(L, name), "libvrc_hip.so does not export %s" % name
     assert sorted(vrc.EXPORTS) == declared
-    assert L.vrc_abi_version() == 3  # the product build; a -DVRC_DEV_BUILD library reports -3
+    assert L.vrc_abi_version() == vrc.ABI_VERSION == 4  # the product build; a -DVRC_DEV_BUILD library reports -4
     assert L.vrc_is_dev_build() == 0
     assert L.vrc_last_kernel() == b""
 

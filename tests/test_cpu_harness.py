@@ -159,7 +159,7 @@ def test_sanitized_build_runs_clean():
         s = scenes.get("hash_clip")
         a, n, _ = orc.harness_render(s, kernel=2, sanitize=True)
         b, m, _ = orc.harness_render(s, kernel=1, sanitize=True)
-        for k in (4, 6, 8):  # fixed-point stepping, trilinear, per-sample classification
+        for k in (4, 6, 8, 9, 10, 12):  # fixed-point stepping, trilinear, per-sample classification, tap-packed atlas
             orc.harness_render(s, kernel=k, sanitize=True)
         orc.harness_render(s, kernel=2, sanitize=True, variant=1)  # glRaycaster rules
         s = scenes.nucleon_scene(viewport=(24, 24))
@@ -220,6 +220,28 @@ def test_trilinear_extension_matches_oracle(name):
         got, n_got, _ = orc.harness_render(s, kernel=kernel)
         scenes.assert_parity(got, want, "%s k%d" % (name, kernel))
         assert abs(n_got - n_want) <= 2e-4 * n_want + 8
+
+
+@pytest.mark.parametrize("name", sorted(scenes.SCENES))
+def test_tap_packed_trilinear_matches_oracle(name):
+    # the trilinear filter through the tap-packed atlas (VRC_KERNEL_PACKED; vrc_core.h: vrc_march_segment_packed):
+    # 32-bit texels holding the 2x2 neighbourhood, two reads per sample -- against the oracle's fetch_trilinear, for
+    # both brick enumerations and with the (grey, alpha) colours of a grey transfer function
+    s = scenes.get(name)
+    if min(s.vi.overlap[a] for a in range(3)) < 1 or s.atlas.dtype.itemsize != 1:
+        pytest.skip("the packed atlas takes its +1 neighbours from the overlap")
+    want, n_want = orc.oracle_render(s, threads=4, filter_mode=1)
+    frames = {}
+    for kernel in (9, 10):  # reference order / grid DDA
+        got, n_got, _ = orc.harness_render(s, kernel=kernel)
+        scenes.assert_parity(got, want, "%s k%d" % (name, kernel))
+        assert abs(n_got - n_want) <= 2e-4 * n_want + 8
+        frames[kernel] = got
+    grey = (s.tf[:, 0] == s.tf[:, 1]).all() and (s.tf[:, 0] == s.tf[:, 2]).all()
+    if grey:  # the same bits with two-float colours
+        for kernel in (11, 12):
+            got, _, _ = orc.harness_render(s, kernel=kernel)
+            assert (got == frames[kernel - 2]).all(), "%s k%d: grey form differs" % (name, kernel)
 
 
 def test_trilinear_differs_from_nearest_on_noise():
@@ -388,6 +410,12 @@ def test_random_views_all_kernel_forms_match_the_oracle(seed):
     want_lin, _ = orc.oracle_render(s, threads=4, filter_mode=1)
     got, _, _ = orc.harness_render(s, kernel=6)
     _fuzz_parity(got, want_lin, "seed %d trilinear %r" % (seed, kw))
+    if min(s.vi.overlap[a] for a in range(3)) >= 1 and max(s.slot_dim) <= 248 and s.atlas.dtype.itemsize == 1:
+        got, _, grid_ok = orc.harness_render(s, kernel=9)
+        _fuzz_parity(got, want_lin, "seed %d trilinear, tap-packed atlas %r" % (seed, kw))
+        if grid_ok:
+            got, _, _ = orc.harness_render(s, kernel=10)
+            _fuzz_parity(got, want_lin, "seed %d trilinear, tap-packed atlas, grid walk %r" % (seed, kw))
     want_gl, _ = orc.oracle_render(s, threads=4, variant=1)
     got, _, _ = orc.harness_render(s, kernel=2, variant=1)
     _fuzz_parity(got, want_gl, "seed %d glRaycaster %r" % (seed, kw))

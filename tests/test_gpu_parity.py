@@ -136,6 +136,78 @@ def test_lds_staged_kernel_parity(vrc, name):
         assert (auto == lin).all()
 
 
+@pytest.mark.parametrize("name", sorted(scenes.SCENES))
+def test_tap_packed_trilinear_parity(vrc, name):
+    # VRC_KERNEL_PACKED: the trilinear filter through the pool's tap-packed atlas (32-bit texels holding the 2x2
+    # neighbourhood, two gathers per sample; vrc_core.h: vrc_march_segment_packed) against the oracle's
+    # fetch_trilinear and against the LDS-staged form, whose positions, weights and arithmetic it shares
+    s = scenes.get(name)
+    L = None
+    with _gpu(s) as g:
+        L = g.L
+        if min(s.vi.overlap[a] for a in range(3)) < 1:
+            with pytest.raises(vrc.VrcError) as e:
+                g.render(kernel=vrc.KERNEL_PACKED, filter_mode=vrc.FILTER_TRILINEAR)
+            assert e.value.code == vrc.VRC_EINVAL
+            return
+        want_lin, n_want_lin = orc.oracle_render(s, threads=8, filter_mode=1)
+        # the packed atlas is built here, from bricks uploaded before anyone asked for it
+        got, n_got, st = g.render(kernel=vrc.KERNEL_PACKED, filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_PACKED
+        grey = (s.tf[:, 0] == s.tf[:, 1]).all() and (s.tf[:, 0] == s.tf[:, 2]).all()
+        assert (b",%d,unsigned int," % (6 if grey else 5)) in L.vrc_last_kernel(), L.vrc_last_kernel()
+        scenes.assert_parity(got, want_lin, name + " trilinear, tap-packed atlas")
+        assert abs(n_got - n_want_lin) <= 2e-4 * n_want_lin + 8
+        staged, n_staged, _ = g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
+        assert n_got == n_staged
+        scenes.assert_same_frame(got, staged, name + ": tap-packed atlas vs LDS-staged", tol=1e-6)
+        # the four-float colours of a coloured transfer function composite the same bits
+        vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 0))
+        four, n_four, _ = g.render(kernel=vrc.KERNEL_PACKED, filter_mode=vrc.FILTER_TRILINEAR)
+        assert b",5,unsigned int," in L.vrc_last_kernel()
+        assert n_four == n_got and (four == got).all()
+        vrc.check(L, L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 1))
+        # point sampling is refused, and leaves the context usable
+        with pytest.raises(vrc.VrcError):
+            g.render(kernel=vrc.KERNEL_PACKED)
+        near, _, _ = g.render(kernel=vrc.KERNEL_GRID_DDA)
+        scenes.assert_parity(near, orc.oracle_render(s, threads=8)[0], name + " nearest after the packed form")
+
+
+def test_tap_packed_atlas_follows_uploads(vrc):
+    # bricks uploaded AFTER the packed atlas exists are packed by their upload; a released and re-used slot too
+    s = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(96, 80), volume="hash", spin=(0.4, 0.3))
+    want_lin, _ = orc.oracle_render(s, threads=8, filter_mode=1)
+    with _gpu(s) as g:
+        L = g.L
+        first, _, _ = g.render(kernel=vrc.KERNEL_PACKED, filter_mode=vrc.FILTER_TRILINEAR)
+        scenes.assert_parity(first, want_lin, "packed atlas, before the re-uploads")
+        # overwrite every slot with zeros, then put the bricks back (same slots: the free list is a stack)
+        ids = list(s.ids)
+        for nid in ids:
+            vrc.check(L, L.vrc_pool_release_slot(g.pool, vrc.f32x3(*g.slots[nid])))
+        zero = np.zeros_like(s.bricks[ids[0]])
+        taken = []
+        for nid in ids:
+            slot = vrc.f32x3()
+            b = s.bricks[nid]
+            vrc.check(L, L.vrc_pool_copy_to_slot(g.pool, zero.ctypes.data, vrc.u32x3(b.shape[2], b.shape[1], b.shape[0]), slot))
+            taken.append((slot[0], slot[1], slot[2]))
+        black, _, _ = g.render(kernel=vrc.KERNEL_PACKED, filter_mode=vrc.FILTER_TRILINEAR)
+        assert (s.tf[0] == 0).all() and not black.any(), "zero bricks under a ramp render nothing"
+        # give the slots back in the order they were taken: the bricks then return to their own slots
+        for t in taken:
+            vrc.check(L, L.vrc_pool_release_slot(g.pool, vrc.f32x3(*t)))
+        for nid in ids:
+            slot = vrc.f32x3()
+            b = s.bricks[nid]
+            vrc.check(L, L.vrc_pool_copy_to_slot(g.pool, b.ctypes.data, vrc.u32x3(b.shape[2], b.shape[1], b.shape[0]), slot))
+            g.slots[nid] = (slot[0], slot[1], slot[2])
+        assert all(g.slots[nid] == s.slot_of[nid] for nid in ids)
+        again, _, _ = g.render(kernel=vrc.KERNEL_PACKED, filter_mode=vrc.FILTER_TRILINEAR)
+        assert (again == first).all()
+
+
 @pytest.mark.parametrize("spin", [(0.0, 0.0), (1.5708, 0.0), (1.40, 0.12), (-1.5, 0.3), (0.0, 1.5708),
                                   (0.3, 1.45), (0.7854, 0.7854)])
 def test_lds_region_shapes_by_view_axis(vrc, spin):

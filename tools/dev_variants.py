@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--alpha", type=float, default=0.05)
     ap.add_argument("--rounds", type=int, default=2, help="interleaved timing rounds over all builds")
     ap.add_argument("--no-tile-order", action="store_true", help="row-major tile order instead of heaviest-first")
+    ap.add_argument("--kernel", type=int, default=vrc.KERNEL_GRID_DDA, help="VRC_KERNEL_* code")
+    ap.add_argument("--filter", type=int, default=0, help="0 nearest, 1 trilinear")
     a = ap.parse_args()
     t0 = time.time()
     s = orc.build_scene(voxels=(a.voxels,) * 3, block=a.block, viewport=(a.viewport,) * 2,
@@ -44,7 +46,7 @@ def main():
     for path in a.libs:
         L = vrc.load_library(path)
         g = GpuScene(s, lib=L)
-        fb, n, st = g.render(kernel=vrc.KERNEL_GRID_DDA, count=True)
+        fb, n, st = g.render(kernel=a.kernel, filter_mode=a.filter, count=True)
         if first is None:
             first = fb
         d = np.abs(fb - first)
