@@ -132,6 +132,12 @@ typedef struct
                                    * operations on the same numbers, so the frame is bit-identical; first pass of
                                    * a frame only (the pixel starts from zero).  0: always the four-float form */
 
+#define VRC_OPT_PACKED_ATLAS 13    /* 1 (default) | 0.  May VRC_KERNEL_AUTO build the pool's tap-packed atlas (VRC_KERNEL_PACKED:
+                                   * 4.5 times the bytes of the brick atlas, on top of the budget given to
+                                   * vrc_pool_create) the first time a frame with the trilinear filter could use it?
+                                   * 0: AUTO stays with the LDS-staged / gather forms; asking for VRC_KERNEL_PACKED
+                                   * explicitly still builds it */
+
 #define VRC_VARIANT_CUDARAYCASTER 0 /* renderers/cudaRaycaster/cuda/Renderer.cu:95-230 */
 #define VRC_VARIANT_GLRAYCASTER 1   /* renderers/glRaycaster/shaders/fragRaycast.glsl:113-215: pixel centre
                                      * +0.5, hit test t0 <= t1, first sample of a brick snapped to the
@@ -152,7 +158,8 @@ typedef struct
 #define VRC_KERNEL_REFERENCE_ORDER 1 /* O(nodes) loop per ray in host order, cuda/Renderer.cu:172-227 */
 #define VRC_KERNEL_GRID_DDA 2        /* 3-D DDA over the brick grid; needs a grid-aligned node set */
 #define VRC_KERNEL_LDS 3             /* grid DDA + voxels staged through LDS per wave and round (needs
-                                      * overlap >= 1); what AUTO picks for the trilinear filter */
+                                      * overlap >= 1); what AUTO picks for the trilinear filter where the
+                                      * tap-packed atlas (VRC_KERNEL_PACKED) is not available */
 #define VRC_KERNEL_PACKED 5          /* the trilinear filter through the pool's tap-packed atlas: a second atlas, 4.5 times
                                       * the bytes, whose 32-bit texel at (x,y,z) holds the 2x2 neighbourhood across x,
                                       * v[x,y,z] | v[x,y+1,z] << 8 | v[x,y,z+1] << 16 | v[x,y+1,z+1] << 24, laid out so that
@@ -161,7 +168,9 @@ typedef struct
                                       * are ONE 8-byte gather.  Needs VRC_FILTER_TRILINEAR, 8-bit bricks with overlap >= 1,
                                       * an atlas of at most 2^32 voxels, VRC_OPT_TF_FRAC_BITS = 8, VRC_OPT_STEPPING = 1
                                       * (VRC_EINVAL otherwise) and the device memory (VRC_ENOMEM).  Same sample
-                                      * positions, weights and arithmetic as the LDS-staged form */
+                                      * positions, weights and arithmetic as the LDS-staged form: the same frame,
+                                      * bit for bit.  What AUTO picks for the trilinear filter where all of this
+                                      * holds (VRC_OPT_PACKED_ATLAS) */
 #define VRC_KERNEL_RAY_LOD 4         /* reported by vrc_get_stats when vrc_set_ray_lod is on; not selectable.  Under
                                       * per-ray LOD VRC_OPT_KERNEL chooses how the hierarchy walk takes its samples:
                                       * AUTO = staged through LDS for the trilinear filter on 8-bit bricks (overlap >= 1,
@@ -309,7 +318,7 @@ const char* vrc_last_error( void );
  * them), "" before the first: lets a benchmark check that a profile it quotes is a profile of what it ran */
 const char* vrc_last_kernel( void );
 /* ABI version of this header */
-#define VRC_ABI_VERSION 4 /* 3: vrc_gather_tiles takes the frame height; 4: VRC_KERNEL_PACKED */
+#define VRC_ABI_VERSION 4 /* 3: vrc_gather_tiles takes the frame height; 4: VRC_KERNEL_PACKED, VRC_OPT_PACKED_ATLAS */
 /* = VRC_ABI_VERSION for the product build; -VRC_ABI_VERSION for a developer build of the library (compiled with
  * -DVRC_DEV_BUILD: experiment switches, statistics, ablations that render wrong pixels on purpose) */
 int vrc_abi_version( void );

@@ -57,7 +57,7 @@
     defined( VRC_SPLIT_GROUP ) || \
     defined( VRC_SMALL_GROUP ) || \
     defined( VRC_SMALL_LAUNCH_TILES ) || \
-    defined( VRC_TILE_W ) || \
+    defined( VRC_TILE_W ) || defined( VRC_SUPER_UNITS ) || \
     defined( VRC_WAVES_PER_WG ) || \
     defined( VRC_MIN_WAVES ) || \
     defined( VRC_RL_WAVES ) || \
@@ -1595,7 +1595,7 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
 #pragma unroll
         for( int k = 0; k < GROUP; ++k )
         {
-#if defined( VRC_PACKED_ABLATE ) /* timing experiment only: no fetch */
+#if defined( VRC_PACKED_ABLATE ) && VRC_PACKED_ABLATE == 1 /* timing experiment only: no fetch */
             t[k] = vrc_texel_pair{ off[k] * 0x01010101u, off[k] * 0x00010101u };
 #else
             t[k] = vrc_packed_load( slot, off[k] );
@@ -1605,6 +1605,14 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
         for( int k = 0; k < GROUP; ++k )
             travel -= stepSize; /* same sequential subtraction as the reference */
         E e[GROUP];
+#if defined( VRC_PACKED_ABLATE ) && VRC_PACKED_ABLATE == 2 /* timing experiment only: fetches, next to no arithmetic */
+#pragma unroll
+        for( int k = 0; k < GROUP; ++k )
+        {
+            e[k] = E{};
+            e[k].w = (float)( ( t[k].t0 ^ t[k].t1 ) >> 31 ) * 1e-9f;
+        }
+#else
 #pragma unroll
         for( int k = 0; k < GROUP; ++k )
         {
@@ -1613,6 +1621,7 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
             q.y += q.dy;
             q.z += q.dz;
         }
+#endif
         const E saved = color;
 #pragma unroll
         for( int k = 0; k < GROUP; ++k )

@@ -18,12 +18,34 @@
  * consecutive slots, and every raycast kernel runs four waves per workgroup, so the four waves of a
  * workgroup -- same CU, same vector L1 -- march neighbouring tiles and the micro-block lines two of them
  * share are fetched from L2 once (measured on C2 with the gather kernel: -3 % kernel time).  A frame whose
- * tile count is odd in x or y has units with fewer than four tiles: their spare slots hold VRC_NO_TILE. */
+ * tile count is odd in x or y has units with fewer than four tiles: their spare slots hold VRC_NO_TILE.
+ *
+ * Round 4: the schedule is XCD-aware.  The dispatcher deals workgroups b, b + 1, ... round-robin over the 8 XCDs
+ * (MI355X_MICROARCH.md, "Workgroup dispatch") and each XCD has its own L2: workgroup b takes unit (b / 8) of XCD
+ * (b % 8)'s list.  A list is made of SUPER-TILES of VRC_SUPER_UNITS x VRC_SUPER_UNITS units (their units in Morton
+ * order), dealt to the XCDs heaviest first in snake order.  Measured on C2 (profiles/r4_schedule_and_hbm_requests.txt):
+ * the L2s fill whole 128-byte lines (TCC_EA0_RDREQ_128B = every request of these kernels) and fetch 1.9 x the packed
+ * atlas per trilinear frame, 2.2 x the volume per point-sampled frame; super-tiles of 4 x 4 units (64 x 64 pixels on
+ * one XCD) take 7 % of those requests away and no time (neighbouring workgroups drift apart in depth by more than the
+ * few steps an L2 remembers), and cost the LDS-staged kernel 5 % (coarser heaviest-first order).  So the product keeps
+ * super-tiles of ONE unit -- the heaviest-first order of rounds 1-3, with the XCD of every workgroup explicit -- and
+ * the size stays a developer switch.  The schedule has VRC_XCDS x ceil(super-tiles / VRC_XCDS) x VRC_SUPER_UNITS^2
+ * units; those outside the frame hold VRC_NO_TILE. */
 #define VRC_NO_TILE 0xFFFFFFFFu
 #define VRC_WAVES_PER_GROUP 4u
+#ifndef VRC_SUPER_UNITS
+#define VRC_SUPER_UNITS 1u
+#endif
+#define VRC_XCDS 8u
+__host__ __device__ inline uint32_t vrc_super_x( uint32_t tilesX ) { return ( ( tilesX + 1u ) / 2u + VRC_SUPER_UNITS - 1u ) / VRC_SUPER_UNITS; }
+__host__ __device__ inline uint32_t vrc_schedule_units( uint32_t tilesX, uint32_t tilesY )
+{
+    const uint32_t nSuper = vrc_super_x( tilesX ) * vrc_super_x( tilesY );
+    return ( nSuper + VRC_XCDS - 1u ) / VRC_XCDS * VRC_XCDS * VRC_SUPER_UNITS * VRC_SUPER_UNITS;
+}
 __host__ __device__ inline uint32_t vrc_schedule_slots( uint32_t tilesX, uint32_t tilesY )
 {
-    return ( ( tilesX + 1u ) / 2u ) * ( ( tilesY + 1u ) / 2u ) * 4u;
+    return vrc_schedule_units( tilesX, tilesY ) * 4u;
 }
 /* tile of slot `slot` of unit `unit` (units row-major over the frame): VRC_NO_TILE outside the frame */
 __host__ __device__ inline uint32_t vrc_unit_tile( uint32_t unit, uint32_t sub, uint32_t tilesX, uint32_t tilesY )
@@ -32,7 +54,7 @@ __host__ __device__ inline uint32_t vrc_unit_tile( uint32_t unit, uint32_t sub, 
     const uint32_t tx = ( unit % unitsX ) * 2u + ( sub & 1u ), ty = ( unit / unitsX ) * 2u + ( sub >> 1 );
     return ( tx < tilesX && ty < tilesY ) ? ty * tilesX + tx : VRC_NO_TILE;
 }
-/* the tile a wave takes: from the heaviest-first schedule, or (no schedule) units in row-major order */
+/* the tile a wave takes: from the schedule, or (no schedule) units in row-major order */
 __device__ inline uint32_t vrc_slot_tile( const uint32_t* __restrict__ tileOrder, uint32_t slot, uint32_t tilesX,
                                           uint32_t tilesY )
 {
@@ -98,8 +120,8 @@ struct vrc_raycast_args
                       * only when early ray termination cannot occur in this frame and the frame is cleared */
 };
 
-/* heaviest-first tile schedule for the frame (order: vrc_schedule_slots() uint32; scratch:
- * VRC_TILE_SCRATCH_WORDS uint32; bucket: one byte per unit) */
+/* the frame's tile schedule (above): order: vrc_schedule_slots() uint32; scratch: VRC_TILE_SCRATCH_WORDS uint32;
+ * bucket: one byte per super-tile (at most one per schedule slot) */
 #define VRC_TILE_SCRATCH_WORDS 260u
 hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t* scratch,
                                   uint8_t* bucket, hipStream_t stream );

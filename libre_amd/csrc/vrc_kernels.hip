@@ -6,9 +6,10 @@
  *   - one wave64 = one 8x8 pixel tile, one workgroup = one wave, so the hardware
  *     dispatcher load-balances tiles (ray lengths differ by >2x across the image) and
  *     no barrier is needed after the table is staged;
- *   - workgroup -> tile mapping: tiles heaviest-first (vrc_k_tile_order); the dispatcher
- *     deals workgroups round-robin over the 8 XCDs, so every XCD gets the same mix (a
- *     contiguous band per XCD was measured slower: there is next to no inter-tile reuse);
+ *   - workgroup -> tile mapping: units of 2x2 tiles heaviest-first, dealt to the XCDs in snake order (the
+ *     dispatcher deals workgroups round-robin over the 8 XCDs; vrc_internal.h, "Tile schedule": spatial
+ *     super-tiles per XCD were measured in round 4 -- 7 % fewer HBM requests, no time -- and one contiguous
+ *     band per XCD in round 1, slower);
  *   - the atlas is read as 8x8x8-voxel micro-blocks (one z-slice of a block = one 64-byte
  *     segment), so the 64 fetches of a wave step land in a handful of cache lines;
  *   - TF lookup + opacity correction are folded into a 256-entry classified table staged
@@ -324,16 +325,17 @@ hipError_t vrc_launch_pack_slots( const void* atlas, void* packed, uint64_t firs
 }
 
 /* ------------------------------------------------------------------------------------------
- * tile schedule: order the 8x8 tiles by estimated work, heaviest first: cost = chord of the
- * tile-centre ray through the (clipped) volume box, counting sort over 256 cost buckets in
- * two passes over all CUs.  Re-run only when the view changes.
+ * tile schedule (vrc_internal.h): super-tiles of VRC_SUPER_UNITS^2 units ordered by estimated work, heaviest first
+ * -- cost = chord of the super-tile-centre ray through the (clipped) volume box, counting sort over 256 cost buckets
+ * -- and dealt to the XCDs in snake order; workgroup b = unit b / 8 of XCD b % 8's list.  Re-run only when the view
+ * changes.
  * ---------------------------------------------------------------------------------------- */
-__device__ __forceinline__ uint32_t vrc_tile_bucket( const vrc_frame& f, uint32_t tile,
-                                                     uint32_t tilesX, float invDiag )
+__device__ __forceinline__ uint32_t vrc_tile_bucket( const vrc_frame& f, uint32_t super, uint32_t superX, float invDiag )
 {
-    /* tile = index of a schedule unit (2x2 tiles), tilesX = units per row: cost at the unit's centre */
-    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
-    uint32_t px = tx * VRC_TILE_W * 2u + VRC_TILE_W, py = ty * VRC_TILE_H * 2u + VRC_TILE_H;
+    /* cost at the super-tile's centre (clamped into the frame) */
+    const uint32_t span = VRC_SUPER_UNITS * 2u;
+    const uint32_t sx = super % superX, sy = super / superX;
+    uint32_t px = sx * VRC_TILE_W * span + VRC_TILE_W * span / 2u, py = sy * VRC_TILE_H * span + VRC_TILE_H * span / 2u;
     px = px < f.width ? px : f.width - 1;
     py = py < f.height ? py : f.height - 1;
     const vrc_ray r = vrc_setup_ray( f, px, f.rowMap ? f.rowMap[py] : py );
@@ -344,11 +346,11 @@ __device__ __forceinline__ uint32_t vrc_tile_bucket( const vrc_frame& f, uint32_
     return 255u - (uint32_t)( q * 255.0f );
 }
 
-/* pass 1: cost bucket of every tile, histogram; the last workgroup to finish turns the
+/* pass 1: cost bucket of every super-tile, histogram; the last workgroup to finish turns the
  * histogram into bucket start offsets.  scratch: [0..255] histogram/offsets, [256] counter
  * of finished workgroups (zeroed by the launcher). */
-__global__ __launch_bounds__( 256 ) void vrc_k_tile_bucket( const vrc_frame f, const uint32_t tilesX,
-                                                            const uint32_t nTiles,
+__global__ __launch_bounds__( 256 ) void vrc_k_tile_bucket( const vrc_frame f, const uint32_t superX,
+                                                            const uint32_t nSuper,
                                                             uint8_t* __restrict__ bucket,
                                                             uint32_t* __restrict__ scratch )
 {
@@ -360,9 +362,9 @@ __global__ __launch_bounds__( 256 ) void vrc_k_tile_bucket( const vrc_frame f, c
     hist[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if( t < nTiles )
+    if( t < nSuper )
     {
-        const uint32_t b = vrc_tile_bucket( f, t, tilesX, invDiag );
+        const uint32_t b = vrc_tile_bucket( f, t, superX, invDiag );
         bucket[t] = (uint8_t)b;
         atomicAdd( &hist[b], 1u );
     }
@@ -389,11 +391,11 @@ __global__ __launch_bounds__( 256 ) void vrc_k_tile_bucket( const vrc_frame f, c
     scratch[threadIdx.x] = threadIdx.x ? hist[threadIdx.x - 1u] : 0u;
 }
 
-/* pass 2: scatter the tiles to their bucket ranges (order inside a bucket is arbitrary).  A
- * workgroup reserves its share of every bucket with one global atomic per bucket; the ranks
- * inside the share come from LDS atomics (most tiles fall into a few buckets: one global
- * atomic per tile serialises in L2, measured 33 us). */
-__global__ __launch_bounds__( 256 ) void vrc_k_tile_scatter( const uint32_t nTiles,
+/* pass 2: every super-tile takes its rank (bucket start + a rank inside the bucket: order inside a bucket is
+ * arbitrary), the rank its XCD and its place in that XCD's list, and writes the tiles of its units there.  A
+ * workgroup reserves its share of every bucket with one global atomic per bucket; the ranks inside the share come
+ * from LDS atomics.  `order` was filled with VRC_NO_TILE by the launcher (places no super-tile takes). */
+__global__ __launch_bounds__( 256 ) void vrc_k_tile_scatter( const uint32_t nSuper, const uint32_t superX,
                                                              const uint8_t* __restrict__ bucket,
                                                              uint32_t* __restrict__ scratch,
                                                              uint32_t* __restrict__ order,
@@ -404,7 +406,7 @@ __global__ __launch_bounds__( 256 ) void vrc_k_tile_scatter( const uint32_t nTil
     __syncthreads();
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     uint32_t b = 0, rank = 0;
-    if( t < nTiles )
+    if( t < nSuper )
     {
         b = bucket[t];
         rank = atomicAdd( &cnt[b], 1u );
@@ -413,13 +415,28 @@ __global__ __launch_bounds__( 256 ) void vrc_k_tile_scatter( const uint32_t nTil
     if( cnt[threadIdx.x] )
         base[threadIdx.x] = atomicAdd( &scratch[threadIdx.x], cnt[threadIdx.x] );
     __syncthreads();
-    if( t < nTiles )
+    if( t < nSuper )
     {
-        /* the unit's four tiles in four consecutive slots (VRC_NO_TILE for those outside the frame) */
-        const uint32_t at = ( base[b] + rank ) * 4u;
+        const uint32_t r = base[b] + rank;
+        /* snake over the XCDs: ranks 0..7 go to XCDs 0..7, ranks 8..15 to XCDs 7..0, ... */
+        const uint32_t row = r / VRC_XCDS, col = r % VRC_XCDS;
+        const uint32_t xcd = ( row & 1u ) ? VRC_XCDS - 1u - col : col;
+        const uint32_t unitsX = ( frameTilesX + 1u ) / 2u, unitsY = ( frameTilesY + 1u ) / 2u;
+        const uint32_t sx = t % superX, sy = t / superX;
+        for( uint32_t u = 0; u < VRC_SUPER_UNITS * VRC_SUPER_UNITS; ++u )
+        {
+            /* Morton order inside the super-tile (up to 16 x 16 units) */
+            const uint32_t ux = ( u & 1u ) | ( ( u >> 1 ) & 2u ) | ( ( u >> 2 ) & 4u ) | ( ( u >> 3 ) & 8u );
+            const uint32_t uy = ( ( u >> 1 ) & 1u ) | ( ( u >> 2 ) & 2u ) | ( ( u >> 3 ) & 4u ) | ( ( u >> 4 ) & 8u );
+            const uint32_t x = sx * VRC_SUPER_UNITS + ux, y = sy * VRC_SUPER_UNITS + uy;
+            /* the workgroup: VRC_WAVES_PER_WG / 4 consecutive units of the super-tile's Morton order (one in the product) */
+            constexpr uint32_t U = VRC_WAVES_PER_WG / 4u;
+            const uint32_t g = VRC_XCDS * ( row * ( VRC_SUPER_UNITS * VRC_SUPER_UNITS / U ) + u / U ) + xcd;
 #pragma unroll
-        for( uint32_t sub = 0; sub < 4u; ++sub )
-            order[at + sub] = vrc_unit_tile( t, sub, frameTilesX, frameTilesY );
+            for( uint32_t sub = 0; sub < 4u; ++sub )
+                order[( g * U + u % U ) * 4u + sub] = ( x < unitsX && y < unitsY ) ? vrc_unit_tile( y * unitsX + x, sub, frameTilesX, frameTilesY )
+                                                                                 : VRC_NO_TILE;
+        }
     }
 }
 
@@ -428,17 +445,17 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t*
 {
     const uint32_t frameTilesX = ( f.width + VRC_TILE_W - 1 ) / VRC_TILE_W;
     const uint32_t frameTilesY = ( f.height + VRC_TILE_H - 1 ) / VRC_TILE_H;
-    /* sorted: the schedule units (2x2 tiles, vrc_internal.h) */
-    const uint32_t tilesX = ( frameTilesX + 1u ) / 2u, tilesY = ( frameTilesY + 1u ) / 2u;
-    const uint32_t nTiles = tilesX * tilesY;
-    if( nTiles == 0 )
+    const uint32_t superX = vrc_super_x( frameTilesX ), nSuper = superX * vrc_super_x( frameTilesY );
+    if( frameTilesX * frameTilesY == 0 )
         return hipSuccess;
     hipError_t e = hipMemsetAsync( scratch, 0, VRC_TILE_SCRATCH_WORDS * sizeof( uint32_t ), stream );
+    if( e == hipSuccess )
+        e = hipMemsetAsync( order, 0xFF, (size_t)vrc_schedule_slots( frameTilesX, frameTilesY ) * sizeof( uint32_t ), stream );
     if( e != hipSuccess )
         return e;
-    const dim3 grid( ( nTiles + 255u ) / 256u ), block( 256 );
-    hipLaunchKernelGGL( vrc_k_tile_bucket, grid, block, 0, stream, f, tilesX, nTiles, bucket, scratch );
-    hipLaunchKernelGGL( vrc_k_tile_scatter, grid, block, 0, stream, nTiles, bucket, scratch, order, frameTilesX,
+    const dim3 grid( ( nSuper + 255u ) / 256u ), block( 256 );
+    hipLaunchKernelGGL( vrc_k_tile_bucket, grid, block, 0, stream, f, superX, nSuper, bucket, scratch );
+    hipLaunchKernelGGL( vrc_k_tile_scatter, grid, block, 0, stream, nSuper, superX, bucket, scratch, order, frameTilesX,
                         frameTilesY );
     return hipGetLastError();
 }
@@ -452,6 +469,9 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t*
  * (mem://), 0.512 -> 0.482 ms (noise); 12: 0.491 / 0.484; 16 (96 VGPRs): 0.487 */
 #define VRC_GREY_GROUP 14
 #endif
+#ifndef VRC_PACKED_WAVES
+#define VRC_PACKED_WAVES 4 /* (developer switch; 6 and 8 measured slower on C2) */
+#endif
 #ifndef VRC_MIN_WAVES
 #define VRC_MIN_WAVES 5 /* measured on C2: 4 -> 5 waves per SIMD with four-wave workgroups: -2 % */
 #endif
@@ -464,9 +484,6 @@ template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLA
 /* waves per SIMD: 5 for the table-driven point-sampling instances (48 VGPRs); the per-sample classification modes,
  * the float position chain, the clamped sampler and 64-bit slot bases need more registers than 5 waves leave (they
  * spilled at 5: the trilinear gather form ran 5.3 instead of 2.9 ms) */
-#ifndef VRC_PACKED_WAVES
-#define VRC_PACKED_WAVES 4
-#endif
 __global__ __launch_bounds__( VRC_WG_THREADS, ( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY ) ? VRC_PACKED_WAVES
                                               : GROUP > VRC_GREY_GROUP ? 2
                                               : ( ( ( MODE == VRC_MODE_TABLE && GROUP <= 8 ) || MODE == VRC_MODE_GREY ) && FIXED && !CLAMP && !BIG
@@ -544,12 +561,9 @@ __global__ __launch_bounds__( VRC_WG_THREADS, ( MODE == VRC_MODE_PACKED || MODE 
     if( slotIndex >= vrc_schedule_slots( tilesX, tilesY ) )
         return;
 
-    /* Workgroup -> tile.  Ray lengths vary by more than 2x over the image and whole tiles miss
-     * the volume, so dispatch order matters more than L2 affinity here (every voxel is
-     * touched by about one wave; there is next to no inter-tile reuse to keep in an L2):
-     * tileOrder lists tiles heaviest-first (vrc_k_tile_order), and because the dispatcher
-     * deals workgroups b, b+1, ... round-robin over the 8 XCDs (MI355X_MICROARCH.md,
-     * "Workgroup dispatch") every XCD gets the same mix and the long tiles start first. */
+    /* Workgroup -> tile: the schedule of vrc_internal.h.  Ray lengths vary by more than 2x over the image and
+     * whole tiles miss the volume, so the heaviest units start first, dealt evenly to the XCDs (the dispatcher
+     * deals workgroups b, b+1, ... round-robin over the 8 XCDs, MI355X_MICROARCH.md "Workgroup dispatch"). */
     const uint32_t tile = vrc_slot_tile( tileOrder, slotIndex, tilesX, tilesY );
     if( tile == VRC_NO_TILE )
         return;

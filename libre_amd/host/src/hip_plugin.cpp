@@ -62,8 +62,18 @@ struct DeviceContext
 };
 std::map< int, DeviceContext > g_deviceContexts;
 
+/* the device layer this plugin was compiled against (a developer build of it reports the negated version) */
+void checkDeviceLayerAbi()
+{
+    const int v = vrc_abi_version();
+    if( v != VRC_ABI_VERSION && v != -VRC_ABI_VERSION )
+        throw std::runtime_error( "libvrc_hip.so has ABI version " + std::to_string( v ) + ", this plugin needs " +
+                                  std::to_string( VRC_ABI_VERSION ) );
+}
+
 vrc_ctx* acquireDeviceContext( int* deviceOut )
 {
+    checkDeviceLayerAbi();
     std::lock_guard< std::mutex > lock( g_deviceMutex );
     const int device = g_device.load();
     DeviceContext& d = g_deviceContexts[device];
@@ -349,6 +359,7 @@ HipTextureObject::~HipTextureObject()
 HipRaycastRenderer::HipRaycastRenderer( const std::string& name )
     : RendererPlugin( name ), _ctx( nullptr ), _computedSamplesPerRay( 0 )
 {
+    checkDeviceLayerAbi();
     throwOnVrcError( vrc_ctx_create( getHipDevice(), &_ctx ), "vrc_ctx_create" );
 }
 
@@ -1046,14 +1057,16 @@ struct HipRaycastPipeline::Impl
     /* Per-ray LOD over a hierarchy larger than the atlas (round 3).  Per-ray LOD picks, at every point of a ray,
      * the level the screen-space-error rule asks for there and falls back to the next resident one -- so a pass that
      * holds only SOME bricks would make rays fall back where the single pass would not.  A pass is therefore a slab
-     * of space across the view's main axis, bounded by faces of the finest bricks, with every brick of every level
+     * of space across an axis every ray runs along in one direction (below), bounded by faces of the finest bricks, with every brick of every level
      * that reaches into the slab resident, and the rays confined to it by two clip planes (the kernel's own
      * tNearGlobal / tFarGlobal, cuda/Renderer.cu:132-149): inside a slab every ray sees exactly the bricks it would
      * see in the whole hierarchy.  Slabs are rendered front to back into the accumulating pixel buffer
      * (Renderer.cu:151-157), as the reference's passes are.  A run that crosses a slab face is cut there (sampling
      * restarts at the face, as it does at every brick face): the frame is the per-ray LOD frame with those extra
      * restarts, and it is what the oracle renders from the same slabs (tests/test_gpu_parity.py).
-     * Returns false (nothing rendered) if even the thinnest slab does not fit or there is no room for two planes. */
+     * Returns false (nothing rendered) if even the thinnest slab does not fit, there is no room for two planes, or no
+     * axis orders the slabs for every ray (round 4: round 3 took the axis from centre - eye, which composites the
+     * rays that run the other way back to front -- eye inside the hierarchy, or outside it on another axis). */
     bool renderRayLodInSlabs( RenderStatistics& statistics, Renderer& renderer, const RenderInputs& in,
                               const NodeIds& hierarchy, uint32_t maxNodesPerPass )
     {
@@ -1076,12 +1089,44 @@ struct HipRaycastPipeline::Impl
                 hi[a] = std::max( hi[a], boxes.back().getMax()[a] );
             }
         }
-        const Vector3f dir = ( lo + hi ) * 0.5f - frustum.getEyePos();
-        int axis = 0;
-        for( int a = 1; a < 3; ++a )
-            if( std::fabs( dir[a] ) > std::fabs( dir[axis] ) )
+        /* An axis serves only if EVERY ray that meets the hierarchy runs the same way along it -- a ray that runs the
+         * other way would cross a slab face into a slab that has been composited already, back to front.  That holds
+         * where the eye lies outside the hierarchy's extent on the axis (a ray that enters [lo, hi] from below goes
+         * up), or where the four corner rays of the frustum share a sign along it (every ray of the frustum is a
+         * positive combination of them).  Among the axes that serve, the one the view looks along most; none (the eye
+         * inside the hierarchy under a wide view): no slabs, the caller renders the per-brick cut. */
+        const Vector3f eye = frustum.getEyePos();
+        Vector3f corner[4];
+        {
+            const float xs[2] = { frustum.left(), frustum.right() }, ys[2] = { frustum.bottom(), frustum.top() };
+            for( int c = 0; c < 4; ++c )
+            {
+                const Vector4f d = frustum.getInvMVMatrix() * Vector4f( xs[c & 1], ys[c >> 1], -frustum.nearPlane(), 0.0f );
+                corner[c] = Vector3f( d[0], d[1], d[2] );
+            }
+        }
+        const Vector3f view = ( corner[0] + corner[1] + corner[2] + corner[3] ) * 0.25f;
+        int axis = -1;
+        bool forward = true;
+        for( int a = 0; a < 3; ++a )
+        {
+            int sign = 0; /* +1 / -1: every ray that meets the hierarchy runs up / down the axis */
+            if( eye[a] <= lo[a] )
+                sign = 1;
+            else if( eye[a] >= hi[a] )
+                sign = -1;
+            else if( corner[0][a] > 0.0f && corner[1][a] > 0.0f && corner[2][a] > 0.0f && corner[3][a] > 0.0f )
+                sign = 1;
+            else if( corner[0][a] < 0.0f && corner[1][a] < 0.0f && corner[2][a] < 0.0f && corner[3][a] < 0.0f )
+                sign = -1;
+            if( sign != 0 && ( axis < 0 || std::fabs( view[a] ) > std::fabs( view[axis] ) ) )
+            {
                 axis = a;
-        const bool forward = dir[axis] > 0.0f;
+                forward = sign > 0;
+            }
+        }
+        if( axis < 0 )
+            return false;
         /* candidate faces: those of the finest bricks present (coarser faces are among them up to rounding) */
         std::vector< float > faces;
         for( size_t i = 0; i < hierarchy.size(); ++i )
@@ -1154,7 +1199,12 @@ struct HipRaycastPipeline::Impl
                 objects = upload( slabs[i].ids, in );
             }
             if( objects.size() != slabs[i].ids.size() )
+            {
+                /* close the frame that slab 0 opened before reporting */
+                if( i > 0 )
+                    renderer.render( in, ConstCacheObjects(), RENDER_END );
                 throw std::runtime_error( "per-ray LOD in slabs: a slab's bricks could not be made resident" );
+            }
             renderer.render( slabIn, objects, renderStages );
             _lastRayLod = _lastRayLod && static_cast< HipRaycastRenderer& >( renderer.getPlugin() ).lastRenderUsedRayLOD();
             bricks += objects.size();

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvrc_hip.so")
 
 VRC_OK, VRC_EINVAL, VRC_EHIP, VRC_EFULL, VRC_ENOMEM, VRC_EUNSUPPORTED, VRC_EHIERARCHY, VRC_ECOMM = range(8)
-OPT_KERNEL, OPT_FILTER, OPT_TF_FRAC_BITS, OPT_COUNT_SAMPLES, OPT_TILE_ORDER, OPT_STEPPING, OPT_VARIANT, OPT_KERNEL_USED, OPT_KERNEL_TIMING, OPT_DEPTH_SPLIT, OPT_ERT_COMPACTION, OPT_GREY_TABLE = range(1, 13)
+OPT_KERNEL, OPT_FILTER, OPT_TF_FRAC_BITS, OPT_COUNT_SAMPLES, OPT_TILE_ORDER, OPT_STEPPING, OPT_VARIANT, OPT_KERNEL_USED, OPT_KERNEL_TIMING, OPT_DEPTH_SPLIT, OPT_ERT_COMPACTION, OPT_GREY_TABLE, OPT_PACKED_ATLAS = range(1, 14)
 VARIANT_CUDARAYCASTER, VARIANT_GLRAYCASTER = 0, 1
 FILTER_NEAREST, FILTER_TRILINEAR = 0, 1
 KERNEL_AUTO, KERNEL_REFERENCE_ORDER, KERNEL_GRID_DDA, KERNEL_LDS, KERNEL_RAY_LOD, KERNEL_PACKED = 0, 1, 2, 3, 4, 5

@@ -873,5 +873,52 @@ def test_per_ray_lod_in_slabs_when_the_hierarchy_exceeds_the_atlas(drv, spin):
     assert p_whole <= 1 and p_slab >= 3 and avail_slab == avail_whole
     # (noise data: a restart at a slab face shifts that run's samples by a fraction of a step -- isolated pixels differ
     # by a few 1e-2, the frame mean by a few 1e-4)
-    scenes.assert_close_frames(slabbed, whole, "slabs of a small atlas against the single pass", max_abs=5e-2, mean_abs=1e-3)
+    scenes.assert_close_frames(slabbed, whole, "slabs of a small atlas against the single pass", max_abs=SLAB_MAX_ABS, mean_abs=SLAB_MEAN_ABS)
     assert 0 < n_slab < n_whole  # (the counter is the last launch's: the last slab)
+
+
+#: what the sampling restarts at slab faces cost against the single pass: isolated pixels / the frame mean.  Measured on
+#: MI355X with the slabs in the rays' order: max 1.8e-2, mean 8.0e-4 (the axis-aligned view of the 128^3 scene: eight
+#: slabs, every coarse-level run cut seven times, transfer function of alpha 0.1); what a wrong ORDER costs is measured
+#: in test_per_ray_lod_slabs_are_ordered_along_the_rays
+SLAB_MAX_ABS, SLAB_MEAN_ABS = 2.5e-2, 1e-3
+
+
+@pytest.mark.parametrize("case", ["eye inside, looking across centre - eye", "flat volume, eye beside it on another axis",
+                                  "eye inside, looking along the diagonal"])
+def test_per_ray_lod_slabs_are_ordered_along_the_rays(drv, case):
+    # Round 3 took the slab axis and direction from (centre of the hierarchy - eye).  With the eye inside the hierarchy's
+    # extent along that axis there are rays of both signs; the ones that run the other way crossed into a slab that had
+    # been composited already -- back to front (advisor).  Now an axis serves only if every ray that meets
+    # the hierarchy runs one way along it (eye outside the extent on that axis, or the four corner rays of the frustum
+    # agree); none: per-brick cut.  Reference passes are front to back by the sorted list: CudaRaycastPipeline.cpp:107-127, :149-185.
+    from libre_amd import vrc
+    if case == "eye inside, looking across centre - eye":
+        # centre - eye = (-0.1, 0, -0.2): round 3 sliced across z, front = high z; the view looks along +x
+        uri, mb, cam = "hash://#256,256,256,32", 2, dict(position=(0.1, 0.0, 0.2), lookat=(1.0, 0.0, 0.2))
+    elif case.startswith("flat"):
+        # 192 x 128 x 64 voxels: world box (+-0.5, +-0.333, +-0.167); the eye is outside in z only; |centre - eye| is the
+        # same along x and z and round 3's tie went to x, along which the rays run both ways
+        uri, mb, cam = "hash://#192,128,64,16", 1, dict(position=(0.3, 0.0, 0.3), lookat=(0.3, 0.0, -1.0))
+    else:
+        # eye inside on every axis, the view along the diagonal: only the corner rays can tell which axes serve
+        uri, mb, cam = "hash://#128,128,128,16", 1, dict(position=(-0.2, -0.1, -0.25), lookat=(1.0, 1.0, 1.0))
+    W, H, sse = 96, 80, 0.6
+    # Transfer functions under which the ORDER matters (at alpha 0.1 compositing nearly commutes and a reversed order
+    # only doubles the restart error).  Measured on MI355X, slabs in the rays' order / reversed on purpose:
+    #   alpha 0.4: max <= 9.9e-3, mean <= 7.0e-4  /  max >= 3.1e-2, mean >= 5.9e-3
+    #   alpha 1.0: max <= 1.0e-3, mean <= 1.8e-5  /  max >= 9.1e-2, mean >= 1.5e-2   (rays end before most slab faces)
+    for alpha, max_abs, mean_abs in ((0.4, SLAB_MAX_ABS, SLAB_MEAN_ABS), (1.0, 2.5e-3, 1e-4)):
+        frames = {}
+        for cache in (256, mb):  # an atlas for the whole visible hierarchy / for a part of it (at least one layer of bricks)
+            with drv.App(uri, W, H, synchronous=True, sse=sse, gpu_cache_mb=cache) as app:
+                app.set_camera(**cam)
+                app.set_colormap(orc.linear_ramp_tf(alpha))
+                app.set_ray_lod(True)
+                fb, st = app.render_frame()
+                frames[cache] = (fb, st.ray_lod, st.n_passes)
+        (whole, lod_whole, p_whole), (small, lod_small, p_small) = frames[256], frames[mb]
+        assert lod_whole == 1 and p_whole <= 1 and whole[..., 3].max() > 0.05
+        assert lod_small == 1 and p_small >= 2, (lod_small, p_small)
+        mx, mean = scenes.assert_close_frames(small, whole, "%s, alpha %g" % (case, alpha), max_abs=max_abs, mean_abs=mean_abs)
+        print("slab order, %s, alpha %g: %d slabs, max|d| %.3g mean|d| %.3g" % (case, alpha, p_small, mx, mean))

@@ -131,8 +131,14 @@ def test_lds_staged_kernel_parity(vrc, name):
         assert st.kernel_variant == vrc.KERNEL_LDS
         scenes.assert_parity(lin, want_lin, name + " lds trilinear")
         assert abs(n_lin - n_want_lin) <= 2e-4 * n_want_lin + 8
+        # AUTO + trilinear: the tap-packed atlas where the bricks have an overlap (the staged form's frame, bit for
+        # bit), else -- or with VRC_OPT_PACKED_ATLAS off -- the staged form itself
         auto, _, st = g.render(filter_mode=vrc.FILTER_TRILINEAR, count=False)
-        assert st.kernel_variant == vrc.KERNEL_LDS  # AUTO + trilinear
+        assert st.kernel_variant == vrc.KERNEL_PACKED
+        assert (auto == lin).all()
+        vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_PACKED_ATLAS, 0))
+        auto, _, st = g.render(filter_mode=vrc.FILTER_TRILINEAR, count=False)
+        assert st.kernel_variant == vrc.KERNEL_LDS
         assert (auto == lin).all()
 
 
@@ -478,12 +484,15 @@ def test_c2_full_size_rows_of_the_other_modes(vrc):
         gl, _, st = g.render(variant=vrc.VARIANT_GLRAYCASTER)
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
         lin, n_lin, st = g.render(filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_PACKED  # what AUTO takes: a 6 GB packed atlas, texels past 4 GiB
+        staged, n_staged, st = g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
         assert st.kernel_variant == vrc.KERNEL_LDS
         lin_gather, n_gather, st = g.render(kernel=vrc.KERNEL_GRID_DDA, filter_mode=vrc.FILTER_TRILINEAR)
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
     scenes.assert_parity(gl[::128], want_gl[::128], "C2 rows, glRaycaster variant")
-    scenes.assert_parity(lin[::128], want_lin[::128], "C2 rows, trilinear (LDS kernel)")
-    scenes.assert_same_frame(lin_gather, lin, "C2 trilinear: gather form vs LDS form", tol=2e-5)
+    scenes.assert_parity(lin[::128], want_lin[::128], "C2 rows, trilinear (tap-packed atlas)")
+    assert n_staged == n_lin and (staged == lin).all(), "C2 trilinear: the staged form composites the packed form's numbers"
+    scenes.assert_same_frame(lin_gather, lin, "C2 trilinear: gather form vs packed form", tol=2e-5)
     assert abs(n_lin - n_gather) <= 2e-4 * n_lin
 
 
@@ -554,9 +563,13 @@ def test_noise_in_136_cubed_slots_every_kernel_form(vrc, spin):
         gl, _, _ = g.render(variant=vrc.VARIANT_GLRAYCASTER)
         scenes.assert_parity(gl, want_gl, "136^3 noise, glRaycaster variant")
         lin, n_got_lin, st = g.render(filter_mode=vrc.FILTER_TRILINEAR)
-        assert st.kernel_variant == vrc.KERNEL_LDS
-        scenes.assert_parity(lin, want_lin, "136^3 noise, trilinear (LDS kernel)")
+        assert st.kernel_variant == vrc.KERNEL_PACKED
+        scenes.assert_parity(lin, want_lin, "136^3 noise, trilinear (tap-packed atlas)")
         assert abs(n_got_lin - n_lin) <= 2e-4 * n_lin + 8
+        staged, n_staged, st = g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_LDS
+        scenes.assert_parity(staged, want_lin, "136^3 noise, trilinear (LDS kernel)")
+        assert n_staged == n_got_lin and (staged == lin).all()
         ling, _, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, filter_mode=vrc.FILTER_TRILINEAR)
         scenes.assert_parity(ling, want_lin, "136^3 noise, trilinear (gather form)")
 
@@ -623,6 +636,10 @@ def test_random_views_all_gpu_kernels_match_the_oracle(vrc, seed):
             _fuzz_parity(got, want_lin, "seed %d k%d trilinear %r" % (seed, k, kw))
             got, _, _ = g.render(kernel=k, variant=vrc.VARIANT_GLRAYCASTER)
             _fuzz_parity(got, want_gl, "seed %d k%d glRaycaster %r" % (seed, k, kw))
+        if min(s.vi.overlap[a] for a in range(3)) >= 1 and max(s.slot_dim) <= 248:
+            got, _, st = g.render(kernel=vrc.KERNEL_PACKED, filter_mode=vrc.FILTER_TRILINEAR)
+            assert st.kernel_variant == vrc.KERNEL_PACKED
+            _fuzz_parity(got, want_lin, "seed %d trilinear, tap-packed atlas %r" % (seed, kw))
 
 
 @pytest.mark.parametrize("seed", range(16 * scenes.FUZZ_SCALE))
