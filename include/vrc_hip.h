@@ -317,8 +317,12 @@ const char* vrc_last_error( void );
 /* the kernel instance the calling thread's last vrc_render launched (template arguments spelled as rocprofv3 prints
  * them), "" before the first: lets a benchmark check that a profile it quotes is a profile of what it ran */
 const char* vrc_last_kernel( void );
+/* ... and how many workgroups of it the runtime says a compute unit holds at once (hipOccupancyMaxActiveBlocksPerMultiprocessor:
+ * registers, LDS and wave slots together), with the workgroup size: the occupancy the kernels' launch bounds ask for,
+ * checkable without a profiler.  The vrc_k_raycast instances only (VRC_EINVAL after another kernel). */
+int vrc_last_kernel_occupancy( int* workgroups_per_cu, int* threads_per_workgroup );
 /* ABI version of this header */
-#define VRC_ABI_VERSION 4 /* 3: vrc_gather_tiles takes the frame height; 4: VRC_KERNEL_PACKED, VRC_OPT_PACKED_ATLAS */
+#define VRC_ABI_VERSION 4 /* 3: vrc_gather_tiles takes the frame height; 4: VRC_KERNEL_PACKED, VRC_OPT_PACKED_ATLAS, vrc_last_kernel_occupancy */
 /* = VRC_ABI_VERSION for the product build; -VRC_ABI_VERSION for a developer build of the library (compiled with
  * -DVRC_DEV_BUILD: experiment switches, statistics, ablations that render wrong pixels on purpose) */
 int vrc_abi_version( void );

@@ -200,6 +200,15 @@ void vrc_internal_note_kernel( const char* fmt, ... )
     vsnprintf( tlsKernel, sizeof( tlsKernel ), fmt, ap );
     va_end( ap );
 }
+static thread_local const void* tlsKernelFn = nullptr;
+static thread_local int tlsKernelThreads = 0;
+static thread_local size_t tlsKernelLds = 0;
+void vrc_internal_note_kernel_fn( const void* fn, int threads, size_t dynamicLds )
+{
+    tlsKernelFn = fn;
+    tlsKernelThreads = threads;
+    tlsKernelLds = dynamicLds;
+}
 hipStream_t vrc_internal_ctx_stream( vrc_ctx* c, int* deviceOut )
 {
     if( deviceOut )
@@ -211,6 +220,20 @@ extern "C" {
 
 const char* vrc_last_error( void ) { return g_lastError.c_str(); }
 const char* vrc_last_kernel( void ) { return tlsKernel; }
+int vrc_last_kernel_occupancy( int* workgroupsPerCu, int* threadsPerWorkgroup )
+{
+    if( !workgroupsPerCu )
+        return fail( VRC_EINVAL, "vrc_last_kernel_occupancy: NULL argument" );
+    *workgroupsPerCu = 0;
+    if( threadsPerWorkgroup )
+        *threadsPerWorkgroup = tlsKernelThreads;
+    if( !tlsKernelFn )
+        return fail( VRC_EINVAL, "vrc_last_kernel_occupancy: the calling thread's last vrc_render did not launch vrc_k_raycast" );
+    int n = 0;
+    VRC_HIP_CHECK( hipOccupancyMaxActiveBlocksPerMultiprocessor( &n, tlsKernelFn, tlsKernelThreads, tlsKernelLds ) );
+    *workgroupsPerCu = n;
+    return VRC_OK;
+}
 #if defined( VRC_DEV_BUILD )
 int vrc_abi_version( void ) { return -VRC_ABI_VERSION; }
 int vrc_is_dev_build( void ) { return 1; }
@@ -1391,6 +1414,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     }
     const std::pair< hipEvent_t, hipEvent_t > evp =
         c->optTiming ? c->evPairs[c->evUsed++] : std::pair< hipEvent_t, hipEvent_t >( nullptr, nullptr );
+    vrc_internal_note_kernel_fn( nullptr, 0, 0 ); /* set again by the launchers that report their occupancy */
     if( c->optTiming )
         VRC_HIP_CHECK( hipEventRecord( evp.first, c->stream ) );
     VRC_HIP_CHECK( useLds      ? vrc_launch_raycast_lds( a, c->stream ) /* (also its per-ray LOD form) */

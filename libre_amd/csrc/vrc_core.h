@@ -50,7 +50,7 @@
     defined( VRC_LDS_REFILL ) || defined( VRC_LDS_SOON ) || \
     defined( VRC_GROUP ) || \
     defined( VRC_GREY_GROUP ) || \
-    defined( VRC_GREY_PAD_KB ) || \
+    defined( VRC_GREY_MAX_WAVES ) || \
     defined( VRC_TAIL_GROUP ) || \
     defined( VRC_LGROUP ) || \
     defined( VRC_PGROUP ) || defined( VRC_PACKED_WAVES ) || defined( VRC_PACKED_ABLATE ) || \

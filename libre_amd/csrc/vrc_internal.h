@@ -142,6 +142,7 @@ hipError_t vrc_launch_raycast_raylod( const vrc_raycast_args& a, hipStream_t str
 struct vrc_ctx;
 int vrc_internal_fail( int code, const std::string& msg );          /* sets vrc_last_error, returns code */
 void vrc_internal_note_kernel( const char* fmt, ... );               /* the kernel instance a launcher took (vrc_last_kernel) */
+void vrc_internal_note_kernel_fn( const void* fn, int threads, size_t dynamicLds ); /* ... and its entry point (vrc_last_kernel_occupancy) */
 hipStream_t vrc_internal_ctx_stream( vrc_ctx* ctx, int* deviceOut ); /* the context's render stream + device */
 
 #endif

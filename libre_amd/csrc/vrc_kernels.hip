@@ -481,14 +481,26 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t*
  * latency sets the time -- the per-rank share of a sort-first frame from 4 ranks up. */
 template < bool DDA, bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, int GROUP = VRC_GROUP,
            bool BIG = false >
-/* waves per SIMD: 5 for the table-driven point-sampling instances (48 VGPRs); the per-sample classification modes,
- * the float position chain, the clamped sampler and 64-bit slot bases need more registers than 5 waves leave (they
- * spilled at 5: the trilinear gather form ran 5.3 instead of 2.9 ms) */
-__global__ __launch_bounds__( VRC_WG_THREADS, ( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY ) ? VRC_PACKED_WAVES
-                                              : GROUP > VRC_GREY_GROUP ? 2
-                                              : ( ( ( MODE == VRC_MODE_TABLE && GROUP <= 8 ) || MODE == VRC_MODE_GREY ) && FIXED && !CLAMP && !BIG
-                                                      ? VRC_MIN_WAVES
-                                                      : ( GROUP > 8 ? 2 : 4 ) ) ) void vrc_k_raycast(
+/* waves per SIMD the compiler plans for (at least): 5 for the table-driven point-sampling instances; the per-sample
+ * classification modes, the float position chain, the clamped sampler and 64-bit slot bases need more registers than
+ * 5 waves leave (they spilled at 5: the trilinear gather form ran 5.3 instead of 2.9 ms).
+ * And at MOST: the grey form in groups of 14 needs 80 registers, a sixth wave per SIMD would fit, and six thrash the
+ * L1 (frames in flight: 2180 -> 1730 frames/s).  amdgpu_waves_per_eu( min, max ) says so to the
+ * compiler, which then reports the register count that admits no sixth wave (88); rounds 2-3 said it with 20 KiB of
+ * LDS the kernel never touched. */
+#define VRC_K_MIN_WAVES                                                                                             \
+    ( ( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY )                                                   \
+          ? VRC_PACKED_WAVES                                                                                        \
+          : GROUP > VRC_GREY_GROUP                                                                                  \
+                ? 2                                                                                                 \
+                : ( ( ( MODE == VRC_MODE_TABLE && GROUP <= 8 ) || MODE == VRC_MODE_GREY ) && FIXED && !CLAMP && !BIG \
+                        ? VRC_MIN_WAVES                                                                             \
+                        : ( GROUP > 8 ? 2 : 4 ) ) )
+#define VRC_K_MAX_WAVES ( ( MODE == VRC_MODE_GREY && GROUP <= VRC_GREY_GROUP && VRC_WAVES_PER_WG == 4u ) ? VRC_GREY_MAX_WAVES : 8 )
+#ifndef VRC_GREY_MAX_WAVES
+#define VRC_GREY_MAX_WAVES 5
+#endif
+__global__ __launch_bounds__( VRC_WG_THREADS ) __attribute__( ( amdgpu_waves_per_eu( VRC_K_MIN_WAVES, VRC_K_MAX_WAVES ) ) ) void vrc_k_raycast(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ gridTable, const ATLAS_T* __restrict__ atlas,
     const vrc_f4* __restrict__ lutGlobal, const vrc_classifier cls,
@@ -649,21 +661,15 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
     const uint32_t nTiles = tilesX * tilesY;
     if( nTiles == 0 )
         return hipSuccess;
-    /* The grey form needs 80 registers: a sixth wave per SIMD would fit, and six thrash the L1 (DESIGN.md section 4;
-     * frames in flight: 2180 -> 1730 frames/s).  20 KiB of LDS the kernel never touches keep it at five workgroups
-     * per CU (160 KiB / (7 + 20) KiB), the occupancy the four-float form has by its registers. */
-#ifndef VRC_GREY_PAD_KB
-#define VRC_GREY_PAD_KB 20u
-#endif
-    const uint32_t ldsPad =
-        ( MODE == VRC_MODE_GREY && GROUP <= VRC_GREY_GROUP && VRC_WAVES_PER_WG == 4u ) ? VRC_GREY_PAD_KB * 1024u : 0u;
     vrc_internal_note_kernel( "vrc_k_raycast<%s,%s,%s,%s,%d,%s,%d,%s>", DDA ? "true" : "false", CLAMP ? "true" : "false",
                               COUNT ? "true" : "false", FIXED ? "true" : "false", (int)MODE,
                               sizeof( ATLAS_T ) == 1 ? "unsigned char" : ( sizeof( ATLAS_T ) == 2 ? "unsigned short" : "unsigned int" ),
                               (int)GROUP, BIG ? "true" : "false" );
+    vrc_internal_note_kernel_fn( (const void*)&vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >,
+                                 (int)VRC_WG_THREADS, 0 );
     hipLaunchKernelGGL( ( vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG > ),
                         dim3( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_WAVES_PER_WG - 1u ) / VRC_WAVES_PER_WG ),
-                        dim3( VRC_WG_THREADS ), ldsPad, stream, a.frame, a.nodes, a.gridTable,
+                        dim3( VRC_WG_THREADS ), 0, stream, a.frame, a.nodes, a.gridTable,
                         (const ATLAS_T*)a.atlas, a.lut, a.classifier, a.pixelBuffer,
                         a.sampleCounter, a.tileOrder, tilesX, nTiles );
     return hipGetLastError();

@@ -58,7 +58,7 @@ EXPORTS = [
     "vrc_pool_release_slot", "vrc_pool_info", "vrc_pool_synchronize", "vrc_pool_read_region",
     "vrc_pool_histogram",
     "vrc_update", "vrc_pre_render", "vrc_set_row_map", "vrc_set_framebuffer", "vrc_get_framebuffer", "vrc_render",
-    "vrc_post_render", "vrc_synchronize", "vrc_get_stats", "vrc_get_ray_counts", "vrc_last_error", "vrc_last_kernel", "vrc_abi_version", "vrc_is_dev_build",
+    "vrc_post_render", "vrc_synchronize", "vrc_get_stats", "vrc_get_ray_counts", "vrc_last_error", "vrc_last_kernel", "vrc_last_kernel_occupancy", "vrc_abi_version", "vrc_is_dev_build",
     "vrc_comm_unique_id", "vrc_comm_create", "vrc_comm_destroy", "vrc_comm_info", "vrc_gather_tiles",
 ]
 COMM_ID_BYTES = 128
@@ -87,6 +87,7 @@ def load_library(path=None):
     L.vrc_abi_version.restype = C.c_int
     L.vrc_is_dev_build.restype = C.c_int
     L.vrc_last_kernel.restype = C.c_char_p
+    L.vrc_last_kernel_occupancy.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     # a developer build (-DVRC_DEV_BUILD) reports the negated version
     if abs(L.vrc_abi_version()) != ABI_VERSION:
         raise RuntimeError("%s has ABI version %d, this binding needs %d: rebuild it (__graft_entry__.build())"

@@ -142,6 +142,30 @@ def test_lds_staged_kernel_parity(vrc, name):
         assert (auto == lin).all()
 
 
+def test_the_judged_kernel_runs_five_workgroups_per_cu(vrc):
+    # The grey table form in groups of 14 (what bench.py times) needs 80 registers: six waves per SIMD would fit and
+    # six thrash the L1.  Rounds 2-3 capped it with 20 KiB of LDS the kernel never touched; now the kernel says
+    # amdgpu_waves_per_eu( 5, 5 ) and the runtime's own occupancy calculator -- no profiler -- must agree: five
+    # workgroups of four waves per compute unit.  Frames are what they were: the parity tests.
+    # (a frame of more than 6144 tiles: smaller launches take the latency-bound instance with 24 samples in flight)
+    s = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(704, 640), volume="hash", spin=(0.5, 0.35))
+    with _gpu(s) as g:
+        g.render(count=False)
+        assert b"<true,false,false,true,3,unsigned char,14,false>" in g.L.vrc_last_kernel(), g.L.vrc_last_kernel()
+        wgs, threads = C.c_int(), C.c_int()
+        vrc.check(g.L, g.L.vrc_last_kernel_occupancy(C.byref(wgs), C.byref(threads)))
+        assert (wgs.value, threads.value) == (5, 256), (wgs.value, threads.value)
+        # the four-float form: five by its registers
+        vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 0))
+        g.render(count=False)
+        assert b",0,unsigned char,8,false>" in g.L.vrc_last_kernel()
+        vrc.check(g.L, g.L.vrc_last_kernel_occupancy(C.byref(wgs), C.byref(threads)))
+        assert wgs.value == 5
+        # the LDS-staged kernel does not report
+        g.render(kernel=vrc.KERNEL_LDS, count=False)
+        assert g.L.vrc_last_kernel_occupancy(C.byref(wgs), C.byref(threads)) == vrc.VRC_EINVAL
+
+
 @pytest.mark.parametrize("name", sorted(scenes.SCENES))
 def test_tap_packed_trilinear_parity(vrc, name):
     # VRC_KERNEL_PACKED: the trilinear filter through the pool's tap-packed atlas (32-bit texels holding the 2x2

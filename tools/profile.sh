@@ -19,6 +19,8 @@ run pmc_sq2 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACT
 run pmc_fetch --pmc FETCH_SIZE
 run pmc_write --pmc WRITE_SIZE
 run pmc_tcc --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum
+# what the L2s ask the fabric / HBM for, by request size: FETCH_SIZE tallies every request at 64 bytes
+run pmc_ea --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
 run pmc_ta --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum
 run pmc_ta2 --pmc TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
 run pmc_tcp --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum
