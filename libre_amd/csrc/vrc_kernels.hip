@@ -430,8 +430,10 @@ __global__ __launch_bounds__( 256 ) void vrc_k_tile_scatter( const uint32_t nSup
             const uint32_t uy = ( ( u >> 1 ) & 1u ) | ( ( u >> 2 ) & 2u ) | ( ( u >> 3 ) & 4u ) | ( ( u >> 4 ) & 8u );
             const uint32_t x = sx * VRC_SUPER_UNITS + ux, y = sy * VRC_SUPER_UNITS + uy;
             /* the workgroup: VRC_WAVES_PER_WG / 4 consecutive units of the super-tile's Morton order (one in the product) */
-            constexpr uint32_t U = VRC_WAVES_PER_WG / 4u;
-            const uint32_t g = VRC_XCDS * ( row * ( VRC_SUPER_UNITS * VRC_SUPER_UNITS / U ) + u / U ) + xcd;
+            /* (developer builds with fewer than four waves per workgroup: the units in rank order, as in rounds 1-3) */
+            constexpr uint32_t U = VRC_WAVES_PER_WG >= 4u ? VRC_WAVES_PER_WG / 4u : 1u;
+            const uint32_t g = VRC_WAVES_PER_WG >= 4u ? VRC_XCDS * ( row * ( VRC_SUPER_UNITS * VRC_SUPER_UNITS / U ) + u / U ) + xcd
+                                                      : r * VRC_SUPER_UNITS * VRC_SUPER_UNITS + u;
 #pragma unroll
             for( uint32_t sub = 0; sub < 4u; ++sub )
                 order[( g * U + u % U ) * 4u + sub] = ( x < unitsX && y < unitsY ) ? vrc_unit_tile( y * unitsX + x, sub, frameTilesX, frameTilesY )
@@ -471,6 +473,20 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t*
 #endif
 #ifndef VRC_PACKED_WAVES
 #define VRC_PACKED_WAVES 4 /* (developer switch; 6 and 8 measured slower on C2) */
+#endif
+#if defined( VRC_WG_TIMELINE )
+/* developer build (tools/dev_timeline.py): when every wave of the last launch started and ended
+ * (s_memrealtime: one 100 MHz clock for the whole chip) and where it ran (HW_ID, XCC_ID) */
+struct vrc_wave_stamp
+{
+    unsigned long long start, end;
+    uint32_t hwId, xccId;
+};
+__device__ vrc_wave_stamp vrc_timeline[1u << 16];
+extern "C" int vrc_dev_read_timeline( void* out, size_t bytes )
+{
+    return (int)hipMemcpyFromSymbol( out, HIP_SYMBOL( vrc_timeline ), bytes < sizeof( vrc_timeline ) ? bytes : sizeof( vrc_timeline ) );
+}
 #endif
 #ifndef VRC_MIN_WAVES
 #define VRC_MIN_WAVES 5 /* measured on C2: 4 -> 5 waves per SIMD with four-wave workgroups: -2 % */
@@ -513,6 +529,25 @@ __global__ __launch_bounds__( VRC_WG_THREADS ) __attribute__( ( amdgpu_waves_per
     __shared__ uint16_t vrc_tile_cand[DDA ? 1u : VRC_WAVES_PER_WG * VRC_TILE_CANDIDATES];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
+#if defined( VRC_WG_TIMELINE )
+    struct vrc_stamp_scope
+    {
+        uint32_t index;
+        bool on;
+        unsigned long long t0;
+        __device__ vrc_stamp_scope( uint32_t i, bool o ) : index( i & 0xFFFFu ), on( o ), t0( wall_clock64() ) {}
+        __device__ ~vrc_stamp_scope()
+        {
+            if( on )
+            {
+                vrc_timeline[index].start = t0;
+                vrc_timeline[index].end = wall_clock64();
+                vrc_timeline[index].hwId = __builtin_amdgcn_s_getreg( ( 31 << 11 ) | 4 );
+                vrc_timeline[index].xccId = __builtin_amdgcn_s_getreg( ( 3 << 11 ) | 20 );
+            }
+        }
+    } vrc_stamp( blockIdx.x * VRC_WAVES_PER_WG + ( tid >> 6 ), lane == 0u );
+#endif
     if( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY )
     {
         /* the packed march's classifier table (vrc_cls8_entry) from the padded transfer function */

@@ -14,7 +14,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cerrno>
 #include <cstring>
+#include <ctime>
 #include <fstream>
 #include <map>
 #include <memory>
@@ -467,6 +469,7 @@ private:
         else throw std::runtime_error( "Not supported data format" );
     }
     /* level k of the pyramid: voxel (x,y,z) = file voxel (x<<k, y<<k, z<<k) */
+    static constexpr uint32_t kMaxPyramidLevels = 32u;
     struct PyramidLevel
     {
         std::unique_ptr< uint8_t[] > owned; /* built in this process ... */
@@ -483,7 +486,13 @@ private:
         }
         /* whatever is missing is built up to the coarsest level of the tree (each level is an eighth of the one
          * below): the file then holds the whole pyramid */
-        const uint32_t top = std::max( k, _volumeInfo.rootNode.getDepth() - 1u );
+        const uint32_t depth = _volumeInfo.rootNode.getDepth();
+        const uint32_t top = std::max( k, depth > 0u ? depth - 1u : 0u );
+        /* references to levels are handed out and used after the lock is gone: the vector never reallocates */
+        if( top >= kMaxPyramidLevels )
+            throw std::runtime_error( "raw://: LOD pyramid of more than 32 levels" );
+        if( _pyramid.capacity() < kMaxPyramidLevels )
+            _pyramid.reserve( kMaxPyramidLevels );
         if( _pyramid.size() <= top )
             _pyramid.resize( top + 1 );
         bool built = false;
@@ -542,13 +551,16 @@ private:
         return _pyramid[k];
     }
 
-    /* ---- the pyramid on disk (round 3) ---------------------------------------------------------------------
-     * <volume file>.lvpyr (or $LIVRE_HIP_PYRAMID_DIR/<file name>.lvpyr; LIVRE_HIP_PYRAMID=0 turns it off): header
-     * { "LVPYR001", size and mtime of the volume file, voxels, bytes per voxel, data offset, levels }, then per level
-     * { dim[3], offset }, then the levels, 4096-aligned.  Written once by the first run that has built every
-     * level (temporary file + rename, best effort: a read-only directory just means the next run builds again),
-     * mapped by later runs after the header has been checked against the volume file as it is now.  The 2048^3
-     * uint16 volume of BASELINE C3 spends 0.26 s of every start-up on the levels otherwise. */
+    /* ---- the pyramid on disk (round 3; opt-in since round 4) ---------------------------------------------------
+     * OFF by default: a renderer does not leave files in the user's data directory unasked (round-3 advisor).
+     * LIVRE_HIP_PYRAMID_DIR=<dir> keeps <dir>/<file name>.lvpyr; LIVRE_HIP_PYRAMID=1 keeps <volume file>.lvpyr next to
+     * the volume.  Header { "LVPYR001", size and mtime of the volume file, voxels, bytes per voxel, data offset,
+     * levels }, then per level { dim[3], offset }, then the levels, 4096-aligned.  Written once by the first process
+     * that has built every level -- through <path>.writing, created with O_EXCL, so that of N ranks starting together
+     * one writes and the others go on with what they built (a .writing file older than ten minutes is a crashed
+     * writer's and is replaced) -- then renamed; best effort: a read-only directory just means the next run builds
+     * again.  Mapped by later runs after the header has been checked against the volume file as it is now.  The
+     * 2048^3 uint16 volume of BASELINE C3 spends 0.26 s of every start-up on the levels otherwise. */
     struct PyramidFileHeader
     {
         char magic[8];
@@ -561,8 +573,8 @@ private:
     };
     std::string pyramidPath() const
     {
-        const char* off = ::getenv( "LIVRE_HIP_PYRAMID" );
-        if( off && off[0] == '0' )
+        const char* on = ::getenv( "LIVRE_HIP_PYRAMID" );
+        if( on && on[0] == '0' )
             return std::string();
         const char* dir = ::getenv( "LIVRE_HIP_PYRAMID_DIR" );
         if( dir && dir[0] )
@@ -570,7 +582,9 @@ private:
             const size_t slash = _dataFile.find_last_of( '/' );
             return std::string( dir ) + "/" + ( slash == std::string::npos ? _dataFile : _dataFile.substr( slash + 1 ) ) + ".lvpyr";
         }
-        return _dataFile + ".lvpyr";
+        if( on && on[0] == '1' )
+            return _dataFile + ".lvpyr";
+        return std::string(); /* not asked for */
     }
     bool fillHeader( PyramidFileHeader& h ) const
     {
@@ -644,10 +658,23 @@ private:
         PyramidFileHeader h;
         if( path.empty() || !fillHeader( h ) || h.levels == 0 || _pyramid.size() <= h.levels )
             return;
-        const std::string tmp = path + "." + std::to_string( ::getpid() ) + ".tmp";
-        FILE* f = std::fopen( tmp.c_str(), "wb" );
+        const std::string tmp = path + ".writing";
+        int wfd = ::open( tmp.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0644 );
+        if( wfd == -1 && errno == EEXIST )
+        {
+            struct stat ts;
+            if( ::stat( tmp.c_str(), &ts ) == 0 && ::time( nullptr ) - ts.st_mtime > 600 && ::unlink( tmp.c_str() ) == 0 )
+                wfd = ::open( tmp.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0644 );
+        }
+        if( wfd == -1 )
+            return; /* another process is writing it, or the directory is not ours to write */
+        FILE* f = ::fdopen( wfd, "wb" );
         if( !f )
+        {
+            ::close( wfd );
+            std::remove( tmp.c_str() );
             return;
+        }
         std::vector< PyramidFileLevel > tl( h.levels );
         uint64_t at = ( sizeof( h ) + h.levels * sizeof( PyramidFileLevel ) + 4095u ) & ~uint64_t( 4095 );
         for( uint32_t l = 1; l <= h.levels; ++l )

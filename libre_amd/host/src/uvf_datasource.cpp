@@ -283,24 +283,46 @@ private:
         /* walk the chain of data blocks (UVFDataSource.cpp:152-165 stops at the first table of contents; Tuvok's
          * UVFDataset::Open takes every TOC block as one time step, and GetNumberOfTimesteps() -- the reference's
          * frame range, :144 -- counts them) */
+        /* The reference stops at the first table of contents, so a file whose LATER blocks are damaged, truncated or of
+         * another shape opens fine there: here the walk ends at such a block and keeps the time steps read so far
+         * (round-3 advisor); only a file without one good table of contents fails to open. */
         bool first = true;
         for( ;; )
         {
             const size_t blockStart = r.pos;
-            const uint64_t idLength = r.get< uint64_t >();
-            r.skip( size_t( idLength ) );
-            const uint64_t semantics = r.get< uint64_t >();
-            r.get< uint64_t >(); /* block compression scheme */
-            const uint64_t next = r.get< uint64_t >();
-            if( semantics == BS_TOC_BLOCK )
+            const VolumeInformation infoBefore = _volumeInfo;
+            const std::vector< Vector3ui > lodSizeBefore = _lodSize;
+            const std::vector< size_t > lodFirstBefore = _lodFirstEntry;
+            uint64_t next = 0;
+            try
             {
-                parseTocBlock( r, first );
-                first = false;
+                const uint64_t idLength = r.get< uint64_t >();
+                r.skip( size_t( idLength ) );
+                const uint64_t semantics = r.get< uint64_t >();
+                r.get< uint64_t >(); /* block compression scheme */
+                next = r.get< uint64_t >();
+                /* a block is at least its own header: a chain that steps by less would be parsed byte by byte */
+                if( next != 0 && next < uint64_t( r.pos - blockStart ) )
+                    throw std::runtime_error( "UVF data format initialization failed" );
+                if( semantics == BS_TOC_BLOCK )
+                {
+                    parseTocBlock( r, first );
+                    first = false;
+                }
+                if( next != 0 && ( next > _size || blockStart > _size - size_t( next ) ) )
+                    throw std::runtime_error( "UVF data format initialization failed" );
+            }
+            catch( const std::exception& )
+            {
+                if( _steps.empty() )
+                    throw;
+                _volumeInfo = infoBefore;
+                _lodSize = lodSizeBefore;
+                _lodFirstEntry = lodFirstBefore;
+                break;
             }
             if( next == 0 )
                 break;
-            if( next > _size || blockStart > _size - size_t( next ) )
-                throw std::runtime_error( "UVF data format initialization failed" );
             r.pos = blockStart + size_t( next );
         }
         if( _steps.empty() )

@@ -444,3 +444,23 @@ def test_parity_rule_rejects_a_biased_kernel(name):
     assert scenes.tie_bias(biased, want, flipped) > 0.9
     with pytest.raises(AssertionError):
         scenes.assert_no_tie_bias(biased, want, flipped, name + " biased")
+
+
+def test_the_parity_contract_is_frozen():
+    # rounds 2-3 re-based the rule's constants after soak failures; since round 4 they are a contract.  A
+    # change to any of them must change this test too, in the open (and DESIGN.md section 2's table with it).
+    frozen = dict(E0=5e-5, TIE_FACTOR=2.0, MAX_ABS_CAP=6e-3, MEAN_ABS_CAP=3e-4, MEAN_E0=2e-5, BUDGET_USE=0.5, NEEDS_BUDGET=0.7,
+                  STRONG_SAMPLE=1e-2, MAX_ABS_CAP_STRONG=3e-2, MEAN_ABS_CAP_STRONG=1.5e-3, NEEDS_BUDGET_STRONG=0.95,
+                  TIE_BIAS_MAX=0.35, RAY_LOD_ALLOW=5e-4)
+    for name, value in frozen.items():
+        assert getattr(scenes, name) == value, name
+    assert not hasattr(scenes, "OPAQUE_ALPHA")
+    for name in frozen:
+        assert ("%g" % frozen[name]) in scenes.rule_string() or name in ("TIE_FACTOR",), name
+    # which frames get the looser caps: by the largest classified opacity of one sample alone
+    s = scenes.get("hash64_spin")  # the alpha-0.05 ramp at the automatic 512 samples per ray: weak samples, tight caps
+    a = float(np.asarray(s.tf).reshape(-1, 4)[:, 3].max())
+    assert 1.0 - (1.0 - a) ** (32.0 / s.render.samplesPerRay) < scenes.STRONG_SAMPLE
+    n = scenes.nucleon_scene()  # alpha 0.3 at 512: strong
+    a = float(np.asarray(n.tf).reshape(-1, 4)[:, 3].max())
+    assert 1.0 - (1.0 - a) ** (32.0 / n.render.samplesPerRay) > scenes.STRONG_SAMPLE

@@ -240,7 +240,8 @@ def test_raw_data_source_bricked_out_of_core(drv, tmp_path, dtype):
 def test_raw_pyramid_is_kept_on_disk(drv, tmp_path, monkeypatch):
     # the LOD pyramid of a bricked raw:// volume: the first run that builds it leaves <file>.lvpyr next to the volume,
     # later runs map it (datasource_brick opens the source anew every call = a new "run"); a file that belongs to
-    # other data is recognised (size / mtime / shape in its header) and replaced; LIVRE_HIP_PYRAMID=0 turns it off
+    # other data is recognised (size / mtime / shape in its header) and replaced.  Opt-in: LIVRE_HIP_PYRAMID=1 (next to the
+    # volume) or LIVRE_HIP_PYRAMID_DIR (a cache directory); one writer among processes that start together
     vol = orc.hash_volume(48, 32, 64).astype(np.uint16) * np.uint16(257)
     path = str(tmp_path / "vol.raw")
     vol.tofile(path)
@@ -248,12 +249,17 @@ def test_raw_pyramid_is_kept_on_disk(drv, tmp_path, monkeypatch):
     vi = orc.mem_volume_info(48, 32, 64, 16)
     coarse = orc.pack(vi.depth - 2, 0, 0, 0)
     pyr = path + ".lvpyr"
-    monkeypatch.setenv("LIVRE_HIP_PYRAMID", "0")
+    # opt-in (round 4): nothing is written next to the user's data unless asked for
+    monkeypatch.delenv("LIVRE_HIP_PYRAMID", raising=False)
+    monkeypatch.delenv("LIVRE_HIP_PYRAMID_DIR", raising=False)
     first = drv.datasource_brick(uri, coarse).copy()
-    assert not os.path.exists(pyr)
-    monkeypatch.delenv("LIVRE_HIP_PYRAMID")
+    assert os.listdir(str(tmp_path)) == ["vol.raw"]
+    monkeypatch.setenv("LIVRE_HIP_PYRAMID", "0")
     assert (drv.datasource_brick(uri, coarse) == first).all()
-    assert os.path.exists(pyr) and open(pyr, "rb").read(8) == b"LVPYR001"
+    assert os.listdir(str(tmp_path)) == ["vol.raw"]
+    monkeypatch.setenv("LIVRE_HIP_PYRAMID", "1")
+    assert (drv.datasource_brick(uri, coarse) == first).all()
+    assert sorted(os.listdir(str(tmp_path))) == ["vol.raw", "vol.raw.lvpyr"] and open(pyr, "rb").read(8) == b"LVPYR001"
     size = os.path.getsize(pyr)
     # served from the file: poison the file's first level and see the poison come back
     raw = bytearray(open(pyr, "rb").read())
@@ -280,7 +286,17 @@ def test_raw_pyramid_is_kept_on_disk(drv, tmp_path, monkeypatch):
     cache.mkdir()
     monkeypatch.setenv("LIVRE_HIP_PYRAMID_DIR", str(cache))
     assert (drv.datasource_brick(uri, coarse).view(np.uint16) == fresh).all()
-    assert os.path.exists(str(cache / "vol.raw.lvpyr"))
+    assert os.listdir(str(cache)) == ["vol.raw.lvpyr"]
+    # a writer that is still at it (or crashed a moment ago) keeps the others out: they render from what they built
+    os.remove(str(cache / "vol.raw.lvpyr"))
+    open(str(cache / "vol.raw.lvpyr.writing"), "wb").close()
+    assert (drv.datasource_brick(uri, coarse).view(np.uint16) == fresh).all()
+    assert os.listdir(str(cache)) == ["vol.raw.lvpyr.writing"]
+    # ... and a ten-minute-old one is a crashed writer's
+    old = os.stat(str(cache / "vol.raw.lvpyr.writing")).st_mtime - 1000
+    os.utime(str(cache / "vol.raw.lvpyr.writing"), (old, old))
+    assert (drv.datasource_brick(uri, coarse).view(np.uint16) == fresh).all()
+    assert os.listdir(str(cache)) == ["vol.raw.lvpyr"]
 
 
 def _uvf_python_decoder(path):
@@ -427,6 +443,46 @@ def test_uvf_time_steps(drv, tmp_path):
     # a frame outside the range is refused
     with pytest.raises(RuntimeError):
         drv.datasource_brick(uri, orc.pack(1, 0, 0, 0, 2))
+
+
+def test_uvf_damaged_trailing_blocks_do_not_fail_the_open(drv, tmp_path):
+    # The reference stops reading at the first table of contents (UVFDataSource.cpp:152-165), so a file whose later
+    # blocks are truncated or malformed opens there; taking every TOC block as a time step must not turn such a file
+    # into an error (round-3 advisor): the walk ends at the bad block and keeps the steps read so far.
+    import struct
+    path = _two_time_step_uvf(tmp_path)
+    good = bytearray(open(path, "rb").read())
+    whole = "uvf://" + path
+    assert drv.datasource_frame_range(whole) == (0, 2)
+    pos = 9 + 24 + struct.unpack_from("<Q", good, 25)[0] + 8
+    start = pos
+    while True:  # the last block of the chain = the appended second table of contents
+        n, = struct.unpack_from("<Q", good, start)
+        nxt, = struct.unpack_from("<Q", good, start + 8 + n + 16)
+        if nxt == 0:
+            break
+        start += nxt
+    second, n2 = start, n
+    # (a) the second TOC block cut off in the middle of its table
+    cut = str(tmp_path / "cut.uvf")
+    open(cut, "wb").write(good[:second + 8 + n2 + 24 + 105 + 150])
+    assert drv.datasource_frame_range("uvf://" + cut) == (0, 1)
+    assert drv.datasource_info("uvf://" + cut)["voxels"] == [75, 75, 138]
+    # (b) a "next" field smaller than the block's own header (would be re-parsed byte by byte): the chain ends there
+    tiny = bytearray(good)
+    struct.pack_into("<Q", tiny, second + 8 + n2 + 16, 3)
+    tp = str(tmp_path / "tiny_next.uvf")
+    open(tp, "wb").write(tiny)
+    assert drv.datasource_frame_range("uvf://" + tp)[0] == 0 and drv.datasource_frame_range("uvf://" + tp)[1] >= 1
+    # the first step still reads
+    py = _uvf_python_decoder(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mouse_reduced.uvf"))
+    got = drv.datasource_brick("uvf://" + cut, orc.pack(1, 1, 0, 0, 0))
+    assert (got.reshape(py["get"](0, 1, 0, 0).shape) == py["get"](0, 1, 0, 0)).all()
+    # a file without ONE good table of contents still fails
+    bad = str(tmp_path / "bad.uvf")
+    open(bad, "wb").write(good[:pos + 200])
+    with pytest.raises(RuntimeError):
+        drv.datasource_frame_range("uvf://" + bad)
 
 
 def test_host_library_under_sanitizers(tmp_path):

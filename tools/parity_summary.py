@@ -4,15 +4,18 @@ largest and the mean error, the pixels' tie budgets and by how much the worst pi
 (<= 0: inside the rule).  usage: python tools/parity_summary.py stats.jsonl [stats2.jsonl ...] > out.json"""
 import collections
 import json
+import os
 import sys
 
-E0, F = 5e-5, 2.0
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import scenes  # noqa: E402  (the rule is printed from the constants it is enforced with)
+
 by = collections.OrderedDict()
 for path in sys.argv[1:]:
     for line in open(path):
         r = json.loads(line)
         by.setdefault(r["test"], []).append(r)
-out = {"rule": "|frame - oracle| <= E0 + 2 x tie budget per pixel, E0 = 5e-5; per frame max <= 6e-3, mean <= 3e-4, mean <= 2e-5 + 0.15 x mean budget, <= 0.7 of the pixels over E0 (tests/scenes.py)",
+out = {"rule": scenes.rule_string(),
        "where": "MI355X, pytest -m gpu" if "gpu" in " ".join(sys.argv[1:]) else "host build of the kernel code",
        "tests": {}}
 for t, rs_all in by.items():
