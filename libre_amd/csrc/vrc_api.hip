@@ -1170,8 +1170,6 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
          * the gather form, LDS for the staged one */
         if( c->optKernel == VRC_KERNEL_REFERENCE_ORDER )
             return fail( VRC_EINVAL, "vrc_render: per-ray LOD walks the hierarchy; VRC_OPT_KERNEL = AUTO, GRID_DDA (gathers) or LDS" );
-        if( pool->bigAtlas )
-            return fail( VRC_EHIERARCHY, "vrc_render: per-ray LOD is not available in atlases of more than 2^32 voxels" );
     }
     bool useDda = c->cachedGridOk;
     /* AUTO keeps the reference's frame: bricks of one size are met by the grid walk in the reference's

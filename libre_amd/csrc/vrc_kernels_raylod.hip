@@ -22,7 +22,9 @@
 #ifndef VRC_RL_MIN_BLOCKS
 #define VRC_RL_MIN_BLOCKS 2
 #endif
-template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T >
+/* BIG: an atlas of more than 2^32 voxels (BASELINE C3's 22.6 GB): 64-bit slot bases, float positions, as the BIG
+ * instances of vrc_k_raycast (round 4: per-ray LOD was not offered for such a pool) */
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, bool BIG = false >
 __global__ __launch_bounds__( VRC_RL_THREADS, VRC_RL_MIN_BLOCKS ) void vrc_k_raycast_raylod(
     const vrc_frame f, const vrc_dev_node* __restrict__ nodes,
     const int32_t* __restrict__ levelTables, const ATLAS_T* __restrict__ atlas,
@@ -76,8 +78,8 @@ __global__ __launch_bounds__( VRC_RL_THREADS, VRC_RL_MIN_BLOCKS ) void vrc_k_ray
 
     uint32_t nSamples = 0;
     if( px < f.width && py < f.height )
-        vrc_pixel_ray_lod< CLAMP, COUNT, FIXED, MODE, ATLAS_T >( f, nodes, levelTables, atlas, lutLevels,
-                                                                 cls, pixelBuffer, px, py, nSamples );
+        vrc_pixel_ray_lod< CLAMP, COUNT, FIXED, MODE, ATLAS_T, VRC_GROUP, BIG >( f, nodes, levelTables, atlas, lutLevels,
+                                                                                 cls, pixelBuffer, px, py, nSamples );
     if( COUNT )
     {
         unsigned long long s = nSamples;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__( VRC_RL_THREADS, VRC_RL_MIN_BLOCKS ) void vrc_k_ray
     }
 }
 
-template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T >
+template < bool CLAMP, bool COUNT, bool FIXED, int MODE, typename ATLAS_T, bool BIG = false >
 static hipError_t launch_raylod( const vrc_raycast_args& a, hipStream_t stream )
 {
     const uint32_t tilesX = ( a.frame.width + 7u ) / 8u, tilesY = ( a.frame.height + 7u ) / 8u;
@@ -99,9 +101,10 @@ static hipError_t launch_raylod( const vrc_raycast_args& a, hipStream_t stream )
     const uint32_t lutEntries = ( MODE == VRC_MODE_TABLE || MODE == VRC_MODE_GREY )
                                     ? a.frame.lodLevels * VRC_LUT_ENTRIES
                                     : VRC_TFP_ENTRIES;
-    vrc_internal_note_kernel( "vrc_k_raycast_raylod<%s,%s,%s,%d,%s>", CLAMP ? "true" : "false", COUNT ? "true" : "false",
-                              FIXED ? "true" : "false", (int)MODE, sizeof( ATLAS_T ) == 1 ? "unsigned char" : "unsigned short" );
-    hipLaunchKernelGGL( ( vrc_k_raycast_raylod< CLAMP, COUNT, FIXED, MODE, ATLAS_T > ),
+    vrc_internal_note_kernel( "vrc_k_raycast_raylod<%s,%s,%s,%d,%s,%s>", CLAMP ? "true" : "false", COUNT ? "true" : "false",
+                              FIXED ? "true" : "false", (int)MODE, sizeof( ATLAS_T ) == 1 ? "unsigned char" : "unsigned short",
+                              BIG ? "true" : "false" );
+    hipLaunchKernelGGL( ( vrc_k_raycast_raylod< CLAMP, COUNT, FIXED, MODE, ATLAS_T, BIG > ),
                         dim3( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_RL_WAVES - 1u ) / VRC_RL_WAVES ),
                         dim3( VRC_RL_THREADS ),
                         lutEntries * ( MODE == VRC_MODE_GREY ? sizeof( vrc_f2 ) : sizeof( vrc_f4 ) ), stream, a.frame,
@@ -111,15 +114,15 @@ static hipError_t launch_raylod( const vrc_raycast_args& a, hipStream_t stream )
     return hipGetLastError();
 }
 
-template < int MODE, typename ATLAS_T >
+template < int MODE, typename ATLAS_T, bool BIG = false >
 static hipError_t launch_raylod_classify( const vrc_raycast_args& a, bool count, hipStream_t stream )
 {
     switch( ( a.clamp ? 2 : 0 ) | ( count ? 1 : 0 ) )
     {
-    case 0: return launch_raylod< false, false, false, MODE, ATLAS_T >( a, stream );
-    case 1: return launch_raylod< false, true, false, MODE, ATLAS_T >( a, stream );
-    case 2: return launch_raylod< true, false, false, MODE, ATLAS_T >( a, stream );
-    default: return launch_raylod< true, true, false, MODE, ATLAS_T >( a, stream );
+    case 0: return launch_raylod< false, false, false, MODE, ATLAS_T, BIG >( a, stream );
+    case 1: return launch_raylod< false, true, false, MODE, ATLAS_T, BIG >( a, stream );
+    case 2: return launch_raylod< true, false, false, MODE, ATLAS_T, BIG >( a, stream );
+    default: return launch_raylod< true, true, false, MODE, ATLAS_T, BIG >( a, stream );
     }
 }
 
@@ -128,9 +131,20 @@ static hipError_t launch_raylod_classify( const vrc_raycast_args& a, bool count,
 hipError_t vrc_launch_raycast_raylod( const vrc_raycast_args& a, hipStream_t stream )
 {
     if( a.frame.lodLevels < 1 || a.frame.lodLevels > VRC_MAX_LOD_LEVELS || !a.gridTable ||
-        a.frame.variant != VRC_VARIANT_CUDA || a.bigAtlas /* 32-bit slot bases only */ )
+        a.frame.variant != VRC_VARIANT_CUDA )
         return hipErrorInvalidValue;
     const bool count = a.sampleCounter != nullptr;
+    if( a.bigAtlas )
+    {
+        /* 64-bit slot bases: float positions (the classified tables of the levels for 8-bit point sampling) */
+        if( a.elemBytes == 2 )
+            return a.linear ? launch_raylod_classify< VRC_MODE_TRILINEAR, uint16_t, true >( a, count, stream )
+                            : launch_raylod_classify< VRC_MODE_POINT, uint16_t, true >( a, count, stream );
+        if( a.elemBytes != 1 )
+            return hipErrorInvalidValue;
+        return a.linear ? launch_raylod_classify< VRC_MODE_TRILINEAR, uint8_t, true >( a, count, stream )
+                        : launch_raylod_classify< VRC_MODE_TABLE, uint8_t, true >( a, count, stream );
+    }
     if( a.elemBytes == 2 )
         return a.linear ? launch_raylod_classify< VRC_MODE_TRILINEAR, uint16_t >( a, count, stream )
                         : launch_raylod_classify< VRC_MODE_POINT, uint16_t >( a, count, stream );

@@ -1067,14 +1067,21 @@ struct HipRaycastPipeline::Impl
      * Returns false (nothing rendered) if even the thinnest slab does not fit, there is no room for two planes, or no
      * axis orders the slabs for every ray (round 4: round 3 took the axis from centre - eye, which composites the
      * rays that run the other way back to front -- eye inside the hierarchy, or outside it on another axis). */
-    bool renderRayLodInSlabs( RenderStatistics& statistics, Renderer& renderer, const RenderInputs& in,
-                              const NodeIds& hierarchy, uint32_t maxNodesPerPass )
+    struct Slab
     {
+        float a, b; /* a < b whatever the direction */
+        NodeIds ids;
+    };
+
+    /* the slabs of a frame, front to back, and the axis they are stacked along; false: none (see above) */
+    bool planRayLodSlabs( const RenderInputs& in, const NodeIds& hierarchy, uint32_t maxNodesPerPass,
+                          std::vector< Slab >& slabs, int& axisOut ) const
+    {
+        slabs.clear();
         const std::vector< Vector4f >& userPlanes = in.renderSettings.getClipPlanes().getPlanes();
         if( userPlanes.size() + 2u > 6u || hierarchy.empty() )
             return false;
         const Frustum& frustum = in.frameInfo.frustum;
-        /* main axis of the view, and which way the rays run along it */
         std::vector< Boxf > boxes;
         boxes.reserve( hierarchy.size() );
         uint32_t finest = 0;
@@ -1127,6 +1134,7 @@ struct HipRaycastPipeline::Impl
         }
         if( axis < 0 )
             return false;
+        axisOut = axis;
         /* candidate faces: those of the finest bricks present (coarser faces are among them up to rounding) */
         std::vector< float > faces;
         for( size_t i = 0; i < hierarchy.size(); ++i )
@@ -1145,12 +1153,6 @@ struct HipRaycastPipeline::Impl
         auto inSlab = [&]( size_t i, float a, float b ) { /* the brick reaches into the open slab (a, b), a < b */
             return boxes[i].getMax()[axis] > a + eps && boxes[i].getMin()[axis] < b - eps;
         };
-        struct Slab
-        {
-            float a, b; /* a < b whatever the direction */
-            NodeIds ids;
-        };
-        std::vector< Slab > slabs;
         for( size_t f0 = 0; f0 + 1 < faces.size(); )
         {
             size_t f1 = f0 + 1, best = 0;
@@ -1168,22 +1170,31 @@ struct HipRaycastPipeline::Impl
                 bestIds.swap( ids );
             }
             if( best == 0 )
+            {
+                slabs.clear();
                 return false; /* one layer of the finest bricks with their ancestors is more than the atlas holds */
+            }
             if( !bestIds.empty() )
                 slabs.push_back( { std::min( faces[f0], faces[best] ), std::max( faces[f0], faces[best] ), bestIds } );
             f0 = best;
         }
+        return true;
+    }
+
+    /* render the first `count` of the frame's slabs (all of them: the whole frame); returns the bricks rendered */
+    size_t renderSlabs( Renderer& renderer, const RenderInputs& in, const std::vector< Slab >& slabs, size_t count, int axis )
+    {
         _keptValid = false;
         _keptObjects.clear();
-        _lastPasses = uint32_t( slabs.size() );
+        _lastPasses = uint32_t( count );
         _lastRayLod = true;
         size_t bricks = 0;
-        for( size_t i = 0; i < slabs.size(); ++i )
+        for( size_t i = 0; i < count; ++i )
         {
             uint32_t renderStages = RENDER_FRAME;
             if( i == 0 )
                 renderStages |= RENDER_BEGIN;
-            if( i + 1 == slabs.size() )
+            if( i + 1 == count )
                 renderStages |= RENDER_END;
             RenderInputs slabIn( in );
             Vector4f pa( 0.0f ), pb( 0.0f ); /* kept: n.x + d >= 0 (Renderer.cu:132-146) */
@@ -1214,11 +1225,101 @@ struct HipRaycastPipeline::Impl
             /* the next slab re-uses slots: this one's bricks must be evictable before it uploads */
             static_cast< HipRaycastRenderer& >( renderer.getPlugin() ).synchronize();
         }
-        if( slabs.empty() )
+        if( count == 0 )
             renderer.render( in, ConstCacheObjects(), RENDER_BEGIN | RENDER_END );
+        return bricks;
+    }
+
+    bool renderRayLodInSlabs( RenderStatistics& statistics, Renderer& renderer, const RenderInputs& in,
+                              const NodeIds& hierarchy, uint32_t maxNodesPerPass )
+    {
+        std::vector< Slab > slabs;
+        int axis = 0;
+        if( !planRayLodSlabs( in, hierarchy, maxNodesPerPass, slabs, axis ) )
+            return false;
+        const size_t bricks = renderSlabs( renderer, in, slabs, slabs.size(), axis );
         statistics.nAvailable = hierarchy.size();
         statistics.nNotAvailable = 0;
         statistics.nRenderAvailable = bricks;
+        return true;
+    }
+
+    /* The same in ASYNCHRONOUS mode (round 4; CudaRaycastPipeline.cpp:236-301 renders what is resident and asks for a
+     * redraw).  An atlas smaller than the hierarchy cannot keep the frame's bricks from one frame to the next, so
+     * "resident" means the CPU data cache here: the frame renders the longest front-to-back PREFIX of slabs whose
+     * bricks are all in it (their uploads are host-to-device copies only), the bricks still missing are read in the
+     * background, and the redraw filter is told the frame is not complete -- the front of the volume first, the rest
+     * slab by slab as the data arrives.  Needs a data cache that holds the hierarchy (else bricks would be evicted
+     * before the frame completes: false, the caller renders the per-brick cut). */
+    bool renderRayLodInSlabsAsync( RenderStatistics& statistics, Renderer& renderer, const RenderInputs& in,
+                                   const NodeIds& hierarchy, uint32_t maxNodesPerPass )
+    {
+        const VolumeInformation& vi = in.dataSource.getVolumeInfo();
+        const size_t brickBytes = size_t( vi.maximumBlockSize[0] ) * vi.maximumBlockSize[1] * vi.maximumBlockSize[2] *
+                                  vi.compCount * vi.getBytesPerVoxel();
+        if( hierarchy.size() * brickBytes > _dataCache->getStatistics().getMaximumMemory() )
+            return false;
+        std::vector< Slab > slabs;
+        int axis = 0;
+        if( !planRayLodSlabs( in, hierarchy, maxNodesPerPass, slabs, axis ) )
+            return false;
+        /* what is missing, in the order the frame fills in: slab by slab from the front (a brick that reaches into
+         * several slabs once) */
+        NodeIds missing;
+        size_t ready = slabs.size();
+        {
+            std::unordered_set< uint64_t > seen;
+            for( size_t i = 0; i < slabs.size(); ++i )
+                for( const NodeId& id : slabs[i].ids )
+                    if( !_dataCache->get( id.getId() ) )
+                    {
+                        ready = std::min( ready, i );
+                        if( seen.insert( id.getId() ).second )
+                            missing.push_back( id );
+                    }
+        }
+        {
+            std::exception_ptr pendingError;
+            {
+                std::lock_guard< std::mutex > lock( _asyncErrorMutex );
+                std::swap( pendingError, _asyncError );
+            }
+            if( pendingError )
+                std::rethrow_exception( pendingError );
+        }
+        if( !missing.empty() )
+        {
+            bool expected = false;
+            if( _asyncBusy.compare_exchange_strong( expected, true ) )
+            {
+                DataSource* ds = &in.dataSource;
+                _asyncUploadExecutor.schedule( [this, missing, ds] {
+                    struct Lower
+                    {
+                        std::atomic< bool >& flag;
+                        ~Lower() { flag = false; }
+                    } lower{ _asyncBusy };
+                    try
+                    {
+                        /* the CPU cache only: the atlas is the slabs' (front to back: the order the frame fills in) */
+                        for( const NodeId& id : missing )
+                            _dataCache->load( id.getId(), *ds );
+                    }
+                    catch( ... )
+                    {
+                        std::lock_guard< std::mutex > lock( _asyncErrorMutex );
+                        if( !_asyncError )
+                            _asyncError = std::current_exception();
+                    }
+                } );
+            }
+        }
+        const size_t bricks = renderSlabs( renderer, in, slabs, ready, axis );
+        statistics.nAvailable = hierarchy.size() - missing.size();
+        statistics.nNotAvailable = missing.size();
+        statistics.nRenderAvailable = bricks;
+        if( in.redrawFilter )
+            in.redrawFilter( missing.empty() && ready == slabs.size() );
         return true;
     }
 
@@ -1230,8 +1331,14 @@ struct HipRaycastPipeline::Impl
         ConstCacheObjects objects;
         const uint32_t maxNodes = uint32_t( _texturePool->getTextureMem() / _texturePool->getSlotMemSize() );
         NodeIds hierarchy = visibles;
-        const bool rayLod = in.vrParameters.getRayLOD() && withAncestors( in, hierarchy ) &&
-                            hierarchy.size() <= maxNodes;
+        bool rayLod = in.vrParameters.getRayLOD() && withAncestors( in, hierarchy );
+        if( rayLod && hierarchy.size() > maxNodes )
+        {
+            /* the hierarchy does not fit the atlas: slabs of space, the prefix whose data has arrived */
+            if( renderRayLodInSlabsAsync( statistics, renderer, in, hierarchy, maxNodes ) )
+                return;
+            rayLod = false;
+        }
         _lastRayLod = rayLod;
         if( rayLod )
         {

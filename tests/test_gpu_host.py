@@ -877,6 +877,60 @@ def test_per_ray_lod_in_slabs_when_the_hierarchy_exceeds_the_atlas(drv, spin):
     assert 0 < n_slab < n_whole  # (the counter is the last launch's: the last slab)
 
 
+def test_per_ray_lod_in_slabs_in_asynchronous_mode(drv):
+    # Round 3's slabs were for --synchronous only; in asynchronous mode (CudaRaycastPipeline.cpp:236-301: render what is
+    # resident, load the rest in the background, ask for a redraw) a hierarchy larger than the atlas fell back to the
+    # per-brick cut.  Now a frame renders the front-to-back prefix of slabs whose bricks have reached the CPU cache:
+    # the first frame has nothing, later frames grow from the front, and the settled frame is the synchronous one.
+    uri, W, H, sse, spin = "hash://#128,128,128,16", 96, 80, 0.6, (0.5, 0.35)
+    with drv.App(uri, W, H, synchronous=True, sse=sse, gpu_cache_mb=2) as sync:
+        sync.set_camera(spin=spin)
+        sync.set_colormap(orc.linear_ramp_tf(0.4))
+        sync.set_ray_lod(True)
+        want, st = sync.render_frame()
+        assert st.ray_lod == 1 and st.n_passes >= 3
+        n_slabs = st.n_passes
+    with drv.App(uri, W, H, synchronous=False, sse=sse, gpu_cache_mb=2) as app:
+        app.set_camera(spin=spin)
+        app.set_colormap(orc.linear_ramp_tf(0.4))
+        app.set_ray_lod(True)
+        fb0, st0 = app.render_frame()
+        assert st0.n_not_available > 0 and st0.n_passes == 0 and not fb0.any()  # nothing has arrived: no slab yet
+        app.wait_uploads()
+        fb1, st1 = app.render_frame()
+        assert st1.ray_lod == 1 and st1.n_not_available == 0 and st1.n_passes == n_slabs
+        assert (fb1 == want).all()
+    # a partial frame is the front of the volume: with the CPU cache holding only the bricks of the first slabs, the
+    # frame equals the synchronous frame wherever the rays end inside them (opaque transfer function: early exits)
+    # -- here simply: monotone growth, every partial frame's opacity is bounded by the full frame's
+    with drv.App(uri, W, H, synchronous=False, sse=sse, gpu_cache_mb=2) as app:
+        app.set_camera(spin=spin)
+        app.set_colormap(orc.linear_ramp_tf(0.4))
+        app.set_ray_lod(True)
+        last, grew = None, 0
+        import time
+        for _ in range(2000):  # (the loader fills the CPU cache meanwhile, slab by slab from the front)
+            time.sleep(0.002)
+            fb, st = app.render_frame()
+            assert (st.ray_lod == 1 or st.n_passes == 0) and np.isfinite(fb).all()
+            assert (fb[..., 3] <= want[..., 3] + 1e-6).all()  # a prefix of the slabs: never more opaque than the whole
+            if last is not None:
+                assert (fb[..., 3] >= last[..., 3] - 1e-6).all()  # the camera stands still: frames only grow
+                grew += int((fb[..., 3] > last[..., 3] + 1e-6).any())
+            last = fb
+            if st.n_not_available == 0:
+                break
+        assert st.n_not_available == 0 and (fb == want).all()
+        assert grew >= 2, "the frame filled in slab by slab (%d growth steps)" % grew
+    # a CPU cache too small for the hierarchy: the per-brick cut, as before
+    with drv.App(uri, W, H, synchronous=False, sse=sse, gpu_cache_mb=2, cpu_cache_mb=1) as app:
+        app.set_camera(spin=spin)
+        app.set_colormap(orc.linear_ramp_tf(0.4))
+        app.set_ray_lod(True)
+        fb, st = app.render_frame()
+        assert st.ray_lod == 0
+
+
 #: what the sampling restarts at slab faces cost against the single pass: isolated pixels / the frame mean.  Measured on
 #: MI355X with the slabs in the rays' order: max 1.8e-2, mean 8.0e-4 (the axis-aligned view of the 128^3 scene: eight
 #: slabs, every coarse-level run cut seven times, transfer function of alpha 0.1); what a wrong ORDER costs is measured

@@ -1162,6 +1162,73 @@ def test_atlas_of_more_than_2_pow_32_voxels(vrc):
         L.vrc_ctx_destroy(ctx)
 
 
+def test_ray_lod_in_an_atlas_of_more_than_2_pow_32_voxels(vrc):
+    # per-ray adaptive LOD in a pool of more than 2^32 voxels (BASELINE C3's full-size atlas is one): round 3 refused it
+    # (32-bit slot bases in the hierarchy walk); now the walk has instances with 64-bit slot bases and float positions
+    # (vrc_k_raycast_raylod<...,true>).  The whole hierarchy of a 64^3 volume in a 6 GB pool, bricks on both sides of the
+    # 4 Gi-voxel line: the frame of the same hierarchy in a small pool with float stepping, bit for bit, point-sampled
+    # and with the trilinear filter (gather form).  Reference hook: CudaRaycastPipeline.cpp:236-301 (what renders C3).
+    vi = orc.mem_volume_info(64, 64, 64, 16)
+    s = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(96, 80), volume="hash", spin=(0.5, 0.35),
+                        ids=orc.all_level_ids(vi))
+    lod = (0.8, orc.world_space_per_pixel(s))
+    with _gpu(s) as g:
+        want, n_want, st = g.render(kernel=vrc.KERNEL_GRID_DDA, stepping=0, ray_lod=lod)
+        assert st.kernel_variant == vrc.KERNEL_RAY_LOD
+        want_lin, n_lin, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, filter_mode=vrc.FILTER_TRILINEAR, ray_lod=lod)
+    L = vrc.load_library()
+    ctx, pool = C.c_void_p(), C.c_void_p()
+    vrc.check(L, L.vrc_ctx_create(0, C.byref(ctx)))
+    try:
+        mb = [s.vi.maximumBlockSize[a] for a in range(3)]
+        vrc.check(L, L.vrc_pool_create(ctx, 1, 0, 0, 1, vrc.u32x3(*mb), 6 * 1000 ** 3, C.byref(pool)))
+        sb, ab, fs = C.c_size_t(), C.c_size_t(), C.c_uint32()
+        ad, sl = vrc.u32x3(), vrc.u32x3()
+        vrc.check(L, L.vrc_pool_info(pool, C.byref(sb), ad, C.byref(ab), sl, C.byref(fs)))
+        atlas_dim = list(ad)
+        assert atlas_dim[0] * atlas_dim[1] * atlas_dim[2] > 2 ** 32
+        slot_dim = [atlas_dim[a] // sl[a] for a in range(3)]
+        slots, high = {}, 0
+        for nid in s.ids:
+            brick = s.bricks[nid]
+            slot = vrc.f32x3()
+            vrc.check(L, L.vrc_pool_copy_to_slot(pool, brick.ctypes.data,
+                                                 vrc.u32x3(brick.shape[2], brick.shape[1], brick.shape[0]), slot))
+            slots[nid] = (slot[0], slot[1], slot[2])
+            idx = [int(round(slot[a] * sl[a])) for a in range(3)]
+            high += ((idx[2] * sl[1] + idx[1]) * sl[0] + idx[0]) * slot_dim[0] * slot_dim[1] * slot_dim[2] >= 2 ** 32
+        assert 0 < high < len(s.ids)
+        nodes = (vrc.NodeData * s.n_nodes)()
+        for k, nid in enumerate(s.sorted_ids):
+            tp, ts = orc.f32x3(), orc.f32x3()
+            orc.lib().orc_texture_object(C.byref(s.vi), C.byref(s.lod[nid]), orc.f32x3(*slots[nid]),
+                                         orc.u32x3(*atlas_dim), tp, ts)
+            for a in range(3):
+                nodes[k].textureMin[a] = tp[a]
+                nodes[k].textureSize[a] = ts[a]
+                nodes[k].aabbMin[a] = s.nodes[k].aabbMin[a]
+                nodes[k].aabbSize[a] = s.nodes[k].aabbSize[a]
+        view = C.cast(C.byref(s.view), C.POINTER(vrc.ViewData))
+        render = C.cast(C.byref(s.render), C.POINTER(vrc.RenderData))
+        vrc.check(L, L.vrc_update(ctx, s.tf.ctypes.data, None, 0))
+        vrc.check(L, L.vrc_set_option(ctx, vrc.OPT_COUNT_SAMPLES, 1))
+        vrc.check(L, L.vrc_set_ray_lod(ctx, 1, lod[0], lod[1]))
+        for flt, frame_want, n in ((vrc.FILTER_NEAREST, want, n_want), (vrc.FILTER_TRILINEAR, want_lin, n_lin)):
+            vrc.check(L, L.vrc_set_option(ctx, vrc.OPT_FILTER, flt))
+            vrc.check(L, L.vrc_pre_render(ctx, view))
+            vrc.check(L, L.vrc_render(ctx, view, nodes, s.n_nodes, render, pool))
+            fb = np.zeros((s.H, s.W, 4), dtype=np.float32)
+            vrc.check(L, L.vrc_post_render(ctx, fb.ctypes.data))
+            st = vrc.Stats()
+            vrc.check(L, L.vrc_get_stats(ctx, C.byref(st)))
+            assert st.kernel_variant == vrc.KERNEL_RAY_LOD and L.vrc_last_kernel().decode().endswith(",true>"), L.vrc_last_kernel()
+            assert st.samples == n and (fb == frame_want).all(), "filter %d" % flt
+    finally:
+        if pool:
+            L.vrc_pool_destroy(pool)
+        L.vrc_ctx_destroy(ctx)
+
+
 def test_slot_longer_than_255_voxels_marches_with_float_positions(vrc):
     # pool creation bounds a slot's volume (2^24 voxels), not its edges: a 300 x 16 x 16 brick (overlap 1) has slot-local
     # coordinates that do not fit the 8.24 fixed-point positions of VRC_OPT_STEPPING = 1, the address tables and the LDS
