@@ -1565,6 +1565,7 @@ VRC_HD void vrc_packed_offsets( const vrc_sampler& s, vrc_fixpos& p, uint32_t* o
 #define VRC_PGROUP 4
 #endif
 
+
 /* March one brick segment through the packed atlas (Renderer.cu:206-223 with the trilinear fetch).  Organised as
  * vrc_march_segment_as: whole groups without per-sample tests while more than GROUP steps remain, the early-exit
  * test once per group with an exact replay, a general tail.  tab: vrc_cls8_entry table.  E: vrc_f4, or vrc_f2
