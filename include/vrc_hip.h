@@ -173,9 +173,11 @@ typedef struct
                                       * holds (VRC_OPT_PACKED_ATLAS) */
 #define VRC_KERNEL_RAY_LOD 4         /* reported by vrc_get_stats when vrc_set_ray_lod is on; not selectable.  Under
                                       * per-ray LOD VRC_OPT_KERNEL chooses how the hierarchy walk takes its samples:
-                                      * AUTO = staged through LDS for the trilinear filter on 8-bit bricks (overlap >= 1,
+                                      * AUTO = for the trilinear filter the tap-packed atlas where VRC_KERNEL_PACKED
+                                      * applies, else staged through LDS (8- or 16-bit bricks, overlap >= 1,
                                       * VRC_OPT_TF_FRAC_BITS 8), by gathers otherwise; GRID_DDA = gathers; LDS = staged or
-                                      * VRC_EINVAL; vrc_last_kernel names the instance that ran */
+                                      * VRC_EINVAL; PACKED = the packed atlas or VRC_EINVAL; vrc_last_kernel names the
+                                      * instance that ran */
 
 /* ---- context ---------------------------------------------------------------------------- */
 /* cuda::Renderer::Renderer() (cuda/Renderer.cu:234-238); device is explicit (fixes Q11) */

@@ -1169,7 +1169,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         /* AUTO: the LDS-staged form for the trilinear filter where it applies, else the gather form; GRID_DDA asks for
          * the gather form, LDS for the staged one */
         if( c->optKernel == VRC_KERNEL_REFERENCE_ORDER )
-            return fail( VRC_EINVAL, "vrc_render: per-ray LOD walks the hierarchy; VRC_OPT_KERNEL = AUTO, GRID_DDA (gathers) or LDS" );
+            return fail( VRC_EINVAL, "vrc_render: per-ray LOD walks the hierarchy; VRC_OPT_KERNEL = AUTO, GRID_DDA (gathers), LDS or PACKED" );
     }
     bool useDda = c->cachedGridOk;
     /* AUTO keeps the reference's frame: bricks of one size are met by the grid walk in the reference's
@@ -1218,22 +1218,23 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
      * its positions and its classifier need -- 8-bit bricks with overlap >= 1 in slots of at most 248 voxels a side, an
      * atlas of at most 2^32 voxels, VRC_OPT_TF_FRAC_BITS = 8 -- and 4.5 times the atlas in device memory; either brick
      * enumeration (grid walk where the node set is grid-aligned, else the reference-order loop) */
-    const bool packedEligible = linear && !c->rayLod && !glSuper && !c->cachedClamp && slotsFit8Bits &&
+    const bool packedEligible = linear && !glSuper && !c->cachedClamp && slotsFit8Bits &&
                                 pool_packed_possible( pool ) && c->optTfFracBits == 8 && c->optStepping != 0;
     bool usePacked = false;
     if( c->optKernel == VRC_KERNEL_PACKED )
     {
         if( !packedEligible )
-            return fail( VRC_EINVAL, "vrc_render: the packed kernel needs the trilinear filter on 8-bit bricks with overlap >= 1 (slots of at most 248 voxels a side, an atlas of at most 2^32 voxels), VRC_OPT_TF_FRAC_BITS = 8, fixed-point stepping, no per-ray LOD" );
+            return fail( VRC_EINVAL, "vrc_render: the packed kernel needs the trilinear filter on 8-bit bricks with overlap >= 1 (slots of at most 248 voxels a side, an atlas of at most 2^32 voxels), VRC_OPT_TF_FRAC_BITS = 8, fixed-point stepping" );
         if( !pool_enable_packed( pool ) )
             return fail( VRC_ENOMEM, "vrc_render: no device memory for the tap-packed atlas (4.5 times the brick atlas)" );
         usePacked = true;
     }
     else if( c->optKernel == VRC_KERNEL_AUTO && packedEligible && c->optPackedAtlas )
-        /* measured on C2: 1.52 against 1.77 ms along the axis, 1.94 against 2.40 at 30/20 degrees;
-         * without the memory for it the frame takes the staged form below */
+        /* measured on C2: 1.51 against 1.69 ms along the axis, 1.93 against 2.40 at 30/20 degrees;
+         * under per-ray LOD 1.1-2.5 x the staged form (profiles/r4_c5_trilinear_three_forms.txt); without the memory for
+         * it the frame takes the staged form below */
         usePacked = pool_enable_packed( pool );
-    const bool useLds = c->rayLod ? ( ldsLodEligible && c->optKernel != VRC_KERNEL_GRID_DDA )
+    const bool useLds = c->rayLod ? ( ldsLodEligible && c->optKernel != VRC_KERNEL_GRID_DDA && !usePacked )
                                   : !glSuper && !usePacked && ( c->optKernel == VRC_KERNEL_LDS ||
                                                   ( c->optKernel == VRC_KERNEL_AUTO && linear && ldsEligible ) );
 

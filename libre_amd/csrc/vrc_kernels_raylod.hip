@@ -36,7 +36,14 @@ __global__ __launch_bounds__( VRC_RL_THREADS, VRC_RL_MIN_BLOCKS ) void vrc_k_ray
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) vrc_f4 lutLevels[]; /* 16: ds_read_b128 per entry */
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
-    if( MODE == VRC_MODE_GREY )
+    if( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY )
+    {
+        /* the tap-packed trilinear march (vrc_core.h): its classifier's table from the padded transfer function (the
+         * level's opacity exponent travels in the classifier), and the packed atlas's per-axis byte offsets below */
+        for( uint32_t i = tid; i < lutEntries; i += VRC_RL_THREADS )
+            lutLevels[i] = vrc_cls8_entry( lutGlobal, i, MODE == VRC_MODE_PACKED_GREY );
+    }
+    else if( MODE == VRC_MODE_GREY )
     {
         /* grey transfer function: (grey, alpha) pairs, half the table bytes (vrc_core.h, VRC_MODE_GREY) */
         vrc_f2* const lut2 = reinterpret_cast< vrc_f2* >( lutLevels );
@@ -50,7 +57,16 @@ __global__ __launch_bounds__( VRC_RL_THREADS, VRC_RL_MIN_BLOCKS ) void vrc_k_ray
         for( uint32_t i = tid; i < lutEntries; i += VRC_RL_THREADS )
             lutLevels[i] = lutGlobal[i];
 #if defined( VRC_ADDR_TABLES )
-    if( FIXED )
+    if( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY )
+    {
+        for( uint32_t u = tid; u < 256u; u += VRC_RL_THREADS )
+        {
+            vrc_addr_tab[u] = 4u * vrc_pk_x( u );
+            vrc_addr_tab[256u + u] = 4u * vrc_pk_y( u, f.sbx );
+            vrc_addr_tab[512u + u] = 4u * vrc_pk_z( u, f.sbx, f.sby );
+        }
+    }
+    else if( FIXED )
     {
         const uint32_t cyy = f.sbx * VRC_MB_VOXELS - 64u, czz = f.sbx * f.sby * VRC_MB_VOXELS - 512u;
         for( uint32_t u = tid; u < 256u; u += VRC_RL_THREADS )
@@ -78,8 +94,9 @@ __global__ __launch_bounds__( VRC_RL_THREADS, VRC_RL_MIN_BLOCKS ) void vrc_k_ray
 
     uint32_t nSamples = 0;
     if( px < f.width && py < f.height )
-        vrc_pixel_ray_lod< CLAMP, COUNT, FIXED, MODE, ATLAS_T, VRC_GROUP, BIG >( f, nodes, levelTables, atlas, lutLevels,
-                                                                                 cls, pixelBuffer, px, py, nSamples );
+        vrc_pixel_ray_lod< CLAMP, COUNT, FIXED, MODE, ATLAS_T,
+                           ( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY ) ? VRC_PGROUP : VRC_GROUP, BIG >(
+            f, nodes, levelTables, atlas, lutLevels, cls, pixelBuffer, px, py, nSamples );
     if( COUNT )
     {
         unsigned long long s = nSamples;
@@ -100,9 +117,10 @@ static hipError_t launch_raylod( const vrc_raycast_args& a, hipStream_t stream )
         return hipSuccess;
     const uint32_t lutEntries = ( MODE == VRC_MODE_TABLE || MODE == VRC_MODE_GREY )
                                     ? a.frame.lodLevels * VRC_LUT_ENTRIES
-                                    : VRC_TFP_ENTRIES;
+                                    : ( ( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY ) ? VRC_CLS8_ENTRIES : VRC_TFP_ENTRIES );
     vrc_internal_note_kernel( "vrc_k_raycast_raylod<%s,%s,%s,%d,%s,%s>", CLAMP ? "true" : "false", COUNT ? "true" : "false",
-                              FIXED ? "true" : "false", (int)MODE, sizeof( ATLAS_T ) == 1 ? "unsigned char" : "unsigned short",
+                              FIXED ? "true" : "false", (int)MODE,
+                              sizeof( ATLAS_T ) == 1 ? "unsigned char" : ( sizeof( ATLAS_T ) == 2 ? "unsigned short" : "unsigned int" ),
                               BIG ? "true" : "false" );
     hipLaunchKernelGGL( ( vrc_k_raycast_raylod< CLAMP, COUNT, FIXED, MODE, ATLAS_T, BIG > ),
                         dim3( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_RL_WAVES - 1u ) / VRC_RL_WAVES ),
@@ -134,6 +152,17 @@ hipError_t vrc_launch_raycast_raylod( const vrc_raycast_args& a, hipStream_t str
         a.frame.variant != VRC_VARIANT_CUDA )
         return hipErrorInvalidValue;
     const bool count = a.sampleCounter != nullptr;
+    if( a.packed )
+    {
+        /* the trilinear filter through the tap-packed atlas (a.atlas), the hierarchy walk around it */
+        if( !a.linear || a.elemBytes != 1 || a.bigAtlas || a.clamp )
+            return hipErrorInvalidValue;
+        if( a.greyTable )
+            return count ? launch_raylod< false, true, true, VRC_MODE_PACKED_GREY, uint32_t >( a, stream )
+                         : launch_raylod< false, false, true, VRC_MODE_PACKED_GREY, uint32_t >( a, stream );
+        return count ? launch_raylod< false, true, true, VRC_MODE_PACKED, uint32_t >( a, stream )
+                     : launch_raylod< false, false, true, VRC_MODE_PACKED, uint32_t >( a, stream );
+    }
     if( a.bigAtlas )
     {
         /* 64-bit slot bases: float positions (the classified tables of the levels for 8-bit point sampling) */

@@ -105,7 +105,7 @@ static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3]
      * transfer function */
     const bool dda = !rayLod && ( kernel == 2 || kernel == 4 || kernel == 6 || kernel == 8 || kernel == 10 || kernel == 12 );
     const bool packedKernel = kernel >= 9 && kernel <= 12;
-    if( packedKernel && ( rayLod || voxelBytes != 1 || t.clamp || fracBits != 8 ) )
+    if( packedKernel && ( voxelBytes != 1 || t.clamp || fracBits != 8 ) )
         return 5;
     /* the tap-packed atlas as vrc_k_pack_slots writes it: blocks of 9 x 8 x 8 texels, the ninth column a copy of the
      * next block's first, neighbours and the copy clamped at the slot's last voxel */
@@ -178,7 +178,13 @@ static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3]
         if( t.clamp ) vrc_pixel_ray_lod< true, true, false, MODE, T >( ARGS_DDA( A ) );              \
         else vrc_pixel_ray_lod< false, true, FIXED, MODE, T >( ARGS_DDA( A ) );                      \
     }
-            if( packedKernel )
+            if( packedKernel && rayLod )
+            {
+                /* per-ray LOD around the tap-packed march (kernel 9; 11: grey colours) */
+                if( kernel >= 11 ) vrc_pixel_ray_lod< false, true, true, VRC_MODE_PACKED_GREY, uint32_t, VRC_PGROUP >( ARGS_DDA( packed.data() ) );
+                else vrc_pixel_ray_lod< false, true, true, VRC_MODE_PACKED, uint32_t, VRC_PGROUP >( ARGS_DDA( packed.data() ) );
+            }
+            else if( packedKernel )
             {
                 if( kernel == 9 ) vrc_pixel_reference_order< false, true, true, VRC_MODE_PACKED, uint32_t, VRC_PGROUP >( ARGS_REF( packed.data() ) );
                 else if( kernel == 10 ) vrc_pixel_grid_dda< false, true, true, VRC_MODE_PACKED, uint32_t, VRC_PGROUP >( ARGS_DDA( packed.data() ) );

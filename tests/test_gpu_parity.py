@@ -963,17 +963,31 @@ def test_ray_lod_trilinear_staged_through_lds(vrc, sse, tf):
     lod = (sse, orc.world_space_per_pixel(s))
     want, n_want = orc.oracle_render(s, ray_lod=lod, filter_mode=1)
     with _gpu(s) as g:
-        staged, n_staged, st = g.render(ray_lod=lod, filter_mode=1)
+        # AUTO: the tap-packed atlas for 8-bit bricks (round 4), the staged form for 16-bit ones
+        auto, n_auto, st = g.render(ray_lod=lod, filter_mode=1)
+        assert st.kernel_variant == vrc.KERNEL_RAY_LOD
+        if voxel == "unsigned char":
+            assert _ran(g).startswith("vrc_k_raycast_raylod<") and ",unsigned int," in _ran(g), _ran(g)
+        staged, n_staged, st = g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_LDS)
         assert st.kernel_variant == vrc.KERNEL_RAY_LOD
         assert _ran(g).startswith("vrc_k_raycast_lds<true,true,") and _ran(g).endswith(",true,%s,false>" % voxel), _ran(g)
+        assert n_auto == n_staged
+        scenes.assert_same_frame(auto, staged, "per-ray LOD trilinear: AUTO vs LDS-staged", tol=1e-6)
         gathered, n_gathered, _ = g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_GRID_DDA)
         assert _ran(g).startswith("vrc_k_raycast_raylod<"), _ran(g)
-        forced, _, _ = g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_LDS)
-        assert (forced == staged).all()
         uncounted, _, _ = g.render(ray_lod=lod, filter_mode=1, count=False)
-        assert (uncounted == staged).all()
+        assert (uncounted == auto).all()
         with pytest.raises(Exception):
             g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_REFERENCE_ORDER)
+        if voxel == "unsigned char":
+            # ... and through the tap-packed atlas (round 4): the staged form's positions, weights and arithmetic
+            packed, n_packed, st = g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_PACKED)
+            assert st.kernel_variant == vrc.KERNEL_RAY_LOD and _ran(g).startswith("vrc_k_raycast_raylod<") and ",unsigned int," in _ran(g), _ran(g)
+            assert n_packed == n_staged
+            scenes.assert_same_frame(packed, staged, "per-ray LOD, tap-packed atlas vs LDS-staged", tol=1e-6)
+        else:
+            with pytest.raises(vrc.VrcError):
+                g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_PACKED)
     _lod_parity(staged, want, "staged sse %g" % sse)
     _lod_parity(gathered, want, "gathers sse %g" % sse)
     assert abs(n_staged - n_want) <= 3e-4 * n_want + 16
@@ -998,8 +1012,12 @@ def test_ray_lod_trilinear_staged_random_views(vrc, seed):
     lod = (float(rng.uniform(0.3, 4.0)) * vox[0] / 64.0 * 48.0 / s.H, orc.world_space_per_pixel(s))
     want, n_want = orc.oracle_render(s, threads=8, ray_lod=lod, filter_mode=1)
     with _gpu(s) as g:
-        got, n_got, _ = g.render(ray_lod=lod, filter_mode=1)
+        got, n_got, _ = g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_LDS)
         assert _ran(g).startswith("vrc_k_raycast_lds<"), _ran(g)
+        auto, n_auto, _ = g.render(ray_lod=lod, filter_mode=1)  # the tap-packed atlas: the same numbers
+        assert ",unsigned int," in _ran(g), _ran(g)
+        assert n_auto == n_got
+        scenes.assert_same_frame(auto, got, "seed %d: tap-packed atlas vs staged under per-ray LOD" % seed, tol=1e-6)
     _lod_parity(got, want, "seed %d %r lod %r" % (seed, kw, lod))
     assert abs(n_got - n_want) <= 3e-4 * n_want + 16
 
@@ -1326,13 +1344,21 @@ def test_ray_lod_trilinear_on_the_pinned_hierarchies(vrc):
         want, n_want = orc.oracle_render(s, threads=8, ray_lod=lod, filter_mode=1)
         assert np.allclose(want, golden_lod[name + "__trilinear"], atol=1e-6) and n_want == int(golden_lod[name + "__trilinear_samples"][0])
         with _gpu(s) as g:
+            # AUTO: the tap-packed atlas where the bricks have an overlap (round 4), else the gather form; with
+            # VRC_OPT_PACKED_ATLAS off the staged form as in round 3
             auto, n_auto, st = g.render(ray_lod=lod, filter_mode=1)
             assert st.kernel_variant == vrc.KERNEL_RAY_LOD
+            packed = ",unsigned int," in _ran(g)
+            vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_PACKED_ATLAS, 0))
+            plain, n_plain, _ = g.render(ray_lod=lod, filter_mode=1)
             staged = _ran(g).startswith("vrc_k_raycast_lds<")
+            assert staged == packed  # both need an overlap
             staged_cases += staged
+            vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_PACKED_ATLAS, 1))
             gathered, n_gathered, _ = g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_GRID_DDA)
-            assert _ran(g).startswith("vrc_k_raycast_raylod<")
-        _lod_parity(auto, want, name + " trilinear, " + ("staged" if staged else "gathers (AUTO)"))
+            assert _ran(g).startswith("vrc_k_raycast_raylod<") and ",unsigned int," not in _ran(g)
+        _lod_parity(auto, want, name + " trilinear, " + ("tap-packed atlas" if packed else "gathers (AUTO)"))
+        _lod_parity(plain, want, name + " trilinear, " + ("staged" if staged else "gathers (AUTO)"))
         _lod_parity(gathered, want, name + " trilinear, gathers")
         assert abs(n_auto - n_want) <= 3e-4 * n_want + 16 and abs(n_gathered - n_want) <= 3e-4 * n_want + 16
     assert staged_cases >= 1

@@ -171,6 +171,12 @@ def test_random_views(seed):
         assert ok
         _parity(got, want, "seed %d k%d %r lod %r" % (seed, kernel, kw, lod))
         assert abs(n_got - n_want) <= 3e-4 * n_want + 16, (seed, kernel, kw)
+    # the trilinear filter through the tap-packed atlas around the same walk (round 4)
+    want_lin, n_lin = orc.oracle_render(s, threads=4, ray_lod=lod, filter_mode=1)
+    got, n_got, ok = orc.harness_render_ray_lod(s, lod, kernel=9)
+    assert ok
+    _parity(got, want_lin, "seed %d tap-packed trilinear %r lod %r" % (seed, kw, lod))
+    assert abs(n_got - n_lin) <= 3e-4 * n_lin + 16, (seed, kw)
 
 
 # ---- ragged trees: the reference's UVF fixture (75x75x138 voxels, bricks of 28^3, two levels whose
@@ -200,7 +206,7 @@ def test_ragged_uvf_tree(sse):
     lod = (sse, orc.world_space_per_pixel(s))
     want, n_want = orc.oracle_render(s, ray_lod=lod)
     assert want[..., 3].max() > 0.3
-    for kernel in (1, 3, 5):
+    for kernel in (1, 3, 5, 9):  # classified tables (float / fixed-point stepping), trilinear by gathers, tap-packed atlas
         if kernel == 5:
             want, n_want = orc.oracle_render(s, ray_lod=lod, filter_mode=1)
         got, n_got, ok = orc.harness_render_ray_lod(s, lod, kernel=kernel)

@@ -1,5 +1,5 @@
 """Developer probe: per-ray LOD with the trilinear filter, samples by gathers (vrc_k_raycast_raylod) against the
-LDS-staged form (vrc_k_raycast_lds<.,true,.,true>), same frames.
+LDS-staged form (vrc_k_raycast_lds<.,true,.,true>) and the tap-packed atlas (vrc_k_raycast_raylod<...,5|6,unsigned int,.>), same frames.
 usage: python tools/dev_c5_trilinear.py [N=1024] [block=128] [viewport=1024]"""
 import os
 import sys
@@ -51,9 +51,12 @@ for alpha, what in ((1.0, "ERT (alpha 1.0)"), (0.05, "no ERT (alpha 0.05)")):
                 app.set_option(vrc.OPT_KERNEL, vrc.KERNEL_GRID_DDA)
                 ms0, n0, st0 = measure(app)
                 k0 = L.vrc_last_kernel().decode()
-                app.set_option(vrc.OPT_KERNEL, vrc.KERNEL_AUTO)
+                app.set_option(vrc.OPT_KERNEL, vrc.KERNEL_LDS)
                 ms1, n1, st1 = measure(app)
                 k1 = L.vrc_last_kernel().decode()
-                print("%-20s sse %.0f %-24s gathers %.3f ms %6.3f Gs | staged %.3f ms %6.3f Gs (ray_lod %d) | x%.2f  [%s | %s]" % (
-                    what, sse, name, ms0, n0 / 1e9, ms1, n1 / 1e9, st1.ray_lod, ms0 / ms1, k0.split("<")[0], k1.split("<")[0]),
+                app.set_option(vrc.OPT_KERNEL, vrc.KERNEL_PACKED)
+                ms2, n2, st2 = measure(app)
+                k2 = L.vrc_last_kernel().decode()
+                print("%-20s sse %.0f %-24s gathers %.3f ms %6.3f Gs | staged %.3f ms (x%.2f) | packed %.3f ms %6.3f Gs (x%.2f; ray_lod %d)  [%s | %s | %s]" % (
+                    what, sse, name, ms0, n0 / 1e9, ms1, ms0 / ms1, ms2, n2 / 1e9, ms0 / ms2, st2.ray_lod, k0.split("<")[0], k1.split("<")[0], k2[:60]),
                     flush=True)
