@@ -290,25 +290,24 @@ hipError_t vrc_launch_read_region( const void* atlas, void* dst, uint32_t elemBy
  * coalesced 4-byte stores; the byte reads hit L1/L2.
  * ---------------------------------------------------------------------------------------- */
 __global__ __launch_bounds__( 256 ) void vrc_k_pack_slots( const uint8_t* __restrict__ atlas, uint32_t* __restrict__ packed,
-                                                           uint64_t firstBlock, uint64_t nBlocks, uint32_t slotBlocks,
-                                                           uint32_t sdx, uint32_t sdy, uint32_t sdz, uint32_t sbx, uint32_t sby )
+                                                           uint64_t firstSlot, uint32_t slotBlocks, uint32_t sdx, uint32_t sdy,
+                                                           uint32_t sdz, uint32_t sbx, uint32_t sby )
 {
-    const uint64_t n = nBlocks * VRC_PK_BLOCK;
-    for( uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x )
+    /* blockIdx.y = the slot (64-bit only in its base), x strides over the slot's packed texels in 32 bits */
+    const uint64_t slotIndex = firstSlot + blockIdx.y;
+    const uint8_t* const slot = atlas + slotIndex * ( (uint64_t)slotBlocks * VRC_MB_VOXELS );
+    uint32_t* const out = packed + slotIndex * ( (uint64_t)slotBlocks * VRC_PK_BLOCK );
+    const uint32_t n = slotBlocks * VRC_PK_BLOCK;
+    for( uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x )
     {
-        const uint64_t blk = firstBlock + i / VRC_PK_BLOCK; /* block of the atlas = block of its slot, slots in order */
-        const uint32_t in = (uint32_t)( i % VRC_PK_BLOCK );
-        const uint64_t slotIndex = blk / slotBlocks;
-        const uint32_t b = (uint32_t)( blk - slotIndex * slotBlocks );
+        const uint32_t b = i / VRC_PK_BLOCK, in = i % VRC_PK_BLOCK;
         const uint32_t ix = in % VRC_PK_ROW, iy = ( in / VRC_PK_ROW ) & 7u, iz = in / VRC_PK_SLICE;
         uint32_t x = ( b % sbx ) * 8u + ix;
         const uint32_t y = ( ( b / sbx ) % sby ) * 8u + iy, z = ( b / ( sbx * sby ) ) * 8u + iz;
         x = x < sdx ? x : sdx - 1u;
         const uint32_t y1 = y + 1u < sdy ? y + 1u : y, z1 = z + 1u < sdz ? z + 1u : z;
-        const uint8_t* const slot = atlas + slotIndex * ( (uint64_t)slotBlocks * VRC_MB_VOXELS );
-        packed[blk * VRC_PK_BLOCK + in] =
-            vrc_pack_taps( slot[vrc_slot_local_index( x, y, z, sbx, sby )], slot[vrc_slot_local_index( x, y1, z, sbx, sby )],
-                           slot[vrc_slot_local_index( x, y, z1, sbx, sby )], slot[vrc_slot_local_index( x, y1, z1, sbx, sby )] );
+        out[i] = vrc_pack_taps( slot[vrc_slot_local_index( x, y, z, sbx, sby )], slot[vrc_slot_local_index( x, y1, z, sbx, sby )],
+                                slot[vrc_slot_local_index( x, y, z1, sbx, sby )], slot[vrc_slot_local_index( x, y1, z1, sbx, sby )] );
     }
 }
 
@@ -318,9 +317,17 @@ hipError_t vrc_launch_pack_slots( const void* atlas, void* packed, uint64_t firs
     if( nElems == 0 )
         return hipSuccess;
     const uint32_t slotBlocks = ( slotDim[0] >> VRC_MB_SHIFT ) * ( slotDim[1] >> VRC_MB_SHIFT ) * ( slotDim[2] >> VRC_MB_SHIFT );
-    hipLaunchKernelGGL( vrc_k_pack_slots, dim3( grid_for( (size_t)( nElems / VRC_MB_VOXELS * VRC_PK_BLOCK ), 256 ) ), dim3( 256 ),
-                        0, stream, (const uint8_t*)atlas, (uint32_t*)packed, firstElem / VRC_MB_VOXELS, nElems / VRC_MB_VOXELS,
-                        slotBlocks, slotDim[0], slotDim[1], slotDim[2], slotDim[0] >> VRC_MB_SHIFT, slotDim[1] >> VRC_MB_SHIFT );
+    const uint64_t slotElems = (uint64_t)slotBlocks * VRC_MB_VOXELS;
+    const uint64_t firstSlot = firstElem / slotElems, nSlots = nElems / slotElems;
+    const uint32_t gx = grid_for( (size_t)slotBlocks * VRC_PK_BLOCK, 256 );
+    /* (grid.y holds at most 65535 slots per launch) */
+    for( uint64_t s0 = 0; s0 < nSlots; s0 += 65535u )
+    {
+        const uint32_t ns = (uint32_t)std::min< uint64_t >( nSlots - s0, 65535u );
+        hipLaunchKernelGGL( vrc_k_pack_slots, dim3( nSlots > 64u ? std::min( gx, 64u ) : gx, ns ), dim3( 256 ), 0, stream,
+                            (const uint8_t*)atlas, (uint32_t*)packed, firstSlot + s0, slotBlocks, slotDim[0], slotDim[1], slotDim[2],
+                            slotDim[0] >> VRC_MB_SHIFT, slotDim[1] >> VRC_MB_SHIFT );
+    }
     return hipGetLastError();
 }
 
