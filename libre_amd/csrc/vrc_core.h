@@ -53,7 +53,7 @@
     defined( VRC_GREY_MAX_WAVES ) || \
     defined( VRC_TAIL_GROUP ) || \
     defined( VRC_LGROUP ) || \
-    defined( VRC_PGROUP ) || defined( VRC_PACKED_WAVES ) || defined( VRC_PACKED_ABLATE ) || \
+    defined( VRC_PGROUP ) || defined( VRC_PACKED_WAVES ) || defined( VRC_PACKED_ABLATE ) || defined( VRC_PK_LAYOUT ) || \
     defined( VRC_SPLIT_GROUP ) || \
     defined( VRC_SMALL_GROUP ) || \
     defined( VRC_SMALL_LAUNCH_TILES ) || \
@@ -1384,18 +1384,46 @@ VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n,
  * z, the transfer function through CUDA's 1.8 fixed-point weight out of one float -> integer conversion), so the
  * two forms composite the same numbers.
  * ---------------------------------------------------------------------------------------- */
-/* slot-local element order of the packed atlas: offset = PX(x) + PY(y) + PZ(z) with blocks of 9 x 8 x 8 texels
- * (x fastest, blocks x-fastest inside the slot); position 8 of a row holds the texel at 8 * (block + 1), clamped to
- * the slot's last column.  Slots are 9/8 of the byte atlas's slots, in the same order. */
+/* slot-local element order of the packed atlas: offset = PX(x) + PY(y) + PZ(z), blocks x-fastest inside the slot.
+ * VRC_PK_LAYOUT 1: blocks of 9 x 8 x 8 texels (x fastest); position 8 of a row holds the texel at 8 * (block + 1),
+ *   clamped to the slot's last column: T(x) and T(x + 1) are ALWAYS neighbours.  Slots are 9/8 of the byte atlas's.
+ * VRC_PK_LAYOUT 2: blocks of 8 x 8 x 8 texels in 128-byte lines of 8 x 2 x 2 (x, then the low bit of y, then of z,
+ *   then the rest of y and z): T(x) and T(x + 1) are neighbours except across a block (x & 7 == 7: the second texel
+ *   is VRC_PK_CROSS elements further, fetched by a second, mostly inactive gather).  No copy: 4 bytes per voxel, and a
+ *   line is as deep as it is high -- what a tile touches per step is about the same for views along every axis. */
+#ifndef VRC_PK_LAYOUT
+#define VRC_PK_LAYOUT 2
+#endif
+#if VRC_PK_LAYOUT == 1
 #define VRC_PK_ROW 9u
 #define VRC_PK_SLICE ( VRC_PK_ROW * VRC_MB )
 #define VRC_PK_BLOCK ( VRC_PK_SLICE * VRC_MB ) /* 576 texels */
 VRC_HD uint32_t vrc_pk_x( uint32_t u ) { return ( u & 7u ) + VRC_PK_BLOCK * ( u >> 3 ); }
 VRC_HD uint32_t vrc_pk_y( uint32_t u, uint32_t sbx ) { return VRC_PK_ROW * ( u & 7u ) + VRC_PK_BLOCK * sbx * ( u >> 3 ); }
 VRC_HD uint32_t vrc_pk_z( uint32_t u, uint32_t sbx, uint32_t sby ) { return VRC_PK_SLICE * ( u & 7u ) + VRC_PK_BLOCK * sbx * sby * ( u >> 3 ); }
+#else
+#define VRC_PK_BLOCK VRC_MB_VOXELS /* 512 texels */
+#define VRC_PK_CROSS ( VRC_PK_BLOCK - 7u ) /* from T(x) at x & 7 == 7 to T(x + 1): position 0 of the next block */
+VRC_HD uint32_t vrc_pk_x( uint32_t u ) { return ( u & 7u ) + VRC_PK_BLOCK * ( u >> 3 ); }
+VRC_HD uint32_t vrc_pk_y( uint32_t u, uint32_t sbx ) { return ( ( u & 1u ) << 3 ) + ( ( ( u >> 1 ) & 3u ) << 5 ) + VRC_PK_BLOCK * sbx * ( u >> 3 ); }
+VRC_HD uint32_t vrc_pk_z( uint32_t u, uint32_t sbx, uint32_t sby ) { return ( ( u & 1u ) << 4 ) + ( ( ( u >> 1 ) & 3u ) << 7 ) + VRC_PK_BLOCK * sbx * sby * ( u >> 3 ); }
+#endif
 VRC_HD uint32_t vrc_packed_local_index( uint32_t x, uint32_t y, uint32_t z, uint32_t sbx, uint32_t sby )
 {
     return vrc_pk_x( x ) + vrc_pk_y( y, sbx ) + vrc_pk_z( z, sbx, sby );
+}
+/* slot-local voxel of packed element `in` of block `b` (the pack kernel's decode); x may be the copy's column (== 8) */
+VRC_HD void vrc_packed_decode( uint32_t in, uint32_t& ix, uint32_t& iy, uint32_t& iz )
+{
+#if VRC_PK_LAYOUT == 1
+    ix = in % VRC_PK_ROW;
+    iy = ( in / VRC_PK_ROW ) & 7u;
+    iz = in / VRC_PK_SLICE;
+#else
+    ix = in & 7u;
+    iy = ( ( in >> 3 ) & 1u ) | ( ( ( in >> 5 ) & 3u ) << 1 );
+    iz = ( ( in >> 4 ) & 1u ) | ( ( ( in >> 7 ) & 3u ) << 1 );
+#endif
 }
 /* texels of a packed slot / element offset of the packed slot that belongs to the byte slot at element slotBase
  * (byte slots are whole blocks of 512) */
@@ -1528,6 +1556,25 @@ VRC_HD vrc_texel_pair vrc_packed_load( const uint8_t* slot, uint32_t byteOffset 
 #endif
 }
 
+/* the pair of a sample whose lower tap is the last texel of a block row (layout 2): its second texel lies in the next
+ * block; only those lanes fetch it (x & 7 is the low three bits of the element's index) */
+VRC_HD void vrc_packed_cross( const uint8_t* slot, uint32_t byteOffset, vrc_texel_pair& t )
+{
+#if VRC_PK_LAYOUT != 1
+    if( ( byteOffset & 28u ) == 28u )
+    {
+#if defined( __HIP_DEVICE_COMPILE__ )
+        typedef __attribute__( ( address_space( 1 ) ) ) const uint32_t g_t;
+        t.t1 = *reinterpret_cast< g_t* >( (uintptr_t)( slot + byteOffset + 4u * VRC_PK_CROSS ) );
+#else
+        t.t1 = *reinterpret_cast< const uint32_t* >( slot + byteOffset + 4u * VRC_PK_CROSS );
+#endif
+    }
+#else
+    (void)slot; (void)byteOffset; (void)t;
+#endif
+}
+
 /* byte offsets (slot-local) of the texel pairs of the next N samples; p advances by N steps.  Device: the per-axis
  * parts from the tables in LDS (filled by the kernel with 4 * vrc_pk_x / y / z). */
 template < int N >
@@ -1562,7 +1609,7 @@ VRC_HD void vrc_packed_offsets( const vrc_sampler& s, vrc_fixpos& p, uint32_t* o
 }
 
 #ifndef VRC_PGROUP
-#define VRC_PGROUP 4
+#define VRC_PGROUP 8 /* (4, 6, 12 measured: 8 is the fastest off-axis -- more fetches in flight per wave -- and level on-axis) */
 #endif
 
 
@@ -1580,8 +1627,7 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
     if( !( travel > 0.0f ) )
         return false;
     const vrc_sampler sm = vrc_make_sampler( n, f );
-    /* the lane's packed slot: 9/8 of the byte slot's element offset, 4 bytes per texel (64 bits: a packed atlas passes
-     * 4 GiB at a byte atlas of 0.9 Gi voxels) */
+    /* the lane's packed slot: 4 bytes per texel (64 bits: a packed atlas passes 4 GiB at a byte atlas of 1 Gi voxels) */
     const uint8_t* const slot = reinterpret_cast< const uint8_t* >( packed ) + vrc_packed_elems( n.slotBase ) * 4u;
     vrc_fixpos fp = vrc_fixpos_init( sm, s.pos, s.step );
     /* texel centres at i + 0.5: the integer part of (coordinate - 0.5) is the lower tap, its fraction the weight */
@@ -1605,6 +1651,11 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
             t[k] = vrc_packed_load( slot, off[k] );
 #endif
         }
+#if !defined( VRC_PACKED_ABLATE )
+#pragma unroll
+        for( int k = 0; k < GROUP; ++k )
+            vrc_packed_cross( slot, off[k], t[k] );
+#endif
 #pragma unroll
         for( int k = 0; k < GROUP; ++k )
             travel -= stepSize; /* same sequential subtraction as the reference */
@@ -1662,9 +1713,13 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
             const bool v = travel > 0.0f;
             cnt += v ? 1u : 0u;
             /* a step the reference does not take reads the slot's first texels and blends nothing */
-            t[k] = vrc_packed_load( slot, v ? off[k] : 0u );
+            off[k] = v ? off[k] : 0u;
+            t[k] = vrc_packed_load( slot, off[k] );
             travel -= stepSize;
         }
+#pragma unroll
+        for( int k = 0; k < TAILG; ++k )
+            vrc_packed_cross( slot, off[k], t[k] );
 #pragma unroll
         for( int k = 0; k < TAILG; ++k )
         {

@@ -284,9 +284,9 @@ hipError_t vrc_launch_read_region( const void* atlas, void* dst, uint32_t elemBy
 
 /* ------------------------------------------------------------------------------------------
  * tap-packed atlas (vrc_core.h, "tap-packed form of the trilinear filter"): texel (x,y,z) of a slot =
- * v[x,y,z] | v[x,y+1,z] << 8 | v[x,y,z+1] << 16 | v[x,y+1,z+1] << 24 of the byte slot, in blocks of 9 x 8 x 8 texels
- * whose ninth column repeats the next block's first (neighbours and the copy clamped at the slot's last voxel: never
- * read with a weight -- a sample's lower tap is at most slotDim - 2 with overlap >= 1).  One thread per packed texel,
+ * v[x,y,z] | v[x,y+1,z] << 8 | v[x,y,z+1] << 16 | v[x,y+1,z+1] << 24 of the byte slot, in the block order of
+ * VRC_PK_LAYOUT (vrc_packed_decode; neighbours -- and layout 1's copy column -- clamped at the slot's last voxel: never
+ * read with a weight, a sample's lower tap is at most slotDim - 2 with overlap >= 1).  One thread per packed texel,
  * coalesced 4-byte stores; the byte reads hit L1/L2.
  * ---------------------------------------------------------------------------------------- */
 __global__ __launch_bounds__( 256 ) void vrc_k_pack_slots( const uint8_t* __restrict__ atlas, uint32_t* __restrict__ packed,
@@ -301,7 +301,8 @@ __global__ __launch_bounds__( 256 ) void vrc_k_pack_slots( const uint8_t* __rest
     for( uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x )
     {
         const uint32_t b = i / VRC_PK_BLOCK, in = i % VRC_PK_BLOCK;
-        const uint32_t ix = in % VRC_PK_ROW, iy = ( in / VRC_PK_ROW ) & 7u, iz = in / VRC_PK_SLICE;
+        uint32_t ix, iy, iz;
+        vrc_packed_decode( in, ix, iy, iz );
         uint32_t x = ( b % sbx ) * 8u + ix;
         const uint32_t y = ( ( b / sbx ) % sby ) * 8u + iy, z = ( b / ( sbx * sby ) ) * 8u + iz;
         x = x < sdx ? x : sdx - 1u;

@@ -107,8 +107,8 @@ static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3]
     const bool packedKernel = kernel >= 9 && kernel <= 12;
     if( packedKernel && ( voxelBytes != 1 || t.clamp || fracBits != 8 ) )
         return 5;
-    /* the tap-packed atlas as vrc_k_pack_slots writes it: blocks of 9 x 8 x 8 texels, the ninth column a copy of the
-     * next block's first, neighbours and the copy clamped at the slot's last voxel */
+    /* the tap-packed atlas as vrc_k_pack_slots writes it (vrc_core.h, VRC_PK_LAYOUT): neighbours -- and, in layout 1,
+     * the ninth column's copy -- clamped at the slot's last voxel */
     std::vector< uint32_t > packed( packedKernel ? (size_t)vrc_packed_elems( nVoxels ) : 0 );
     if( packedKernel )
     {
@@ -125,7 +125,7 @@ static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3]
                     for( uint32_t z = 0; z < slotDim[2]; ++z )
                         for( uint32_t y = 0; y < slotDim[1]; ++y )
                             for( uint32_t bx = 0; bx < sbx; ++bx )
-                                for( uint32_t ix = 0; ix < 9u; ++ix )
+                                for( uint32_t ix = 0; ix < ( VRC_PK_LAYOUT == 1 ? 9u : 8u ); ++ix )
                                 {
                                     uint32_t x = bx * 8u + ix;
                                     x = x < slotDim[0] ? x : slotDim[0] - 1u;
