@@ -685,7 +685,7 @@ static bool pool_enable_packed( vrc_pool* p )
         return true;
     if( p->packedFailed || !pool_packed_possible( p ) )
         return false;
-    const size_t bytes = (size_t)vrc_packed_elems( p->atlasBytes ) * 4u;
+    const size_t bytes = (size_t)vrc_packed_elems( p->atlasBytes ) * VRC_PK_TEXEL + 8u; /* (+ 8: a pair read at the last texel) */
     size_t freeMem = 0, totalMem = 0;
     hipError_t e = hipMemGetInfo( &freeMem, &totalMem );
     /* leave a margin for the caller's frame buffers and staging */

@@ -53,7 +53,7 @@
     defined( VRC_GREY_MAX_WAVES ) || \
     defined( VRC_TAIL_GROUP ) || \
     defined( VRC_LGROUP ) || \
-    defined( VRC_PGROUP ) || defined( VRC_PACKED_WAVES ) || defined( VRC_PACKED_ABLATE ) || defined( VRC_PK_LAYOUT ) || \
+    defined( VRC_PGROUP ) || defined( VRC_PACKED_WAVES ) || defined( VRC_PACKED_ABLATE ) || \
     defined( VRC_SPLIT_GROUP ) || \
     defined( VRC_SMALL_GROUP ) || \
     defined( VRC_SMALL_LAUNCH_TILES ) || \
@@ -1368,72 +1368,52 @@ VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n,
  * enum in the reference (cuda/TexturePool.cu:163-170, cudaFilterModePoint -> Linear) and free in its hardware; here
  * the eight taps were eight byte gathers (above) or a staged box in LDS (vrc_kernels_lds.hip), both bound by the
  * instructions and cache look-ups around the sample while HBM idles.  This form spends memory instead: next to the
- * byte atlas the pool keeps a second atlas whose 32-bit texel at (x,y,z) holds the 2x2 neighbourhood ACROSS x,
- *     T(x,y,z) = v[x,y,z] | v[x,y+1,z] << 8 | v[x,y,z+1] << 16 | v[x,y+1,z+1] << 24,
- * and in which T(x,y,z) and T(x+1,y,z) are ALWAYS neighbours in memory: the texels lie in blocks of 8x8x8 whose
- * x-rows carry a ninth texel, a copy of the next block's first (9/8 x 4 = 4.5 times the bytes of the byte atlas;
- * written by vrc_k_pack_slots when a brick is uploaded; the slot's overlap >= 1 supplies the +1 neighbours).  The
- * eight taps of a sample are then ONE 8-byte gather -- global_load_dwordx2 at a 4-byte-aligned address, T(x0,y0,z0)
- * and T(x0+1,y0,z0) -- eight byte -> float conversions straight out of the two registers and the seven
- * interpolations: no box, no staging, no walk batching, the same work for every view direction, and a quarter of
- * the vector-L1 tag look-ups of eight byte gathers (the unit that bounds every gather form of this kernel: a
- * look-up per 64-byte line per quad of lanes).
+ * byte atlas the pool keeps a second atlas of 16-bit texels, each a voxel and its neighbour along z,
+ *     t(x,y,z) = v[x,y,z] | v[x,y,z+1] << 8,
+ * in which t(x,y,z) and t(x+1,y,z) are ALWAYS neighbours in memory: the texels lie in blocks of 8x8x8 whose x-rows
+ * carry a ninth texel, a copy of the next block's first (9/8 x 2 = 2.25 times the bytes of the byte atlas; written by
+ * vrc_k_pack_slots when a brick is uploaded; the slot's overlap >= 1 supplies the +1 neighbours).  The eight taps of
+ * a sample are then TWO 4-byte gathers -- global_load_dword at 2-byte-aligned addresses that never leave an 18-byte
+ * row: t(x0, y0, z0) | t(x0+1, y0, z0) << 16 and the same at y0 + 1 -- eight byte -> float conversions straight out
+ * of the two registers and the seven interpolations: no box, no staging, no walk batching, the same work for every
+ * view direction.  The 64 rows of a block lie in Morton order of (y, z), so a 128-byte line holds 9 x 2 x 2 ... 9 x 4
+ * x 2 texels and what a tile touches per step is about the same along every axis.
+ * (Measured and dropped, profiles/r4_packed_kernel_experiments.txt: 32-bit texels of the 2x2 neighbourhood in (x, y)
+ * or (y, z) -- one 8-byte gather, twice the line fills --, rows of 8 with the pair across a block fetched by masked
+ * second gathers, and four other row orders.)
  *
  * Sample positions, weights, interpolation and classification are the staged kernel's, operation for operation
  * (8.24 fixed-point positions from vrc_fixpos_init minus half a voxel, 24-bit weights used unscaled, x then y then
  * z, the transfer function through CUDA's 1.8 fixed-point weight out of one float -> integer conversion), so the
  * two forms composite the same numbers.
  * ---------------------------------------------------------------------------------------- */
-/* slot-local element order of the packed atlas: offset = PX(x) + PY(y) + PZ(z), blocks x-fastest inside the slot.
- * VRC_PK_LAYOUT 1: blocks of 9 x 8 x 8 texels (x fastest); position 8 of a row holds the texel at 8 * (block + 1),
- *   clamped to the slot's last column: T(x) and T(x + 1) are ALWAYS neighbours.  Slots are 9/8 of the byte atlas's.
- * VRC_PK_LAYOUT 2: blocks of 8 x 8 x 8 texels in 128-byte lines of 8 x 2 x 2 (x, then the low bit of y, then of z,
- *   then the rest of y and z): T(x) and T(x + 1) are neighbours except across a block (x & 7 == 7: the second texel
- *   is VRC_PK_CROSS elements further, fetched by a second, mostly inactive gather).  No copy: 4 bytes per voxel, and a
- *   line is as deep as it is high -- what a tile touches per step is about the same for views along every axis. */
-#ifndef VRC_PK_LAYOUT
-#define VRC_PK_LAYOUT 2
-#endif
-#if VRC_PK_LAYOUT == 1
+/* slot-local element order of the packed atlas: offset = PX(x) + PY(y) + PZ(z), blocks x-fastest inside the slot */
+#define VRC_PK_TEXEL 2u /* bytes per texel */
 #define VRC_PK_ROW 9u
-#define VRC_PK_SLICE ( VRC_PK_ROW * VRC_MB )
-#define VRC_PK_BLOCK ( VRC_PK_SLICE * VRC_MB ) /* 576 texels */
+#define VRC_PK_BLOCK ( VRC_PK_ROW * 64u ) /* 576 texels */
+/* row number of (y & 7, z & 7) inside a block: the bits of y and z interleaved */
+VRC_HD uint32_t vrc_pk_ry( uint32_t u ) { return ( u & 1u ) | ( ( ( u >> 1 ) & 1u ) << 2 ) | ( ( ( u >> 2 ) & 1u ) << 4 ); }
+VRC_HD uint32_t vrc_pk_rz( uint32_t u ) { return vrc_pk_ry( u ) << 1; }
 VRC_HD uint32_t vrc_pk_x( uint32_t u ) { return ( u & 7u ) + VRC_PK_BLOCK * ( u >> 3 ); }
-VRC_HD uint32_t vrc_pk_y( uint32_t u, uint32_t sbx ) { return VRC_PK_ROW * ( u & 7u ) + VRC_PK_BLOCK * sbx * ( u >> 3 ); }
-VRC_HD uint32_t vrc_pk_z( uint32_t u, uint32_t sbx, uint32_t sby ) { return VRC_PK_SLICE * ( u & 7u ) + VRC_PK_BLOCK * sbx * sby * ( u >> 3 ); }
-#else
-#define VRC_PK_BLOCK VRC_MB_VOXELS /* 512 texels */
-#define VRC_PK_CROSS ( VRC_PK_BLOCK - 7u ) /* from T(x) at x & 7 == 7 to T(x + 1): position 0 of the next block */
-VRC_HD uint32_t vrc_pk_x( uint32_t u ) { return ( u & 7u ) + VRC_PK_BLOCK * ( u >> 3 ); }
-VRC_HD uint32_t vrc_pk_y( uint32_t u, uint32_t sbx ) { return ( ( u & 1u ) << 3 ) + ( ( ( u >> 1 ) & 3u ) << 5 ) + VRC_PK_BLOCK * sbx * ( u >> 3 ); }
-VRC_HD uint32_t vrc_pk_z( uint32_t u, uint32_t sbx, uint32_t sby ) { return ( ( u & 1u ) << 4 ) + ( ( ( u >> 1 ) & 3u ) << 7 ) + VRC_PK_BLOCK * sbx * sby * ( u >> 3 ); }
-#endif
+VRC_HD uint32_t vrc_pk_y( uint32_t u, uint32_t sbx ) { return VRC_PK_ROW * vrc_pk_ry( u ) + VRC_PK_BLOCK * sbx * ( u >> 3 ); }
+VRC_HD uint32_t vrc_pk_z( uint32_t u, uint32_t sbx, uint32_t sby ) { return VRC_PK_ROW * vrc_pk_rz( u ) + VRC_PK_BLOCK * sbx * sby * ( u >> 3 ); }
 VRC_HD uint32_t vrc_packed_local_index( uint32_t x, uint32_t y, uint32_t z, uint32_t sbx, uint32_t sby )
 {
     return vrc_pk_x( x ) + vrc_pk_y( y, sbx ) + vrc_pk_z( z, sbx, sby );
 }
-/* slot-local voxel of packed element `in` of block `b` (the pack kernel's decode); x may be the copy's column (== 8) */
+/* slot-local voxel of packed element `in` of a block (the pack kernel's decode); ix == 8: the copy's column */
 VRC_HD void vrc_packed_decode( uint32_t in, uint32_t& ix, uint32_t& iy, uint32_t& iz )
 {
-#if VRC_PK_LAYOUT == 1
+    const uint32_t r = in / VRC_PK_ROW;
     ix = in % VRC_PK_ROW;
-    iy = ( in / VRC_PK_ROW ) & 7u;
-    iz = in / VRC_PK_SLICE;
-#else
-    ix = in & 7u;
-    iy = ( ( in >> 3 ) & 1u ) | ( ( ( in >> 5 ) & 3u ) << 1 );
-    iz = ( ( in >> 4 ) & 1u ) | ( ( ( in >> 7 ) & 3u ) << 1 );
-#endif
+    iy = ( r & 1u ) | ( ( ( r >> 2 ) & 1u ) << 1 ) | ( ( ( r >> 4 ) & 1u ) << 2 );
+    iz = ( ( r >> 1 ) & 1u ) | ( ( ( r >> 3 ) & 1u ) << 1 ) | ( ( ( r >> 5 ) & 1u ) << 2 );
 }
 /* texels of a packed slot / element offset of the packed slot that belongs to the byte slot at element slotBase
  * (byte slots are whole blocks of 512) */
 VRC_HD uint64_t vrc_packed_elems( uint64_t byteElems ) { return byteElems / VRC_MB_VOXELS * VRC_PK_BLOCK; }
 
-VRC_HD uint32_t vrc_pack_taps( uint32_t v00, uint32_t v10, uint32_t v01, uint32_t v11 )
-{
-    /* (y0,z0), (y1,z0), (y0,z1), (y1,z1) at one x */
-    return v00 | ( v10 << 8 ) | ( v01 << 16 ) | ( v11 << 24 );
-}
+VRC_HD uint16_t vrc_pack_taps( uint32_t vz0, uint32_t vz1 ) { return (uint16_t)( vz0 | ( vz1 << 8 ) ); }
 
 /* classifier of a trilinear sample that arrives scaled by 2^72 (three unscaled 24-bit weights): the oracle's
  * orc_tf_fetch + composite (cuda/ColorMap.cu:40-45, cuda/Renderer.cu:83-93) with the transfer-function texel pair
@@ -1519,66 +1499,48 @@ VRC_HD vrc_f4 vrc_classify8( const vrc_f4*, const vrc_f4* tab, float d, const vr
     return e;
 }
 
-/* the interpolated density of a sample, times 2^72: texels T0 = T(x0,y0,z0) and T1 = T(x0+1,y0,z0), weights = the 24
- * fraction bits of the sample's 8.24 coordinates, NOT scaled by 2^-24 -- W and 2^24 - W are exact, so every product
- * and sum is 2^24 (2^48, 2^72) times the one with scaled weights, bit for bit; vrc_cls8.mult carries the 2^-72.
- * The oracle's order: x, then y, then z; a * (1 - w) + b * w. */
+/* the interpolated density of a sample, times 2^72: T0 = t(x0,y0,z0) | t(x0+1,y0,z0) << 16, T1 the same at y0 + 1 (a
+ * texel's low byte is z0, its high byte z0 + 1); weights = the 24 fraction bits of the sample's 8.24 coordinates, NOT
+ * scaled by 2^-24 -- W and 2^24 - W are exact, so every product and sum is 2^24 (2^48, 2^72) times the one with scaled
+ * weights, bit for bit; vrc_cls8.mult carries the 2^-72.  The oracle's order: x, then y, then z; a * (1 - w) + b * w. */
 VRC_HD float vrc_trilerp_packed( uint32_t T0, uint32_t T1, uint32_t fx, uint32_t fy, uint32_t fz )
 {
     const float wx = (float)( fx & 0xFFFFFFu ), wy = (float)( fy & 0xFFFFFFu ), wz = (float)( fz & 0xFFFFFFu );
     const float ux = 16777216.0f - wx, uy = 16777216.0f - wy, uz = 16777216.0f - wz;
-    const float c00 = __builtin_fmaf( (float)( T1 & 255u ), wx, (float)( T0 & 255u ) * ux );                  /* y0 z0 */
-    const float c10 = __builtin_fmaf( (float)( ( T1 >> 8 ) & 255u ), wx, (float)( ( T0 >> 8 ) & 255u ) * ux );   /* y1 z0 */
-    const float c01 = __builtin_fmaf( (float)( ( T1 >> 16 ) & 255u ), wx, (float)( ( T0 >> 16 ) & 255u ) * ux ); /* y0 z1 */
-    const float c11 = __builtin_fmaf( (float)( T1 >> 24 ), wx, (float)( T0 >> 24 ) * ux );                    /* y1 z1 */
+    const float c00 = __builtin_fmaf( (float)( ( T0 >> 16 ) & 255u ), wx, (float)( T0 & 255u ) * ux );  /* y0 z0 */
+    const float c01 = __builtin_fmaf( (float)( T0 >> 24 ), wx, (float)( ( T0 >> 8 ) & 255u ) * ux );    /* y0 z1 */
+    const float c10 = __builtin_fmaf( (float)( ( T1 >> 16 ) & 255u ), wx, (float)( T1 & 255u ) * ux );  /* y1 z0 */
+    const float c11 = __builtin_fmaf( (float)( T1 >> 24 ), wx, (float)( ( T1 >> 8 ) & 255u ) * ux );    /* y1 z1 */
     const float c0 = __builtin_fmaf( c10, wy, c00 * uy );
     const float c1 = __builtin_fmaf( c11, wy, c01 * uy );
     return __builtin_fmaf( c1, wz, c0 * uz );
 }
 
-/* texel pair at a byte offset of the lane's packed slot: one 8-byte load at a 4-byte-aligned address.  On the
- * device the pointer is typed as global memory and as a two-dword vector of 4-byte alignment, so the compiler emits
- * one global_load_dwordx2 (multi-dword loads need dword alignment only). */
+/* the two texel pairs of a sample at byte offsets of the lane's packed slot: 4-byte loads at 2-byte-aligned
+ * addresses.  On the device the pointer is typed as global memory, so the compiler emits global_load_dword. */
 struct vrc_texel_pair
 {
     uint32_t t0, t1;
 };
-VRC_HD vrc_texel_pair vrc_packed_load( const uint8_t* slot, uint32_t byteOffset )
+VRC_HD vrc_texel_pair vrc_packed_load( const uint8_t* slot, uint32_t byteOffset, uint32_t byteOffsetY1 )
 {
 #if defined( __HIP_DEVICE_COMPILE__ )
-    typedef uint32_t u32x2_a4 __attribute__( ( ext_vector_type( 2 ), aligned( 4 ) ) );
-    typedef __attribute__( ( address_space( 1 ) ) ) const u32x2_a4 g_t;
-    const u32x2_a4 v = *reinterpret_cast< g_t* >( (uintptr_t)( slot + byteOffset ) );
-    return vrc_texel_pair{ v.x, v.y };
+    typedef uint32_t u32_a2 __attribute__( ( aligned( 2 ) ) );
+    typedef __attribute__( ( address_space( 1 ) ) ) const u32_a2 g_t;
+    return vrc_texel_pair{ *reinterpret_cast< g_t* >( (uintptr_t)( slot + byteOffset ) ),
+                           *reinterpret_cast< g_t* >( (uintptr_t)( slot + byteOffsetY1 ) ) };
 #else
-    const uint32_t* const p = reinterpret_cast< const uint32_t* >( slot + byteOffset );
-    return vrc_texel_pair{ p[0], p[1] };
-#endif
-}
-
-/* the pair of a sample whose lower tap is the last texel of a block row (layout 2): its second texel lies in the next
- * block; only those lanes fetch it (x & 7 is the low three bits of the element's index) */
-VRC_HD void vrc_packed_cross( const uint8_t* slot, uint32_t byteOffset, vrc_texel_pair& t )
-{
-#if VRC_PK_LAYOUT != 1
-    if( ( byteOffset & 28u ) == 28u )
-    {
-#if defined( __HIP_DEVICE_COMPILE__ )
-        typedef __attribute__( ( address_space( 1 ) ) ) const uint32_t g_t;
-        t.t1 = *reinterpret_cast< g_t* >( (uintptr_t)( slot + byteOffset + 4u * VRC_PK_CROSS ) );
-#else
-        t.t1 = *reinterpret_cast< const uint32_t* >( slot + byteOffset + 4u * VRC_PK_CROSS );
-#endif
-    }
-#else
-    (void)slot; (void)byteOffset; (void)t;
+    vrc_texel_pair t;
+    memcpy( &t.t0, slot + byteOffset, 4 );
+    memcpy( &t.t1, slot + byteOffsetY1, 4 );
+    return t;
 #endif
 }
 
 /* byte offsets (slot-local) of the texel pairs of the next N samples; p advances by N steps.  Device: the per-axis
- * parts from the tables in LDS (filled by the kernel with 4 * vrc_pk_x / y / z). */
+ * parts from the tables in LDS (filled by the kernel with VRC_PK_TEXEL * vrc_pk_x / y / z). */
 template < int N >
-VRC_HD void vrc_packed_offsets( const vrc_sampler& s, vrc_fixpos& p, uint32_t* off )
+VRC_HD void vrc_packed_offsets( const vrc_sampler& s, vrc_fixpos& p, uint32_t* off, uint32_t* offY1 )
 {
 #if defined( __HIP_DEVICE_COMPILE__ ) && defined( VRC_ADDR_TABLES )
     (void)s;
@@ -1587,9 +1549,10 @@ VRC_HD void vrc_packed_offsets( const vrc_sampler& s, vrc_fixpos& p, uint32_t* o
     {
         const char* const t = reinterpret_cast< const char* >( vrc_addr_tab );
         const uint32_t tx = *reinterpret_cast< const uint32_t* >( t + ( ( p.x >> 22 ) & 0x3FCu ) );
-        const uint32_t ty = *reinterpret_cast< const uint32_t* >( t + 1024 + ( ( p.y >> 22 ) & 0x3FCu ) );
+        const uint32_t* const py = reinterpret_cast< const uint32_t* >( t + 1024 + ( ( p.y >> 22 ) & 0x3FCu ) );
         const uint32_t tz = *reinterpret_cast< const uint32_t* >( t + 2048 + ( ( p.z >> 22 ) & 0x3FCu ) );
-        off[k] = tx + ty + tz;
+        off[k] = tx + py[0] + tz;
+        offY1[k] = tx + py[1] + tz; /* (y = 255 reads the z table's first entry: no sample with a weight has it) */
         p.x += p.dx;
         p.y += p.dy;
         p.z += p.dz;
@@ -1600,7 +1563,8 @@ VRC_HD void vrc_packed_offsets( const vrc_sampler& s, vrc_fixpos& p, uint32_t* o
 #pragma unroll
     for( int k = 0; k < N; ++k )
     {
-        off[k] = 4u * vrc_packed_local_index( p.x >> 24, p.y >> 24, p.z >> 24, sbx, sby );
+        off[k] = VRC_PK_TEXEL * vrc_packed_local_index( p.x >> 24, p.y >> 24, p.z >> 24, sbx, sby );
+        offY1[k] = VRC_PK_TEXEL * vrc_packed_local_index( p.x >> 24, ( ( p.y >> 24 ) + 1u ) & 255u, p.z >> 24, sbx, sby );
         p.x += p.dx;
         p.y += p.dy;
         p.z += p.dz;
@@ -1609,7 +1573,7 @@ VRC_HD void vrc_packed_offsets( const vrc_sampler& s, vrc_fixpos& p, uint32_t* o
 }
 
 #ifndef VRC_PGROUP
-#define VRC_PGROUP 8 /* (4, 6, 12 measured: 8 is the fastest off-axis -- more fetches in flight per wave -- and level on-axis) */
+#define VRC_PGROUP 12 /* (4 ... 24 measured: the fetches in flight per wave decide; 12 at three waves per SIMD) */
 #endif
 
 
@@ -1628,7 +1592,7 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
         return false;
     const vrc_sampler sm = vrc_make_sampler( n, f );
     /* the lane's packed slot: 4 bytes per texel (64 bits: a packed atlas passes 4 GiB at a byte atlas of 1 Gi voxels) */
-    const uint8_t* const slot = reinterpret_cast< const uint8_t* >( packed ) + vrc_packed_elems( n.slotBase ) * 4u;
+    const uint8_t* const slot = reinterpret_cast< const uint8_t* >( packed ) + vrc_packed_elems( n.slotBase ) * VRC_PK_TEXEL;
     vrc_fixpos fp = vrc_fixpos_init( sm, s.pos, s.step );
     /* texel centres at i + 0.5: the integer part of (coordinate - 0.5) is the lower tap, its fraction the weight */
     fp.x -= 1u << 23;
@@ -1638,24 +1602,19 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
     const float guard = stepSize * (float)( GROUP + 1 );
     while( travel > guard )
     {
-        uint32_t off[GROUP];
+        uint32_t off[GROUP], offY1[GROUP];
         vrc_texel_pair t[GROUP];
         vrc_fixpos q = fp; /* the group's first sample: the weights are taken again from here after the loads */
-        vrc_packed_offsets< GROUP >( sm, fp, off );
+        vrc_packed_offsets< GROUP >( sm, fp, off, offY1 );
 #pragma unroll
         for( int k = 0; k < GROUP; ++k )
         {
 #if defined( VRC_PACKED_ABLATE ) && VRC_PACKED_ABLATE == 1 /* timing experiment only: no fetch */
             t[k] = vrc_texel_pair{ off[k] * 0x01010101u, off[k] * 0x00010101u };
 #else
-            t[k] = vrc_packed_load( slot, off[k] );
+            t[k] = vrc_packed_load( slot, off[k], offY1[k] );
 #endif
         }
-#if !defined( VRC_PACKED_ABLATE )
-#pragma unroll
-        for( int k = 0; k < GROUP; ++k )
-            vrc_packed_cross( slot, off[k], t[k] );
-#endif
 #pragma unroll
         for( int k = 0; k < GROUP; ++k )
             travel -= stepSize; /* same sequential subtraction as the reference */
@@ -1703,10 +1662,10 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
     constexpr int TAILG = GROUP >= 4 ? GROUP / 2 : 1;
     while( travel > 0.0f && !done )
     {
-        uint32_t off[TAILG], cnt = 0;
+        uint32_t off[TAILG], offY1[TAILG], cnt = 0;
         vrc_texel_pair t[TAILG];
         vrc_fixpos q = fp;
-        vrc_packed_offsets< TAILG >( sm, fp, off );
+        vrc_packed_offsets< TAILG >( sm, fp, off, offY1 );
 #pragma unroll
         for( int k = 0; k < TAILG; ++k )
         {
@@ -1714,12 +1673,10 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
             cnt += v ? 1u : 0u;
             /* a step the reference does not take reads the slot's first texels and blends nothing */
             off[k] = v ? off[k] : 0u;
-            t[k] = vrc_packed_load( slot, off[k] );
+            offY1[k] = v ? offY1[k] : 0u;
+            t[k] = vrc_packed_load( slot, off[k], offY1[k] );
             travel -= stepSize;
         }
-#pragma unroll
-        for( int k = 0; k < TAILG; ++k )
-            vrc_packed_cross( slot, off[k], t[k] );
 #pragma unroll
         for( int k = 0; k < TAILG; ++k )
         {

@@ -284,20 +284,21 @@ hipError_t vrc_launch_read_region( const void* atlas, void* dst, uint32_t elemBy
 
 /* ------------------------------------------------------------------------------------------
  * tap-packed atlas (vrc_core.h, "tap-packed form of the trilinear filter"): texel (x,y,z) of a slot =
- * v[x,y,z] | v[x,y+1,z] << 8 | v[x,y,z+1] << 16 | v[x,y+1,z+1] << 24 of the byte slot, in the block order of
- * VRC_PK_LAYOUT (vrc_packed_decode; neighbours -- and layout 1's copy column -- clamped at the slot's last voxel: never
- * read with a weight, a sample's lower tap is at most slotDim - 2 with overlap >= 1).  One thread per packed texel,
- * coalesced 4-byte stores; the byte reads hit L1/L2.
+ * v[x,y,z] | v[x,y,z+1] << 8 of the byte slot, in blocks of 64 rows of 9 texels (vrc_packed_decode; the ninth column
+ * repeats the next block's first; the z neighbour and the copy clamped at the slot's last voxel: never read with a
+ * weight, a sample's lower tap is at most slotDim - 2 with overlap >= 1).  One thread per packed texel, coalesced
+ * 2-byte stores; the byte reads hit L1/L2.
  * ---------------------------------------------------------------------------------------- */
-__global__ __launch_bounds__( 256 ) void vrc_k_pack_slots( const uint8_t* __restrict__ atlas, uint32_t* __restrict__ packed,
+__global__ __launch_bounds__( 256 ) void vrc_k_pack_slots( const uint8_t* __restrict__ atlas, uint16_t* __restrict__ packed,
                                                            uint64_t firstSlot, uint32_t slotBlocks, uint32_t sdx, uint32_t sdy,
                                                            uint32_t sdz, uint32_t sbx, uint32_t sby )
 {
     /* blockIdx.y = the slot (64-bit only in its base), x strides over the slot's packed texels in 32 bits */
     const uint64_t slotIndex = firstSlot + blockIdx.y;
     const uint8_t* const slot = atlas + slotIndex * ( (uint64_t)slotBlocks * VRC_MB_VOXELS );
-    uint32_t* const out = packed + slotIndex * ( (uint64_t)slotBlocks * VRC_PK_BLOCK );
+    uint16_t* const out = packed + slotIndex * ( (uint64_t)slotBlocks * VRC_PK_BLOCK );
     const uint32_t n = slotBlocks * VRC_PK_BLOCK;
+    (void)sdy;
     for( uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x )
     {
         const uint32_t b = i / VRC_PK_BLOCK, in = i % VRC_PK_BLOCK;
@@ -306,9 +307,8 @@ __global__ __launch_bounds__( 256 ) void vrc_k_pack_slots( const uint8_t* __rest
         uint32_t x = ( b % sbx ) * 8u + ix;
         const uint32_t y = ( ( b / sbx ) % sby ) * 8u + iy, z = ( b / ( sbx * sby ) ) * 8u + iz;
         x = x < sdx ? x : sdx - 1u;
-        const uint32_t y1 = y + 1u < sdy ? y + 1u : y, z1 = z + 1u < sdz ? z + 1u : z;
-        out[i] = vrc_pack_taps( slot[vrc_slot_local_index( x, y, z, sbx, sby )], slot[vrc_slot_local_index( x, y1, z, sbx, sby )],
-                                slot[vrc_slot_local_index( x, y, z1, sbx, sby )], slot[vrc_slot_local_index( x, y1, z1, sbx, sby )] );
+        const uint32_t z1 = z + 1u < sdz ? z + 1u : z;
+        out[i] = vrc_pack_taps( slot[vrc_slot_local_index( x, y, z, sbx, sby )], slot[vrc_slot_local_index( x, y, z1, sbx, sby )] );
     }
 }
 
@@ -326,7 +326,7 @@ hipError_t vrc_launch_pack_slots( const void* atlas, void* packed, uint64_t firs
     {
         const uint32_t ns = (uint32_t)std::min< uint64_t >( nSlots - s0, 65535u );
         hipLaunchKernelGGL( vrc_k_pack_slots, dim3( nSlots > 64u ? std::min( gx, 64u ) : gx, ns ), dim3( 256 ), 0, stream,
-                            (const uint8_t*)atlas, (uint32_t*)packed, firstSlot + s0, slotBlocks, slotDim[0], slotDim[1], slotDim[2],
+                            (const uint8_t*)atlas, (uint16_t*)packed, firstSlot + s0, slotBlocks, slotDim[0], slotDim[1], slotDim[2],
                             slotDim[0] >> VRC_MB_SHIFT, slotDim[1] >> VRC_MB_SHIFT );
     }
     return hipGetLastError();
@@ -480,7 +480,7 @@ hipError_t vrc_launch_tile_order( const vrc_frame& f, uint32_t* order, uint32_t*
 #define VRC_GREY_GROUP 14
 #endif
 #ifndef VRC_PACKED_WAVES
-#define VRC_PACKED_WAVES 4 /* (developer switch; 6 and 8 measured slower on C2) */
+#define VRC_PACKED_WAVES 3 /* (developer switch; 2 ... 6 measured on C2 with groups of 4 ... 24: the group decides, not the waves) */
 #endif
 #if defined( VRC_WG_TIMELINE )
 /* developer build (tools/dev_timeline.py): when every wave of the last launch started and ended
@@ -588,9 +588,9 @@ __global__ __launch_bounds__( VRC_WG_THREADS ) __attribute__( ( amdgpu_waves_per
         /* per-axis BYTE offsets of the packed atlas's texels (vrc_core.h: vrc_pk_x / y / z) */
         for( uint32_t u = tid; u < 256u; u += VRC_WG_THREADS )
         {
-            vrc_addr_tab[u] = 4u * vrc_pk_x( u );
-            vrc_addr_tab[256u + u] = 4u * vrc_pk_y( u, f.sbx );
-            vrc_addr_tab[512u + u] = 4u * vrc_pk_z( u, f.sbx, f.sby );
+            vrc_addr_tab[u] = VRC_PK_TEXEL * vrc_pk_x( u );
+            vrc_addr_tab[256u + u] = VRC_PK_TEXEL * vrc_pk_y( u, f.sbx );
+            vrc_addr_tab[512u + u] = VRC_PK_TEXEL * vrc_pk_z( u, f.sbx, f.sby );
         }
     }
     else if( FIXED )

@@ -61,9 +61,9 @@ __global__ __launch_bounds__( VRC_RL_THREADS, VRC_RL_MIN_BLOCKS ) void vrc_k_ray
     {
         for( uint32_t u = tid; u < 256u; u += VRC_RL_THREADS )
         {
-            vrc_addr_tab[u] = 4u * vrc_pk_x( u );
-            vrc_addr_tab[256u + u] = 4u * vrc_pk_y( u, f.sbx );
-            vrc_addr_tab[512u + u] = 4u * vrc_pk_z( u, f.sbx, f.sby );
+            vrc_addr_tab[u] = VRC_PK_TEXEL * vrc_pk_x( u );
+            vrc_addr_tab[256u + u] = VRC_PK_TEXEL * vrc_pk_y( u, f.sbx );
+            vrc_addr_tab[512u + u] = VRC_PK_TEXEL * vrc_pk_z( u, f.sbx, f.sby );
         }
     }
     else if( FIXED )

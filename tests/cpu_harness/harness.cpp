@@ -107,32 +107,29 @@ static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3]
     const bool packedKernel = kernel >= 9 && kernel <= 12;
     if( packedKernel && ( voxelBytes != 1 || t.clamp || fracBits != 8 ) )
         return 5;
-    /* the tap-packed atlas as vrc_k_pack_slots writes it (vrc_core.h, VRC_PK_LAYOUT): neighbours -- and, in layout 1,
-     * the ninth column's copy -- clamped at the slot's last voxel */
-    std::vector< uint32_t > packed( packedKernel ? (size_t)vrc_packed_elems( nVoxels ) : 0 );
+    /* the tap-packed atlas as vrc_k_pack_slots writes it (vrc_core.h): 16-bit texels in rows of 9, the z neighbour and
+     * the ninth column's copy clamped at the slot's last voxel (+ 2 words: a pair is read as 4 bytes) */
+    std::vector< uint32_t > packed( packedKernel ? (size_t)( vrc_packed_elems( nVoxels ) * VRC_PK_TEXEL / 4u + 2u ) : 0 );
     if( packedKernel )
     {
         const uint32_t sbx = slotDim[0] / 8u, sby = slotDim[1] / 8u;
-        const uint64_t slotVoxels = (uint64_t)slotDim[0] * slotDim[1] * slotDim[2];
         for( uint32_t k = 0; k < geom.slots[2]; ++k )
             for( uint32_t j = 0; j < geom.slots[1]; ++j )
                 for( uint32_t i = 0; i < geom.slots[0]; ++i )
                 {
                     const uint64_t base = vrc_slot_base( lay, i, j, k ); /* of the byte slot */
                     const uint8_t* const slot = atlas.data() + base;
-                    uint32_t* const out = packed.data() + vrc_packed_elems( base );
-                    (void)slotVoxels;
+                    uint16_t* const out = reinterpret_cast< uint16_t* >( packed.data() ) + vrc_packed_elems( base );
                     for( uint32_t z = 0; z < slotDim[2]; ++z )
                         for( uint32_t y = 0; y < slotDim[1]; ++y )
                             for( uint32_t bx = 0; bx < sbx; ++bx )
-                                for( uint32_t ix = 0; ix < ( VRC_PK_LAYOUT == 1 ? 9u : 8u ); ++ix )
+                                for( uint32_t ix = 0; ix < VRC_PK_ROW; ++ix )
                                 {
                                     uint32_t x = bx * 8u + ix;
                                     x = x < slotDim[0] ? x : slotDim[0] - 1u;
-                                    const uint32_t y1 = y + 1u < slotDim[1] ? y + 1u : y, z1 = z + 1u < slotDim[2] ? z + 1u : z;
+                                    const uint32_t z1 = z + 1u < slotDim[2] ? z + 1u : z;
                                     out[vrc_packed_local_index( bx * 8u, y, z, sbx, sby ) + ix] =
-                                        vrc_pack_taps( slot[vrc_slot_local_index( x, y, z, sbx, sby )], slot[vrc_slot_local_index( x, y1, z, sbx, sby )],
-                                                       slot[vrc_slot_local_index( x, y, z1, sbx, sby )], slot[vrc_slot_local_index( x, y1, z1, sbx, sby )] );
+                                        vrc_pack_taps( slot[vrc_slot_local_index( x, y, z, sbx, sby )], slot[vrc_slot_local_index( x, y, z1, sbx, sby )] );
                                 }
                 }
     }
