@@ -671,7 +671,7 @@ static int pool_upload( vrc_pool* p, const void* src, bool srcIsDevice, const ui
     return VRC_OK;
 }
 
-/* The tap-packed atlas of the trilinear filter, on first use: 4.5 times the byte atlas, filled from it on the upload
+/* The tap-packed atlas of the trilinear filter, on first use: 2.25 times the byte atlas, filled from it on the upload
  * stream behind every upload queued so far.  false (and no error) when the pool cannot have one: 16-bit voxels, more
  * than 2^32 voxels, or not enough device memory (tried once). */
 static bool pool_packed_possible( const vrc_pool* p )
@@ -1216,7 +1216,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         return fail( VRC_EINVAL, "vrc_render: under per-ray LOD the LDS kernel needs the trilinear filter, 8- or 16-bit bricks with overlap >= 1 and VRC_OPT_TF_FRAC_BITS = 8" );
     /* tap-packed atlas (VRC_KERNEL_PACKED; vrc_core.h): the trilinear filter as two dword gathers per sample.  Needs what
      * its positions and its classifier need -- 8-bit bricks with overlap >= 1 in slots of at most 248 voxels a side, an
-     * atlas of at most 2^32 voxels, VRC_OPT_TF_FRAC_BITS = 8 -- and 4.5 times the atlas in device memory; either brick
+     * atlas of at most 2^32 voxels, VRC_OPT_TF_FRAC_BITS = 8 -- and 2.25 times the atlas in device memory; either brick
      * enumeration (grid walk where the node set is grid-aligned, else the reference-order loop) */
     const bool packedEligible = linear && !glSuper && !c->cachedClamp && slotsFit8Bits &&
                                 pool_packed_possible( pool ) && c->optTfFracBits == 8 && c->optStepping != 0;
@@ -1226,7 +1226,7 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
         if( !packedEligible )
             return fail( VRC_EINVAL, "vrc_render: the packed kernel needs the trilinear filter on 8-bit bricks with overlap >= 1 (slots of at most 248 voxels a side, an atlas of at most 2^32 voxels), VRC_OPT_TF_FRAC_BITS = 8, fixed-point stepping" );
         if( !pool_enable_packed( pool ) )
-            return fail( VRC_ENOMEM, "vrc_render: no device memory for the tap-packed atlas (4.5 times the brick atlas)" );
+            return fail( VRC_ENOMEM, "vrc_render: no device memory for the tap-packed atlas (2.25 times the brick atlas)" );
         usePacked = true;
     }
     else if( c->optKernel == VRC_KERNEL_AUTO && packedEligible && c->optPackedAtlas )
@@ -1326,6 +1326,8 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     a.gridTable = ( useDda || c->rayLod ) ? c->dGrid : nullptr;
     a.atlas = usePacked ? pool->dPacked : pool->dAtlas;
     a.packed = usePacked;
+    /* a packed atlas of more than 4 GiB: 64-bit lane pointers (the BIG instances of the packed modes) */
+    a.packedWide = usePacked && vrc_packed_elems( pool->atlasBytes ) * VRC_PK_TEXEL + 8u > 0xFFFFFFFFull;
     a.lut = c->dLut;
     a.pixelBuffer = ctx_fb( c );
     a.sampleCounter = c->optCount ? c->dCounter : nullptr;

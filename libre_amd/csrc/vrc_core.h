@@ -1524,6 +1524,10 @@ struct vrc_texel_pair
 };
 VRC_HD vrc_texel_pair vrc_packed_load( const uint8_t* slot, uint32_t byteOffset, uint32_t byteOffsetY1 )
 {
+#if defined( VRC_PACKED_ABLATE ) && VRC_PACKED_ABLATE == 3 /* timing experiment only: 4-byte-aligned (wrong) addresses */
+    byteOffset &= ~2u;
+    byteOffsetY1 &= ~2u;
+#endif
 #if defined( __HIP_DEVICE_COMPILE__ )
     typedef uint32_t u32_a2 __attribute__( ( aligned( 2 ) ) );
     typedef __attribute__( ( address_space( 1 ) ) ) const u32_a2 g_t;
@@ -1537,10 +1541,10 @@ VRC_HD vrc_texel_pair vrc_packed_load( const uint8_t* slot, uint32_t byteOffset,
 #endif
 }
 
-/* byte offsets (slot-local) of the texel pairs of the next N samples; p advances by N steps.  Device: the per-axis
+/* byte offsets (slot-local + bias) of the texel pairs of the next N samples; p advances by N steps.  Device: the per-axis
  * parts from the tables in LDS (filled by the kernel with VRC_PK_TEXEL * vrc_pk_x / y / z). */
 template < int N >
-VRC_HD void vrc_packed_offsets( const vrc_sampler& s, vrc_fixpos& p, uint32_t* off, uint32_t* offY1 )
+VRC_HD void vrc_packed_offsets( const vrc_sampler& s, vrc_fixpos& p, uint32_t bias, uint32_t* off, uint32_t* offY1 )
 {
 #if defined( __HIP_DEVICE_COMPILE__ ) && defined( VRC_ADDR_TABLES )
     (void)s;
@@ -1551,8 +1555,9 @@ VRC_HD void vrc_packed_offsets( const vrc_sampler& s, vrc_fixpos& p, uint32_t* o
         const uint32_t tx = *reinterpret_cast< const uint32_t* >( t + ( ( p.x >> 22 ) & 0x3FCu ) );
         const uint32_t* const py = reinterpret_cast< const uint32_t* >( t + 1024 + ( ( p.y >> 22 ) & 0x3FCu ) );
         const uint32_t tz = *reinterpret_cast< const uint32_t* >( t + 2048 + ( ( p.z >> 22 ) & 0x3FCu ) );
-        off[k] = tx + py[0] + tz;
-        offY1[k] = tx + py[1] + tz; /* (y = 255 reads the z table's first entry: no sample with a weight has it) */
+        const uint32_t xz = tx + tz + bias; /* (one v_add3_u32) */
+        off[k] = xz + py[0];
+        offY1[k] = xz + py[1]; /* (y = 255 reads the z table's first entry: no sample with a weight has it) */
         p.x += p.dx;
         p.y += p.dy;
         p.z += p.dz;
@@ -1563,8 +1568,8 @@ VRC_HD void vrc_packed_offsets( const vrc_sampler& s, vrc_fixpos& p, uint32_t* o
 #pragma unroll
     for( int k = 0; k < N; ++k )
     {
-        off[k] = VRC_PK_TEXEL * vrc_packed_local_index( p.x >> 24, p.y >> 24, p.z >> 24, sbx, sby );
-        offY1[k] = VRC_PK_TEXEL * vrc_packed_local_index( p.x >> 24, ( ( p.y >> 24 ) + 1u ) & 255u, p.z >> 24, sbx, sby );
+        off[k] = bias + VRC_PK_TEXEL * vrc_packed_local_index( p.x >> 24, p.y >> 24, p.z >> 24, sbx, sby );
+        offY1[k] = bias + VRC_PK_TEXEL * vrc_packed_local_index( p.x >> 24, ( ( p.y >> 24 ) + 1u ) & 255u, p.z >> 24, sbx, sby );
         p.x += p.dx;
         p.y += p.dy;
         p.z += p.dz;
@@ -1581,7 +1586,7 @@ VRC_HD void vrc_packed_offsets( const vrc_sampler& s, vrc_fixpos& p, uint32_t* o
  * vrc_march_segment_as: whole groups without per-sample tests while more than GROUP steps remain, the early-exit
  * test once per group with an exact replay, a general tail.  tab: vrc_cls8_entry table.  E: vrc_f4, or vrc_f2
  * for a grey transfer function (vrc_raycast_args.greyTable). */
-template < bool COUNT, int GROUP, typename E >
+template < bool COUNT, int GROUP, typename E, bool WIDE >
 VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n, vrc_segment s,
                                       const uint32_t* __restrict__ packed, const vrc_f4* tab, const vrc_cls8& kc,
                                       E& color, uint32_t& nSamples, float levelStep )
@@ -1591,8 +1596,11 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
     if( !( travel > 0.0f ) )
         return false;
     const vrc_sampler sm = vrc_make_sampler( n, f );
-    /* the lane's packed slot: 4 bytes per texel (64 bits: a packed atlas passes 4 GiB at a byte atlas of 1 Gi voxels) */
-    const uint8_t* const slot = reinterpret_cast< const uint8_t* >( packed ) + vrc_packed_elems( n.slotBase ) * VRC_PK_TEXEL;
+    /* the lane's packed slot.  A packed atlas of at most 4 GiB: the atlas pointer (uniform: a scalar base) + a 32-bit
+     * byte offset per lane, the slot's offset folded into it.  WIDE (a larger one): a 64-bit pointer per lane. */
+    const uint64_t slotBytes = vrc_packed_elems( n.slotBase ) * VRC_PK_TEXEL;
+    const uint8_t* const slot = reinterpret_cast< const uint8_t* >( packed ) + ( WIDE ? slotBytes : 0u );
+    const uint32_t bias = WIDE ? 0u : (uint32_t)slotBytes;
     vrc_fixpos fp = vrc_fixpos_init( sm, s.pos, s.step );
     /* texel centres at i + 0.5: the integer part of (coordinate - 0.5) is the lower tap, its fraction the weight */
     fp.x -= 1u << 23;
@@ -1605,7 +1613,7 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
         uint32_t off[GROUP], offY1[GROUP];
         vrc_texel_pair t[GROUP];
         vrc_fixpos q = fp; /* the group's first sample: the weights are taken again from here after the loads */
-        vrc_packed_offsets< GROUP >( sm, fp, off, offY1 );
+        vrc_packed_offsets< GROUP >( sm, fp, bias, off, offY1 );
 #pragma unroll
         for( int k = 0; k < GROUP; ++k )
         {
@@ -1665,15 +1673,15 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
         uint32_t off[TAILG], offY1[TAILG], cnt = 0;
         vrc_texel_pair t[TAILG];
         vrc_fixpos q = fp;
-        vrc_packed_offsets< TAILG >( sm, fp, off, offY1 );
+        vrc_packed_offsets< TAILG >( sm, fp, bias, off, offY1 );
 #pragma unroll
         for( int k = 0; k < TAILG; ++k )
         {
             const bool v = travel > 0.0f;
             cnt += v ? 1u : 0u;
             /* a step the reference does not take reads the slot's first texels and blends nothing */
-            off[k] = v ? off[k] : 0u;
-            offY1[k] = v ? offY1[k] : 0u;
+            off[k] = v ? off[k] : bias;
+            offY1[k] = v ? offY1[k] : bias;
             t[k] = vrc_packed_load( slot, off[k], offY1[k] );
             travel -= stepSize;
         }
@@ -1722,7 +1730,23 @@ VRC_HD bool vrc_march_brick( const vrc_frame& f, const vrc_dev_node& n, const vr
                              const vrc_classifier& cls, vrc_f4& color, uint32_t& nSamples,
                              float levelStep = 0.0f )
 {
-    if( BIG )
+    if constexpr( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY )
+    {
+        /* (BIG here: a packed atlas of more than 4 GiB -- 64-bit lane pointers; the byte atlas has < 2^32 voxels) */
+        static_assert( sizeof( ATLAS_T ) == 4 && !CLAMP, "the packed atlas: passed as 32-bit words, overlap >= 1" );
+        const vrc_cls8 kc = vrc_make_cls8( cls );
+        if constexpr( MODE == VRC_MODE_PACKED_GREY )
+        {
+            vrc_f2 c = { color.x, color.w };
+            const bool done = vrc_march_segment_packed< COUNT, GROUP, vrc_f2, BIG >( f, n, s, atlas, lut, kc, c, nSamples, levelStep );
+            color.x = color.y = color.z = c.x;
+            color.w = c.w;
+            return done;
+        }
+        else
+            return vrc_march_segment_packed< COUNT, GROUP, vrc_f4, BIG >( f, n, s, atlas, lut, kc, color, nSamples, levelStep );
+    }
+    else if( BIG )
     {
         vrc_dev_node local = n;
         local.slotBase = 0u;
@@ -1730,22 +1754,7 @@ VRC_HD bool vrc_march_brick( const vrc_frame& f, const vrc_dev_node& n, const vr
         return vrc_march_brick< CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, false >( f, local, s, slot, lut, cls,
                                                                                 color, nSamples, levelStep );
     }
-    if constexpr( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY )
-    {
-        static_assert( sizeof( ATLAS_T ) == 4 && !CLAMP && !BIG, "the packed atlas: 32-bit texels, overlap >= 1, 32-bit slot bases" );
-        const vrc_cls8 kc = vrc_make_cls8( cls );
-        if constexpr( MODE == VRC_MODE_PACKED_GREY )
-        {
-            vrc_f2 c = { color.x, color.w };
-            const bool done = vrc_march_segment_packed< COUNT, GROUP, vrc_f2 >( f, n, s, atlas, lut, kc, c, nSamples, levelStep );
-            color.x = color.y = color.z = c.x;
-            color.w = c.w;
-            return done;
-        }
-        else
-            return vrc_march_segment_packed< COUNT, GROUP, vrc_f4 >( f, n, s, atlas, lut, kc, color, nSamples, levelStep );
-    }
-    else if constexpr( MODE == VRC_MODE_GREY )
+    if constexpr( MODE == VRC_MODE_GREY )
         return vrc_march_segment< CLAMP, COUNT, FIXED, ATLAS_T, GROUP, true >( f, n, s, atlas, lut, color, nSamples,
                                                                              levelStep );
     else if constexpr( MODE == VRC_MODE_POINT_GREY )

@@ -116,6 +116,7 @@ struct vrc_raycast_args
                         * only for the table-driven point-sampling walk kernel and frames below 65536 pixels a side */
     uint32_t* rayList; /* counts[VRC_MAX_ERT_PARTS] | two lists of width * height packed pixels */
     bool packed;     /* trilinear through the tap-packed atlas: atlas = the pool's packed atlas (vrc_march_segment_packed) */
+    bool packedWide; /* ... of more than 4 GiB: 64-bit lane pointers instead of scalar base + 32-bit offset (BIG instances) */
     bool depthSplit; /* two waves per tile, near / far half of every ray (vrc_k_raycast_split): set by the host
                       * only when early ray termination cannot occur in this frame and the frame is cleared */
 };

@@ -1054,15 +1054,16 @@ static hipError_t launch_big( const vrc_raycast_args& a, bool count, hipStream_t
 }
 
 /* trilinear through the tap-packed atlas (a.atlas = the packed atlas; the host offers it for 8-bit bricks with
- * overlap >= 1, slots of at most 248 voxels a side, atlases of at most 2^32 voxels, VRC_OPT_TF_FRAC_BITS = 8) */
-template < int MODE >
+ * overlap >= 1, slots of at most 248 voxels a side, atlases of at most 2^32 voxels, VRC_OPT_TF_FRAC_BITS = 8);
+ * WIDE: a packed atlas of more than 4 GiB */
+template < int MODE, bool WIDE >
 static hipError_t launch_packed( const vrc_raycast_args& a, bool count, hipStream_t stream )
 {
     if( a.gridDda )
-        return count ? launch_variant< true, false, true, true, MODE, uint32_t, VRC_PGROUP >( a, stream )
-                     : launch_variant< true, false, false, true, MODE, uint32_t, VRC_PGROUP >( a, stream );
-    return count ? launch_variant< false, false, true, true, MODE, uint32_t, VRC_PGROUP >( a, stream )
-                 : launch_variant< false, false, false, true, MODE, uint32_t, VRC_PGROUP >( a, stream );
+        return count ? launch_variant< true, false, true, true, MODE, uint32_t, VRC_PGROUP, WIDE >( a, stream )
+                     : launch_variant< true, false, false, true, MODE, uint32_t, VRC_PGROUP, WIDE >( a, stream );
+    return count ? launch_variant< false, false, true, true, MODE, uint32_t, VRC_PGROUP, WIDE >( a, stream )
+                 : launch_variant< false, false, false, true, MODE, uint32_t, VRC_PGROUP, WIDE >( a, stream );
 }
 
 hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
@@ -1072,8 +1073,11 @@ hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
     {
         if( !a.linear || a.elemBytes != 1 || a.bigAtlas || a.clamp )
             return hipErrorInvalidValue;
-        return a.greyTable ? launch_packed< VRC_MODE_PACKED_GREY >( a, count, stream )
-                           : launch_packed< VRC_MODE_PACKED >( a, count, stream );
+        if( a.packedWide )
+            return a.greyTable ? launch_packed< VRC_MODE_PACKED_GREY, true >( a, count, stream )
+                               : launch_packed< VRC_MODE_PACKED, true >( a, count, stream );
+        return a.greyTable ? launch_packed< VRC_MODE_PACKED_GREY, false >( a, count, stream )
+                           : launch_packed< VRC_MODE_PACKED, false >( a, count, stream );
     }
     if( a.bigAtlas )
     {

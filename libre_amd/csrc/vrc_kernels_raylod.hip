@@ -157,6 +157,14 @@ hipError_t vrc_launch_raycast_raylod( const vrc_raycast_args& a, hipStream_t str
         /* the trilinear filter through the tap-packed atlas (a.atlas), the hierarchy walk around it */
         if( !a.linear || a.elemBytes != 1 || a.bigAtlas || a.clamp )
             return hipErrorInvalidValue;
+        if( a.packedWide ) /* a packed atlas of more than 4 GiB: 64-bit lane pointers */
+        {
+            if( a.greyTable )
+                return count ? launch_raylod< false, true, true, VRC_MODE_PACKED_GREY, uint32_t, true >( a, stream )
+                             : launch_raylod< false, false, true, VRC_MODE_PACKED_GREY, uint32_t, true >( a, stream );
+            return count ? launch_raylod< false, true, true, VRC_MODE_PACKED, uint32_t, true >( a, stream )
+                         : launch_raylod< false, false, true, VRC_MODE_PACKED, uint32_t, true >( a, stream );
+        }
         if( a.greyTable )
             return count ? launch_raylod< false, true, true, VRC_MODE_PACKED_GREY, uint32_t >( a, stream )
                          : launch_raylod< false, false, true, VRC_MODE_PACKED_GREY, uint32_t >( a, stream );

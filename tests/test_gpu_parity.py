@@ -508,7 +508,7 @@ def test_c2_full_size_rows_of_the_other_modes(vrc):
         gl, _, st = g.render(variant=vrc.VARIANT_GLRAYCASTER)
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
         lin, n_lin, st = g.render(filter_mode=vrc.FILTER_TRILINEAR)
-        assert st.kernel_variant == vrc.KERNEL_PACKED  # what AUTO takes: a 6 GB packed atlas, texels past 4 GiB
+        assert st.kernel_variant == vrc.KERNEL_PACKED  # what AUTO takes: a 3 GB packed atlas
         staged, n_staged, st = g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
         assert st.kernel_variant == vrc.KERNEL_LDS
         lin_gather, n_gather, st = g.render(kernel=vrc.KERNEL_GRID_DDA, filter_mode=vrc.FILTER_TRILINEAR)
@@ -1180,31 +1180,21 @@ def test_atlas_of_more_than_2_pow_32_voxels(vrc):
         L.vrc_ctx_destroy(ctx)
 
 
-def test_ray_lod_in_an_atlas_of_more_than_2_pow_32_voxels(vrc):
-    # per-ray adaptive LOD in a pool of more than 2^32 voxels (BASELINE C3's full-size atlas is one): round 3 refused it
-    # (32-bit slot bases in the hierarchy walk); now the walk has instances with 64-bit slot bases and float positions
-    # (vrc_k_raycast_raylod<...,true>).  The whole hierarchy of a 64^3 volume in a 6 GB pool, bricks on both sides of the
-    # 4 Gi-voxel line: the frame of the same hierarchy in a small pool with float stepping, bit for bit, point-sampled
-    # and with the trilinear filter (gather form).  Reference hook: CudaRaycastPipeline.cpp:236-301 (what renders C3).
-    vi = orc.mem_volume_info(64, 64, 64, 16)
-    s = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(96, 80), volume="hash", spin=(0.5, 0.35),
-                        ids=orc.all_level_ids(vi))
-    lod = (0.8, orc.world_space_per_pixel(s))
-    with _gpu(s) as g:
-        want, n_want, st = g.render(kernel=vrc.KERNEL_GRID_DDA, stepping=0, ray_lod=lod)
-        assert st.kernel_variant == vrc.KERNEL_RAY_LOD
-        want_lin, n_lin, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, filter_mode=vrc.FILTER_TRILINEAR, ray_lod=lod)
+def _frames_in_a_large_pool(vrc, s, pool_bytes, line_voxels, cases):
+    """Upload the scene's bricks into a pool of pool_bytes (bricks must land on both sides of voxel offset line_voxels),
+    render every case = (options {OPT: value}, ray_lod or None) and return [(frame, samples, kernel name)]."""
     L = vrc.load_library()
     ctx, pool = C.c_void_p(), C.c_void_p()
     vrc.check(L, L.vrc_ctx_create(0, C.byref(ctx)))
+    out = []
     try:
         mb = [s.vi.maximumBlockSize[a] for a in range(3)]
-        vrc.check(L, L.vrc_pool_create(ctx, 1, 0, 0, 1, vrc.u32x3(*mb), 6 * 1000 ** 3, C.byref(pool)))
+        vrc.check(L, L.vrc_pool_create(ctx, 1, 0, 0, 1, vrc.u32x3(*mb), pool_bytes, C.byref(pool)))
         sb, ab, fs = C.c_size_t(), C.c_size_t(), C.c_uint32()
         ad, sl = vrc.u32x3(), vrc.u32x3()
         vrc.check(L, L.vrc_pool_info(pool, C.byref(sb), ad, C.byref(ab), sl, C.byref(fs)))
         atlas_dim = list(ad)
-        assert atlas_dim[0] * atlas_dim[1] * atlas_dim[2] > 2 ** 32
+        assert atlas_dim[0] * atlas_dim[1] * atlas_dim[2] > line_voxels
         slot_dim = [atlas_dim[a] // sl[a] for a in range(3)]
         slots, high = {}, 0
         for nid in s.ids:
@@ -1214,7 +1204,7 @@ def test_ray_lod_in_an_atlas_of_more_than_2_pow_32_voxels(vrc):
                                                  vrc.u32x3(brick.shape[2], brick.shape[1], brick.shape[0]), slot))
             slots[nid] = (slot[0], slot[1], slot[2])
             idx = [int(round(slot[a] * sl[a])) for a in range(3)]
-            high += ((idx[2] * sl[1] + idx[1]) * sl[0] + idx[0]) * slot_dim[0] * slot_dim[1] * slot_dim[2] >= 2 ** 32
+            high += ((idx[2] * sl[1] + idx[1]) * sl[0] + idx[0]) * slot_dim[0] * slot_dim[1] * slot_dim[2] >= line_voxels
         assert 0 < high < len(s.ids)
         nodes = (vrc.NodeData * s.n_nodes)()
         for k, nid in enumerate(s.sorted_ids):
@@ -1230,21 +1220,65 @@ def test_ray_lod_in_an_atlas_of_more_than_2_pow_32_voxels(vrc):
         render = C.cast(C.byref(s.render), C.POINTER(vrc.RenderData))
         vrc.check(L, L.vrc_update(ctx, s.tf.ctypes.data, None, 0))
         vrc.check(L, L.vrc_set_option(ctx, vrc.OPT_COUNT_SAMPLES, 1))
-        vrc.check(L, L.vrc_set_ray_lod(ctx, 1, lod[0], lod[1]))
-        for flt, frame_want, n in ((vrc.FILTER_NEAREST, want, n_want), (vrc.FILTER_TRILINEAR, want_lin, n_lin)):
-            vrc.check(L, L.vrc_set_option(ctx, vrc.OPT_FILTER, flt))
+        for options, lod in cases:
+            for o, v in options.items():
+                vrc.check(L, L.vrc_set_option(ctx, o, v))
+            vrc.check(L, L.vrc_set_ray_lod(ctx, 1 if lod else 0, lod[0] if lod else 0.0, lod[1] if lod else 0.0))
             vrc.check(L, L.vrc_pre_render(ctx, view))
             vrc.check(L, L.vrc_render(ctx, view, nodes, s.n_nodes, render, pool))
             fb = np.zeros((s.H, s.W, 4), dtype=np.float32)
             vrc.check(L, L.vrc_post_render(ctx, fb.ctypes.data))
             st = vrc.Stats()
             vrc.check(L, L.vrc_get_stats(ctx, C.byref(st)))
-            assert st.kernel_variant == vrc.KERNEL_RAY_LOD and L.vrc_last_kernel().decode().endswith(",true>"), L.vrc_last_kernel()
-            assert st.samples == n and (fb == frame_want).all(), "filter %d" % flt
+            out.append((fb, st.samples, st.kernel_variant, L.vrc_last_kernel().decode()))
     finally:
         if pool:
             L.vrc_pool_destroy(pool)
         L.vrc_ctx_destroy(ctx)
+    return out
+
+
+def test_ray_lod_in_an_atlas_of_more_than_2_pow_32_voxels(vrc):
+    # per-ray adaptive LOD in a pool of more than 2^32 voxels (BASELINE C3's full-size atlas is one): round 3 refused it
+    # (32-bit slot bases in the hierarchy walk); now the walk has instances with 64-bit slot bases and float positions
+    # (vrc_k_raycast_raylod<...,true>).  The whole hierarchy of a 64^3 volume in a 6 GB pool, bricks on both sides of the
+    # 4 Gi-voxel line: the frame of the same hierarchy in a small pool with float stepping, bit for bit, point-sampled
+    # and with the trilinear filter (gather form).  Reference hook: CudaRaycastPipeline.cpp:236-301 (what renders C3).
+    vi = orc.mem_volume_info(64, 64, 64, 16)
+    s = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(96, 80), volume="hash", spin=(0.5, 0.35),
+                        ids=orc.all_level_ids(vi))
+    lod = (0.8, orc.world_space_per_pixel(s))
+    with _gpu(s) as g:
+        want, n_want, st = g.render(kernel=vrc.KERNEL_GRID_DDA, stepping=0, ray_lod=lod)
+        assert st.kernel_variant == vrc.KERNEL_RAY_LOD
+        want_lin, n_lin, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, filter_mode=vrc.FILTER_TRILINEAR, ray_lod=lod)
+    got = _frames_in_a_large_pool(vrc, s, 6 * 1000 ** 3, 2 ** 32,
+                                  [({vrc.OPT_FILTER: vrc.FILTER_NEAREST}, lod), ({vrc.OPT_FILTER: vrc.FILTER_TRILINEAR}, lod)])
+    for (fb, n, variant, name), frame_want, n_w in zip(got, (want, want_lin), (n_want, n_lin)):
+        assert variant == vrc.KERNEL_RAY_LOD and name.endswith(",true>"), name
+        assert n == n_w and (fb == frame_want).all(), name
+
+
+def test_tap_packed_atlas_of_more_than_4_gib(vrc):
+    # the packed kernels address the packed atlas as scalar base + 32-bit byte offset per lane; a packed atlas of more
+    # than 4 GiB (a byte atlas past 1.9 Gi voxels: the reference's default 3 GB texture cache is one) takes instances
+    # with 64-bit lane pointers (<..., true>).  A 64^3 volume's hierarchy in a 3 GB pool, bricks on both sides of the
+    # packed atlas's 4 GiB line: the frames of the small pool, bit for bit, with and without per-ray LOD
+    vi = orc.mem_volume_info(64, 64, 64, 16)
+    s = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(96, 80), volume="hash", spin=(0.5, 0.35),
+                        ids=orc.all_level_ids(vi))
+    lod = (0.8, orc.world_space_per_pixel(s))
+    with _gpu(s) as g:
+        want_lod, n_lod, st = g.render(kernel=vrc.KERNEL_PACKED, filter_mode=vrc.FILTER_TRILINEAR, ray_lod=lod)
+        assert st.kernel_variant == vrc.KERNEL_RAY_LOD and _ran(g).endswith(",unsigned int,false>"), _ran(g)
+        want, n_want, st = g.render(kernel=vrc.KERNEL_PACKED, filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_PACKED and _ran(g).endswith(",false>"), _ran(g)
+    line = (2 ** 32) * 4 // 9  # voxels whose packed texels (2.25 bytes each) fill 4 GiB
+    opts = {vrc.OPT_FILTER: vrc.FILTER_TRILINEAR, vrc.OPT_KERNEL: vrc.KERNEL_PACKED}
+    got = _frames_in_a_large_pool(vrc, s, 3 * 1000 ** 3, line, [(opts, lod), (opts, None)])
+    for (fb, n, variant, name), frame_want, n_w, v in zip(got, (want_lod, want), (n_lod, n_want), (vrc.KERNEL_RAY_LOD, vrc.KERNEL_PACKED)):
+        assert variant == v and ",unsigned int," in name and name.endswith(",true>"), name
+        assert n == n_w and (fb == frame_want).all(), name
 
 
 def test_slot_longer_than_255_voxels_marches_with_float_positions(vrc):
