@@ -548,7 +548,7 @@ def main():
 
     def trilinear_forms(the_app, n_warm=5, n_timed=20):
         # the trilinear filter (north star; extension: the reference's sampler is point-sampled) in the form
-        # VRC_KERNEL_AUTO takes -- the pool's tap-packed atlas, one 8-byte gather per sample -- and in the LDS-staged
+        # VRC_KERNEL_AUTO takes -- the pool's tap-packed atlas, two 4-byte gathers per sample -- and in the LDS-staged
         # form it took until round 3 (VRC_OPT_PACKED_ATLAS = 0); the same frame, bit for bit
         the_app.set_option(vrc.OPT_FILTER, vrc.FILTER_TRILINEAR)
         res = {}
@@ -573,14 +573,14 @@ def main():
             res = trilinear_forms(app)
         auto = res["auto"]
         alg = a.voxels ** 3 + W * H * 16 + (a.voxels // a.block) ** 3 * 48 + 4096
-        return {"kernel": auto["kernel"] + " (tap-packed atlas: 4.5 B per voxel next to the byte atlas, one 8-byte gather per sample)",
+        return {"kernel": auto["kernel"] + " (tap-packed atlas: 2.25 B per voxel next to the byte atlas, two 4-byte gathers per sample)",
                 "kernel_ms_per_frame": auto["kernel_ms_per_frame"], "samples_per_frame": res["samples_per_frame"],
                 "Msamples_per_s": auto["Msamples_per_s"],
                 "roofline_frac": alg / (auto["kernel_ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 "lds_staged_form": res["lds_staged"],
                 "note": "roofline_frac = the judged workload's algorithmic bytes / kernel time / HBM peak; what the "
-                        "kernel really moves is the packed atlas (DESIGN.md section 4: 10 GB of 128-byte line fills "
-                        "per frame, the bound of this kernel)"}
+                        "kernel really moves is the packed atlas (DESIGN.md section 4.2: 5.4 GB of 128-byte line fills "
+                        "per frame; arithmetic, fills and L1 look-ups are level)"}
 
     def extra_moving_camera():
         # outside the judged number too: frame rate while the camera moves (every frame re-derives the

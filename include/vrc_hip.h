@@ -133,7 +133,7 @@ typedef struct
                                    * a frame only (the pixel starts from zero).  0: always the four-float form */
 
 #define VRC_OPT_PACKED_ATLAS 13    /* 1 (default) | 0.  May VRC_KERNEL_AUTO build the pool's tap-packed atlas (VRC_KERNEL_PACKED:
-                                   * 4.5 times the bytes of the brick atlas, on top of the budget given to
+                                   * 2.25 times the bytes of the brick atlas, on top of the budget given to
                                    * vrc_pool_create) the first time a frame with the trilinear filter could use it?
                                    * 0: AUTO stays with the LDS-staged / gather forms; asking for VRC_KERNEL_PACKED
                                    * explicitly still builds it */
@@ -160,12 +160,12 @@ typedef struct
 #define VRC_KERNEL_LDS 3             /* grid DDA + voxels staged through LDS per wave and round (needs
                                       * overlap >= 1); what AUTO picks for the trilinear filter where the
                                       * tap-packed atlas (VRC_KERNEL_PACKED) is not available */
-#define VRC_KERNEL_PACKED 5          /* the trilinear filter through the pool's tap-packed atlas: a second atlas, 4.5 times
-                                      * the bytes, whose 32-bit texel at (x,y,z) holds the 2x2 neighbourhood across x,
-                                      * v[x,y,z] | v[x,y+1,z] << 8 | v[x,y,z+1] << 16 | v[x,y+1,z+1] << 24, laid out so that
-                                      * the texels at x and x + 1 are always neighbours in memory; allocated and filled on
-                                      * first use and kept up to date by every later upload: the eight taps of a sample
-                                      * are ONE 8-byte gather.  Needs VRC_FILTER_TRILINEAR, 8-bit bricks with overlap >= 1,
+#define VRC_KERNEL_PACKED 5          /* the trilinear filter through the pool's tap-packed atlas: a second atlas, 2.25 times
+                                      * the bytes, whose 16-bit texel at (x,y,z) holds a voxel and its neighbour along z,
+                                      * v[x,y,z] | v[x,y,z+1] << 8, laid out so that the texels at x and x + 1 are always
+                                      * neighbours in memory; allocated and filled on first use and kept up to date by
+                                      * every later upload: the eight taps of a sample are TWO 4-byte gathers (rows y
+                                      * and y + 1).  Needs VRC_FILTER_TRILINEAR, 8-bit bricks with overlap >= 1,
                                       * an atlas of at most 2^32 voxels, VRC_OPT_TF_FRAC_BITS = 8, VRC_OPT_STEPPING = 1
                                       * (VRC_EINVAL otherwise) and the device memory (VRC_ENOMEM).  Same sample
                                       * positions, weights and arithmetic as the LDS-staged form: the same frame,

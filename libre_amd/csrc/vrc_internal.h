@@ -24,7 +24,7 @@
  * (MI355X_MICROARCH.md, "Workgroup dispatch") and each XCD has its own L2: workgroup b takes unit (b / 8) of XCD
  * (b % 8)'s list.  A list is made of SUPER-TILES of VRC_SUPER_UNITS x VRC_SUPER_UNITS units (their units in Morton
  * order), dealt to the XCDs heaviest first in snake order.  Measured on C2 (profiles/r4_schedule_and_hbm_requests.txt):
- * the L2s fill whole 128-byte lines (TCC_EA0_RDREQ_128B = every request of these kernels) and fetch 1.9 x the packed
+ * the L2s fill whole 128-byte lines (TCC_EA0_RDREQ_128B = every request of these kernels) and fetch 1.9 x the packed (32-bit texel)
  * atlas per trilinear frame, 2.2 x the volume per point-sampled frame; super-tiles of 4 x 4 units (64 x 64 pixels on
  * one XCD) take 7 % of those requests away and no time (neighbouring workgroups drift apart in depth by more than the
  * few steps an L2 remembers), and cost the LDS-staged kernel 5 % (coarser heaviest-first order).  So the product keeps
