@@ -72,6 +72,7 @@
 #define VRC_HD __host__ __device__ __forceinline__
 #else
 #include <math.h>
+#include <string.h>
 #define VRC_HD inline
 #endif
 
