@@ -194,7 +194,11 @@ struct vrc_layout
 };
 
 /* ---- slot-local layout: element offset = LX(x) + LY(y) + LZ(z), one part per axis ---------------
- * VRC_LAYOUT 0 (the product's layout): 8x8x8 micro-blocks as described above.
+ * VRC_LAYOUT 0 (the product's layout): 8x8x8 micro-blocks, blocks x-fastest inside the slot; inside a block the
+ * 64 x-rows of 8 voxels lie in the order y & 3, z & 3, y >> 2, z >> 2, so that a 128-byte line -- what an L2 fetches
+ * from HBM -- is a block of 8 x 4 x 4 voxels and the lines a tile touches per step are the same for views along every
+ * axis (round 4; rounds 1-3 had the rows in the order y, z -- lines of 8 x 8 x 2 -- and ran views along x and y
+ * 17 % / 7 % slower than along z: profiles/r4_byte_atlas_line_shapes.txt).  Rows y and y + 1 (y even) stay neighbours.
  * Other values are developer experiments (tools/dev_layouts.sh): only the table-driven point-sampling
  * kernel understands them.
  *   1: micro-blocks 576 B apart and block rows padded to 3 mod 8 blocks: the 64-B lines of x/y
@@ -202,7 +206,16 @@ struct vrc_layout
  *   2: row-major (x fastest), pitch slotDim.x + VRC_LAYOUT_PADX
  *   3: 64-B lines of 32 x 2 voxels      4: 64-B lines of 16 x 4 voxels
  *   5: 64-B lines of 4 x 4 x 4 voxels, z fastest (a dword = four voxels along z); with VRC_ZRUN the fast groups of
- *      the march keep a lane's dword and reload it only when the voxel column or the 4-voxel block changes */
+ *      the march keep a lane's dword and reload it only when the voxel column or the 4-voxel block changes
+ *   6: micro-blocks with the rows in the order y, z (rounds 1-3: lines of 8 x 8 x 2)
+ *   7: ... in the order y & 1, z, y >> 1 (lines of 8 x 2 x 8) */
+/* in-block offset of row y / slice z (bits 0-2 of u count) */
+VRC_HD uint32_t vrc_mb_y( uint32_t u ) { return ( ( u & 3u ) << 3 ) | ( ( u & 4u ) << 5 ); }
+VRC_HD uint32_t vrc_mb_z( uint32_t u ) { return ( ( u & 3u ) << 5 ) | ( ( u & 4u ) << 6 ); }
+/* the same as corrections of the plain order: vrc_mb_y( u ) = 8 (u & 7) + VRC_MB_FIX_Y( u ),
+ * vrc_mb_z( u ) = 64 (u & 7) - VRC_MB_FIX_Z( u ) -- what the arithmetic address paths add to 8 y + 64 z */
+#define VRC_MB_FIX_Y( u ) ( 96u * ( ( ( u ) >> 2 ) & 1u ) )
+#define VRC_MB_FIX_Z( u ) ( 32u * ( ( u ) & 3u ) )
 #ifndef VRC_LAYOUT
 #define VRC_LAYOUT 0
 #endif
@@ -216,7 +229,7 @@ struct vrc_lay
 VRC_HD vrc_lay vrc_make_lay( uint32_t sbx, uint32_t sby )
 {
     vrc_lay l;
-#if VRC_LAYOUT == 0
+#if VRC_LAYOUT == 0 || VRC_LAYOUT == 6
     l.a = 504u; l.b = sbx * VRC_MB_VOXELS - 64u; l.c = sbx * sby * VRC_MB_VOXELS - 512u;
 #elif VRC_LAYOUT == 1
     const uint32_t sbxp = sbx + ( ( 3u - sbx ) & 7u );
@@ -227,6 +240,8 @@ VRC_HD vrc_lay vrc_make_lay( uint32_t sbx, uint32_t sby )
     l.a = 64u; l.b = 64u * ( ( sbx * 8u + 31u ) / 32u ); l.c = l.b * sby * 4u;
 #elif VRC_LAYOUT == 5
     l.a = 64u; l.b = 64u * sbx * 2u; l.c = l.b * sby * 2u;
+#elif VRC_LAYOUT == 7
+    l.a = 504u; l.b = sbx * VRC_MB_VOXELS; l.c = sbx * sby * VRC_MB_VOXELS;
 #else
     l.a = 64u; l.b = 64u * ( ( sbx * 8u + 15u ) / 16u ); l.c = l.b * sby * 2u;
 #endif
@@ -234,7 +249,7 @@ VRC_HD vrc_lay vrc_make_lay( uint32_t sbx, uint32_t sby )
 }
 VRC_HD uint32_t vrc_lay_x( const vrc_lay& l, uint32_t u )
 {
-#if VRC_LAYOUT == 0
+#if VRC_LAYOUT == 0 || VRC_LAYOUT == 6 || VRC_LAYOUT == 7
     return u + l.a * ( u >> 3 );
 #elif VRC_LAYOUT == 1
     return ( u & 7u ) + l.a * ( u >> 3 );
@@ -251,6 +266,8 @@ VRC_HD uint32_t vrc_lay_x( const vrc_lay& l, uint32_t u )
 VRC_HD uint32_t vrc_lay_y( const vrc_lay& l, uint32_t u )
 {
 #if VRC_LAYOUT == 0
+    return 8u * u + l.b * ( u >> 3 ) + VRC_MB_FIX_Y( u );
+#elif VRC_LAYOUT == 6
     return 8u * u + l.b * ( u >> 3 );
 #elif VRC_LAYOUT == 1
     return 8u * ( u & 7u ) + l.b * ( u >> 3 );
@@ -260,6 +277,8 @@ VRC_HD uint32_t vrc_lay_y( const vrc_lay& l, uint32_t u )
     return 32u * ( u & 1u ) + l.b * ( u >> 1 );
 #elif VRC_LAYOUT == 5
     return 4u * ( u & 3u ) + l.b * ( u >> 2 );
+#elif VRC_LAYOUT == 7
+    return 8u * ( ( u & 1u ) | ( ( ( u >> 1 ) & 3u ) << 4 ) ) + l.b * ( u >> 3 );
 #else
     return 16u * ( u & 3u ) + l.b * ( u >> 2 );
 #endif
@@ -267,11 +286,15 @@ VRC_HD uint32_t vrc_lay_y( const vrc_lay& l, uint32_t u )
 VRC_HD uint32_t vrc_lay_z( const vrc_lay& l, uint32_t u )
 {
 #if VRC_LAYOUT == 0
+    return 64u * u + l.c * ( u >> 3 ) - VRC_MB_FIX_Z( u );
+#elif VRC_LAYOUT == 6
     return 64u * u + l.c * ( u >> 3 );
 #elif VRC_LAYOUT == 1
     return 64u * ( u & 7u ) + l.c * ( u >> 3 );
 #elif VRC_LAYOUT == 5
     return ( u & 3u ) + l.c * ( u >> 2 );
+#elif VRC_LAYOUT == 7
+    return 8u * ( ( u & 7u ) << 1 ) + l.c * ( u >> 3 );
 #else
     return l.c * u;
 #endif
@@ -279,7 +302,7 @@ VRC_HD uint32_t vrc_lay_z( const vrc_lay& l, uint32_t u )
 /* physical elements of one slot */
 VRC_HD uint64_t vrc_slot_elems( uint32_t sdx, uint32_t sdy, uint32_t sdz )
 {
-#if VRC_LAYOUT == 0
+#if VRC_LAYOUT == 0 || VRC_LAYOUT == 6 || VRC_LAYOUT == 7
     return (uint64_t)sdx * sdy * sdz;
 #elif VRC_LAYOUT == 1
     return (uint64_t)vrc_make_lay( sdx >> 3, sdy >> 3 ).c * ( sdz >> 3 );
@@ -296,7 +319,7 @@ VRC_HD uint32_t vrc_slot_local_index( uint32_t x, uint32_t y, uint32_t z, uint32
 #if VRC_LAYOUT == 0
     const uint32_t blk = ( ( z >> VRC_MB_SHIFT ) * sby + ( y >> VRC_MB_SHIFT ) ) * sbx +
                          ( x >> VRC_MB_SHIFT );
-    const uint32_t inner = ( ( z & 7u ) << 6 ) | ( ( y & 7u ) << 3 ) | ( x & 7u );
+    const uint32_t inner = vrc_mb_z( z ) | vrc_mb_y( y ) | ( x & 7u );
     return blk * VRC_MB_VOXELS + inner;
 #else
     const vrc_lay l = vrc_make_lay( sbx, sby );
@@ -639,7 +662,8 @@ VRC_HD uint32_t vrc_voxel_address( const vrc_sampler& s, uint32_t ux, uint32_t u
      * (c & 7) * s = c * s - (c >> 3) * 8 * s this is
      *   slotBase + x + 8 y + 64 z + qx * 504 + qy * (512 sbx - 64) + qz * (512 sbx sby - 512):
      * three shifts, three 24-bit multiply-adds (full rate; operands < 2^24: slot-local block
-     * counts <= 512, slot < 16 Mi elements, checked at pool creation), two shift-adds, one add. */
+     * counts <= 512, slot < 16 Mi elements, checked at pool creation), two shift-adds, one add --
+     * plus the row order's corrections (VRC_MB_FIX_Y / _Z: the rows of a block lie y & 3, z & 3, y >> 2, z >> 2). */
 #if defined( __HIP_DEVICE_COMPILE__ )
     /* spelled out: hipcc otherwise emits multiply + 3-input add pairs (eleven instructions).
      * v_mad_u32_u24 takes one scalar operand (the stride). */
@@ -649,14 +673,14 @@ VRC_HD uint32_t vrc_voxel_address( const vrc_sampler& s, uint32_t ux, uint32_t u
     asm( "v_mad_u32_u24 %0, %1, %2, %3" : "=v"( e ) : "v"( uz >> VRC_MB_SHIFT ), "s"( s.czz ), "v"( t ) );
     asm( "v_lshl_add_u32 %0, %1, 3, %2" : "=v"( t ) : "v"( uy ), "v"( e ) );
     asm( "v_lshl_add_u32 %0, %1, 6, %2" : "=v"( e ) : "v"( uz ), "v"( t ) );
-    return e + s.slotBase;
+    return e + s.slotBase + VRC_MB_FIX_Y( uy ) - VRC_MB_FIX_Z( uz );
 #else
     uint32_t e = vrc_mul24( ux >> VRC_MB_SHIFT, 504u ) + ux;
     e = vrc_mul24( uy >> VRC_MB_SHIFT, s.cyy ) + e;
     e = vrc_mul24( uz >> VRC_MB_SHIFT, s.czz ) + e;
     e = ( uy << 3 ) + e;
     e = ( uz << 6 ) + e;
-    return e + s.slotBase;
+    return e + s.slotBase + VRC_MB_FIX_Y( uy ) - VRC_MB_FIX_Z( uz );
 #endif
 }
 
@@ -733,7 +757,7 @@ VRC_HD vrc_fixpos vrc_fixpos_init( const vrc_sampler& s, const vrc_f3& pos, cons
 #endif
 #if defined( __HIPCC__ ) && defined( VRC_ADDR_TABLES )
 /* Per-axis address parts of vrc_voxel_address as three 256-entry tables in LDS (filled by the
- * raycast kernel): TX[u] = u + 504 (u>>3), TY[u] = 8u + cyy (u>>3), TZ[u] = 64u + czz (u>>3).
+ * raycast kernel): TX[u] = u + 504 (u>>3), TY[u] = 8u + cyy (u>>3) + FIX_Y(u), TZ[u] = 64u + czz (u>>3) - FIX_Z(u).
  * Replaces 3 shifts + 3 24-bit multiply-adds + 2 shift-adds (the slow VALU classes) by 3 masks
  * + 3 LDS reads + one 3-input add per sample. */
 __shared__ uint32_t vrc_addr_tab[3 * 256];
@@ -1245,8 +1269,8 @@ VRC_HD vrc_taps vrc_trilinear_taps( const vrc_sampler& s, float lx, float ly, fl
     for( int i = 0; i < 2; ++i )
     {
         t.ax[i] = vrc_mul24( ux[i] >> VRC_MB_SHIFT, 504u ) + ux[i];
-        t.ay[i] = vrc_mul24( uy[i] >> VRC_MB_SHIFT, s.cyy ) + ( uy[i] << 3 );
-        t.az[i] = vrc_mul24( uz[i] >> VRC_MB_SHIFT, s.czz ) + ( uz[i] << 6 ) + s.slotBase;
+        t.ay[i] = vrc_mul24( uy[i] >> VRC_MB_SHIFT, s.cyy ) + ( uy[i] << 3 ) + VRC_MB_FIX_Y( uy[i] );
+        t.az[i] = vrc_mul24( uz[i] >> VRC_MB_SHIFT, s.czz ) + ( uz[i] << 6 ) - VRC_MB_FIX_Z( uz[i] ) + s.slotBase;
     }
     return t;
 }

@@ -217,7 +217,7 @@ __device__ __forceinline__ void lds_stage( const uint16_t* __restrict__ slotPtr,
         {
             const uint32_t zc = (uint32_t)z < dz ? (uint32_t)z : dz - 1u;
             const uint32_t zz = z0 + zc;
-            const uint16_t* zb = slotPtr + ( ( zz >> VRC_MB_SHIFT ) * sliceStride + ( ( zz & 7u ) << 6 ) );
+            const uint16_t* zb = slotPtr + ( ( zz >> VRC_MB_SHIFT ) * sliceStride + vrc_mb_z( zz ) );
             asm volatile( "" : "+s"( zb ), "+v"( pl ) ); /* see the 8-bit form */
             lds_g_u16* const g = (lds_g_u16*)zb;
             v0[z] = *(lds_g_u32x4*)( g + pl );
@@ -256,7 +256,7 @@ __device__ __forceinline__ void lds_stage( const uint8_t* __restrict__ slotPtr, 
         {
             const uint32_t zc = (uint32_t)z < dz ? (uint32_t)z : dz - 1u;
             const uint32_t zz = z0 + zc;
-            const uint8_t* zb = slotPtr + ( ( zz >> VRC_MB_SHIFT ) * sliceStride + ( ( zz & 7u ) << 6 ) );
+            const uint8_t* zb = slotPtr + ( ( zz >> VRC_MB_SHIFT ) * sliceStride + vrc_mb_z( zz ) );
             /* the slice's base is wave-uniform: kept in a scalar register pair (the empty asm stops the compiler from
              * re-associating it into slotPtr + partial + slice offset, a 64-bit vector addition per slice), so that the
              * load takes the scalar base + 32-bit lane offset form */
@@ -978,8 +978,7 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
 #endif
                 const bool on = sxr * 8u < box.dx && syp * 2u < box.dy;
                 const uint32_t partial =
-                    ( ( y >> VRC_MB_SHIFT ) * f.sbx + ( x >> VRC_MB_SHIFT ) ) * VRC_MB_VOXELS +
-                    ( ( y & 7u ) << 3 );
+                    ( ( y >> VRC_MB_SHIFT ) * f.sbx + ( x >> VRC_MB_SHIFT ) ) * VRC_MB_VOXELS + vrc_mb_y( y );
                 V* const dst = region + ldsLane;
                 /* every slice load of a batch is issued before the first LDS write; slices
                  * past the box repeat its last slice (branch-free, same cache lines) */
@@ -1224,8 +1223,8 @@ __global__ __launch_bounds__( 64 * VRC_LDS_WAVES, sizeof( V ) == 2 ? VRC_LDS_OCC
                             {
                                 const uint32_t cx = ux + (uint32_t)i, cy = uy + (uint32_t)i, cz = uz + (uint32_t)i;
                                 ax[i] = vrc_mul24( cx >> VRC_MB_SHIFT, 504u ) + cx;
-                                ay[i] = vrc_mul24( cy >> VRC_MB_SHIFT, cyy ) + ( cy << 3 );
-                                az[i] = vrc_mul24( cz >> VRC_MB_SHIFT, czz ) + ( cz << 6 ) + ( BIG ? 0u : laneSlotBase );
+                                ay[i] = vrc_mul24( cy >> VRC_MB_SHIFT, cyy ) + ( cy << 3 ) + VRC_MB_FIX_Y( cy );
+                                az[i] = vrc_mul24( cz >> VRC_MB_SHIFT, czz ) + ( cz << 6 ) - VRC_MB_FIX_Z( cz ) + ( BIG ? 0u : laneSlotBase );
                             }
 #pragma unroll
                             for( int c = 0; c < 8; ++c )

@@ -73,8 +73,8 @@ __global__ __launch_bounds__( VRC_RL_THREADS, VRC_RL_MIN_BLOCKS ) void vrc_k_ray
         {
             const uint32_t q = u >> VRC_MB_SHIFT;
             vrc_addr_tab[u] = u + 504u * q;
-            vrc_addr_tab[256u + u] = 8u * u + cyy * q;
-            vrc_addr_tab[512u + u] = 64u * u + czz * q;
+            vrc_addr_tab[256u + u] = 8u * u + cyy * q + VRC_MB_FIX_Y( u );
+            vrc_addr_tab[512u + u] = 64u * u + czz * q - VRC_MB_FIX_Z( u );
         }
     }
 #endif
