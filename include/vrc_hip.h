@@ -161,12 +161,13 @@ typedef struct
                                       * overlap >= 1); what AUTO picks for the trilinear filter where the
                                       * tap-packed atlas (VRC_KERNEL_PACKED) is not available */
 #define VRC_KERNEL_PACKED 5          /* the trilinear filter through the pool's tap-packed atlas: a second atlas, 2.25 times
-                                      * the bytes, whose 16-bit texel at (x,y,z) holds a voxel and its neighbour along z,
-                                      * v[x,y,z] | v[x,y,z+1] << 8, laid out so that the texels at x and x + 1 are always
-                                      * neighbours in memory; allocated and filled on first use and kept up to date by
-                                      * every later upload: the eight taps of a sample are TWO 4-byte gathers (rows y
-                                      * and y + 1).  Needs VRC_FILTER_TRILINEAR, 8-bit bricks with overlap >= 1,
-                                      * an atlas of at most 2^32 voxels, VRC_OPT_TF_FRAC_BITS = 8, VRC_OPT_STEPPING = 1
+                                      * the bytes, whose texel at (x,y,z) holds a voxel and its neighbour along z,
+                                      * v[x,y,z] | v[x,y,z+1] << 8 (16-bit voxels: << 16), laid out so that the texels at
+                                      * x and x + 1 are always neighbours in memory; allocated and filled on first use
+                                      * and kept up to date by every later upload: the eight taps of a sample are TWO
+                                      * gathers (rows y and y + 1; 4 bytes each, 8 for 16-bit voxels).  Needs
+                                      * VRC_FILTER_TRILINEAR, 8- or 16-bit bricks with overlap >= 1 in slots of at
+                                      * most 248 voxels a side, VRC_OPT_TF_FRAC_BITS = 8, VRC_OPT_STEPPING = 1
                                       * (VRC_EINVAL otherwise) and the device memory (VRC_ENOMEM).  Same sample
                                       * positions, weights and arithmetic as the LDS-staged form: the same frame,
                                       * bit for bit.  What AUTO picks for the trilinear filter where all of this

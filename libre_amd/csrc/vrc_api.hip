@@ -56,7 +56,8 @@ struct vrc_pool
     size_t slotBytes = 0, atlasBytes = 0;
     void* dAtlas = nullptr;
     bool bigAtlas = false; /* more than 2^32 voxels */
-    /* tap-packed atlas of the trilinear filter (vrc_core.h): same slots, a 32-bit texel per voxel in blocks of 9 x 8 x 8.
+    /* tap-packed atlas of the trilinear filter (vrc_core.h): same slots, a texel of twice the voxel's bytes per voxel in
+     * blocks of 64 rows of 9.
      * Allocated and filled from the byte atlas the first time a render asks for it (pool_enable_packed); from then
      * on every upload packs its slot too.  Guarded by `mutex`. */
     void* dPacked = nullptr;
@@ -641,7 +642,7 @@ static int pool_upload( vrc_pool* p, const void* src, bool srcIsDevice, const ui
             if( e == hipSuccess && p->packedOn )
                 e = vrc_launch_pack_slots( p->dAtlas, p->dPacked, base,
                                            (uint64_t)p->slotDim[0] * p->slotDim[1] * p->slotDim[2], p->slotDim,
-                                           p->uploadStream );
+                                           p->elemBytes, p->uploadStream );
             if( e == hipSuccess )
                 e = hipEventRecord( st.done, p->uploadStream );
             if( e == hipSuccess )
@@ -671,12 +672,17 @@ static int pool_upload( vrc_pool* p, const void* src, bool srcIsDevice, const ui
     return VRC_OK;
 }
 
-/* The tap-packed atlas of the trilinear filter, on first use: 2.25 times the byte atlas, filled from it on the upload
- * stream behind every upload queued so far.  false (and no error) when the pool cannot have one: 16-bit voxels, more
- * than 2^32 voxels, or not enough device memory (tried once). */
+/* The tap-packed atlas of the trilinear filter, on first use: 2.25 times the atlas's bytes, filled from it on the upload
+ * stream behind every upload queued so far.  false (and no error) when the pool cannot have one: voxels of more than
+ * 16 bits, or not enough device memory (tried once). */
 static bool pool_packed_possible( const vrc_pool* p )
 {
-    return p->elemBytes == 1 && !p->bigAtlas && VRC_LAYOUT == 0;
+    return ( p->elemBytes == 1 || p->elemBytes == 2 ) && VRC_LAYOUT == 0;
+}
+/* bytes of the pool's packed atlas (+ 8: a pair is read as 4 / 8 bytes at the last texel) */
+static uint64_t pool_packed_bytes( const vrc_pool* p )
+{
+    return vrc_packed_elems( p->atlasBytes / p->elemBytes ) * VRC_PK_TEXEL( p->elemBytes ) + 8u;
 }
 static bool pool_enable_packed( vrc_pool* p )
 {
@@ -685,7 +691,7 @@ static bool pool_enable_packed( vrc_pool* p )
         return true;
     if( p->packedFailed || !pool_packed_possible( p ) )
         return false;
-    const size_t bytes = (size_t)vrc_packed_elems( p->atlasBytes ) * VRC_PK_TEXEL + 8u; /* (+ 8: a pair read at the last texel) */
+    const size_t bytes = (size_t)pool_packed_bytes( p );
     size_t freeMem = 0, totalMem = 0;
     hipError_t e = hipMemGetInfo( &freeMem, &totalMem );
     /* leave a margin for the caller's frame buffers and staging */
@@ -694,7 +700,8 @@ static bool pool_enable_packed( vrc_pool* p )
     if( e == hipSuccess )
         e = hipMalloc( &p->dPacked, bytes );
     if( e == hipSuccess )
-        e = vrc_launch_pack_slots( p->dAtlas, p->dPacked, 0u, p->atlasBytes, p->slotDim, p->uploadStream );
+        e = vrc_launch_pack_slots( p->dAtlas, p->dPacked, 0u, p->atlasBytes / p->elemBytes, p->slotDim, p->elemBytes,
+                                   p->uploadStream );
     if( e == hipSuccess )
     {
         e = hipEventRecord( p->lastUpload, p->uploadStream );
@@ -1214,9 +1221,9 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
                                 c->optTfFracBits == 8;
     if( c->rayLod && c->optKernel == VRC_KERNEL_LDS && !ldsLodEligible )
         return fail( VRC_EINVAL, "vrc_render: under per-ray LOD the LDS kernel needs the trilinear filter, 8- or 16-bit bricks with overlap >= 1 and VRC_OPT_TF_FRAC_BITS = 8" );
-    /* tap-packed atlas (VRC_KERNEL_PACKED; vrc_core.h): the trilinear filter as two dword gathers per sample.  Needs what
-     * its positions and its classifier need -- 8-bit bricks with overlap >= 1 in slots of at most 248 voxels a side, an
-     * atlas of at most 2^32 voxels, VRC_OPT_TF_FRAC_BITS = 8 -- and 2.25 times the atlas in device memory; either brick
+    /* tap-packed atlas (VRC_KERNEL_PACKED; vrc_core.h): the trilinear filter as two gathers per sample.  Needs what its
+     * positions and its classifier need -- 8- or 16-bit bricks with overlap >= 1 in slots of at most 248 voxels a side,
+     * VRC_OPT_TF_FRAC_BITS = 8, fixed-point stepping -- and 2.25 times the atlas in device memory; either brick
      * enumeration (grid walk where the node set is grid-aligned, else the reference-order loop) */
     const bool packedEligible = linear && !glSuper && !c->cachedClamp && slotsFit8Bits &&
                                 pool_packed_possible( pool ) && c->optTfFracBits == 8 && c->optStepping != 0;
@@ -1224,14 +1231,14 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     if( c->optKernel == VRC_KERNEL_PACKED )
     {
         if( !packedEligible )
-            return fail( VRC_EINVAL, "vrc_render: the packed kernel needs the trilinear filter on 8-bit bricks with overlap >= 1 (slots of at most 248 voxels a side, an atlas of at most 2^32 voxels), VRC_OPT_TF_FRAC_BITS = 8, fixed-point stepping" );
+            return fail( VRC_EINVAL, "vrc_render: the packed kernel needs the trilinear filter on 8- or 16-bit bricks with overlap >= 1 (slots of at most 248 voxels a side), VRC_OPT_TF_FRAC_BITS = 8, fixed-point stepping" );
         if( !pool_enable_packed( pool ) )
             return fail( VRC_ENOMEM, "vrc_render: no device memory for the tap-packed atlas (2.25 times the brick atlas)" );
         usePacked = true;
     }
     else if( c->optKernel == VRC_KERNEL_AUTO && packedEligible && c->optPackedAtlas )
-        /* measured on C2: 1.51 against 1.69 ms along the axis, 1.93 against 2.40 at 30/20 degrees;
-         * under per-ray LOD 1.1-2.5 x the staged form (profiles/r4_c5_trilinear_three_forms.txt); without the memory for
+        /* measured on C2: 1.2 against 1.7 ms along the axis, 1.5 against 2.4 at 30/20 degrees;
+         * under per-ray LOD 1.4-2.1 x the staged form (profiles/r4_c5_trilinear_three_forms.txt); without the memory for
          * it the frame takes the staged form below */
         usePacked = pool_enable_packed( pool );
     const bool useLds = c->rayLod ? ( ldsLodEligible && c->optKernel != VRC_KERNEL_GRID_DDA && !usePacked )
@@ -1326,8 +1333,9 @@ int vrc_render( vrc_ctx* c, const vrc_view_data* view, const vrc_node_data* node
     a.gridTable = ( useDda || c->rayLod ) ? c->dGrid : nullptr;
     a.atlas = usePacked ? pool->dPacked : pool->dAtlas;
     a.packed = usePacked;
-    /* a packed atlas of more than 4 GiB: 64-bit lane pointers (the BIG instances of the packed modes) */
-    a.packedWide = usePacked && vrc_packed_elems( pool->atlasBytes ) * VRC_PK_TEXEL + 8u > 0xFFFFFFFFull;
+    /* a packed atlas of more than 4 GiB, or of a pool of more than 2^32 voxels: 64-bit lane pointers (the BIG instances of
+     * the packed modes) */
+    a.packedWide = usePacked && ( pool->bigAtlas || pool_packed_bytes( pool ) > 0xFFFFFFFFull );
     a.lut = c->dLut;
     a.pixelBuffer = ctx_fb( c );
     a.sampleCounter = c->optCount ? c->dCounter : nullptr;

@@ -53,7 +53,7 @@
     defined( VRC_GREY_MAX_WAVES ) || \
     defined( VRC_TAIL_GROUP ) || \
     defined( VRC_LGROUP ) || \
-    defined( VRC_PGROUP ) || defined( VRC_PACKED_WAVES ) || defined( VRC_PACKED_ABLATE ) || \
+    defined( VRC_PGROUP ) || defined( VRC_PGROUP16 ) || defined( VRC_PACKED_WAVES ) || defined( VRC_PACKED_ABLATE ) || \
     defined( VRC_SPLIT_GROUP ) || \
     defined( VRC_SMALL_GROUP ) || \
     defined( VRC_SMALL_LAUNCH_TILES ) || \
@@ -1394,7 +1394,7 @@ VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n,
  * the eight taps were eight byte gathers (above) or a staged box in LDS (vrc_kernels_lds.hip), both bound by the
  * instructions and cache look-ups around the sample while HBM idles.  This form spends memory instead: next to the
  * byte atlas the pool keeps a second atlas of 16-bit texels, each a voxel and its neighbour along z,
- *     t(x,y,z) = v[x,y,z] | v[x,y,z+1] << 8,
+ *     t(x,y,z) = v[x,y,z] | v[x,y,z+1] << 8      (16-bit voxels: 32-bit texels, << 16, the gathers 8 bytes each),
  * in which t(x,y,z) and t(x+1,y,z) are ALWAYS neighbours in memory: the texels lie in blocks of 8x8x8 whose x-rows
  * carry a ninth texel, a copy of the next block's first (9/8 x 2 = 2.25 times the bytes of the byte atlas; written by
  * vrc_k_pack_slots when a brick is uploaded; the slot's overlap >= 1 supplies the +1 neighbours).  The eight taps of
@@ -1413,7 +1413,9 @@ VRC_HD bool vrc_march_segment_linear( const vrc_frame& f, const vrc_dev_node& n,
  * two forms composite the same numbers.
  * ---------------------------------------------------------------------------------------- */
 /* slot-local element order of the packed atlas: offset = PX(x) + PY(y) + PZ(z), blocks x-fastest inside the slot */
-#define VRC_PK_TEXEL 2u /* bytes per texel */
+/* bytes per texel: twice the voxel's -- 2 (8-bit voxels: TB = 2 below) or 4 (16-bit voxels: t = v[z] | v[z+1] << 16,
+ * 4.5 bytes per voxel next to the atlas's 2; the pairs of rows y and y + 1 are then two 8-byte gathers) */
+#define VRC_PK_TEXEL( voxelBytes ) ( 2u * ( voxelBytes ) )
 #define VRC_PK_ROW 9u
 #define VRC_PK_BLOCK ( VRC_PK_ROW * 64u ) /* 576 texels */
 /* row number of (y & 7, z & 7) inside a block: the bits of y and z interleaved */
@@ -1438,7 +1440,9 @@ VRC_HD void vrc_packed_decode( uint32_t in, uint32_t& ix, uint32_t& iy, uint32_t
  * (byte slots are whole blocks of 512) */
 VRC_HD uint64_t vrc_packed_elems( uint64_t byteElems ) { return byteElems / VRC_MB_VOXELS * VRC_PK_BLOCK; }
 
-VRC_HD uint16_t vrc_pack_taps( uint32_t vz0, uint32_t vz1 ) { return (uint16_t)( vz0 | ( vz1 << 8 ) ); }
+/* texel of a voxel and its neighbour along z; T = uint16_t (8-bit voxels) or uint32_t (16-bit voxels) */
+template < typename T >
+VRC_HD T vrc_pack_taps( uint32_t vz0, uint32_t vz1 ) { return (T)( vz0 | ( vz1 << ( 4u * sizeof( T ) ) ) ); }
 
 /* classifier of a trilinear sample that arrives scaled by 2^72 (three unscaled 24-bit weights): the oracle's
  * orc_tf_fetch + composite (cuda/ColorMap.cu:40-45, cuda/Renderer.cu:83-93) with the transfer-function texel pair
@@ -1524,12 +1528,29 @@ VRC_HD vrc_f4 vrc_classify8( const vrc_f4*, const vrc_f4* tab, float d, const vr
     return e;
 }
 
-/* the interpolated density of a sample, times 2^72: T0 = t(x0,y0,z0) | t(x0+1,y0,z0) << 16, T1 the same at y0 + 1 (a
- * texel's low byte is z0, its high byte z0 + 1); weights = the 24 fraction bits of the sample's 8.24 coordinates, NOT
- * scaled by 2^-24 -- W and 2^24 - W are exact, so every product and sum is 2^24 (2^48, 2^72) times the one with scaled
- * weights, bit for bit; vrc_cls8.mult carries the 2^-72.  The oracle's order: x, then y, then z; a * (1 - w) + b * w. */
-VRC_HD float vrc_trilerp_packed( uint32_t T0, uint32_t T1, uint32_t fx, uint32_t fy, uint32_t fz )
+/* the taps of a sample as they come out of the two gathers (TB = bytes per texel).  TB = 2: t0 = t(x0,y0,z0) |
+ * t(x0+1,y0,z0) << 16, t1 the same at y0 + 1 (a texel's low byte is z0, its high byte z0 + 1).  TB = 4: one texel per
+ * word, a = row y0, b = row y0 + 1, 0 / 1 = x0 / x0 + 1 (low half z0, high half z0 + 1). */
+template < int TB >
+struct vrc_pk_taps;
+template <>
+struct vrc_pk_taps< 2 >
 {
+    uint32_t t0, t1;
+};
+template <>
+struct vrc_pk_taps< 4 >
+{
+    uint32_t a0, a1, b0, b1;
+};
+
+/* the interpolated density of a sample, times 2^72; weights = the 24 fraction bits of the sample's 8.24 coordinates,
+ * NOT scaled by 2^-24 -- W and 2^24 - W are exact, so every product and sum is 2^24 (2^48, 2^72) times the one with
+ * scaled weights, bit for bit; vrc_cls8.mult carries the 2^-72.  The oracle's order: x, then y, then z;
+ * a * (1 - w) + b * w. */
+VRC_HD float vrc_trilerp_packed( const vrc_pk_taps< 2 >& t, uint32_t fx, uint32_t fy, uint32_t fz )
+{
+    const uint32_t T0 = t.t0, T1 = t.t1;
     const float wx = (float)( fx & 0xFFFFFFu ), wy = (float)( fy & 0xFFFFFFu ), wz = (float)( fz & 0xFFFFFFu );
     const float ux = 16777216.0f - wx, uy = 16777216.0f - wy, uz = 16777216.0f - wz;
     const float c00 = __builtin_fmaf( (float)( ( T0 >> 16 ) & 255u ), wx, (float)( T0 & 255u ) * ux );  /* y0 z0 */
@@ -1540,14 +1561,23 @@ VRC_HD float vrc_trilerp_packed( uint32_t T0, uint32_t T1, uint32_t fx, uint32_t
     const float c1 = __builtin_fmaf( c11, wy, c01 * uy );
     return __builtin_fmaf( c1, wz, c0 * uz );
 }
-
-/* the two texel pairs of a sample at byte offsets of the lane's packed slot: 4-byte loads at 2-byte-aligned
- * addresses.  On the device the pointer is typed as global memory, so the compiler emits global_load_dword. */
-struct vrc_texel_pair
+VRC_HD float vrc_trilerp_packed( const vrc_pk_taps< 4 >& t, uint32_t fx, uint32_t fy, uint32_t fz )
 {
-    uint32_t t0, t1;
-};
-VRC_HD vrc_texel_pair vrc_packed_load( const uint8_t* slot, uint32_t byteOffset, uint32_t byteOffsetY1 )
+    const float wx = (float)( fx & 0xFFFFFFu ), wy = (float)( fy & 0xFFFFFFu ), wz = (float)( fz & 0xFFFFFFu );
+    const float ux = 16777216.0f - wx, uy = 16777216.0f - wy, uz = 16777216.0f - wz;
+    const float c00 = __builtin_fmaf( (float)( t.a1 & 0xFFFFu ), wx, (float)( t.a0 & 0xFFFFu ) * ux ); /* y0 z0 */
+    const float c01 = __builtin_fmaf( (float)( t.a1 >> 16 ), wx, (float)( t.a0 >> 16 ) * ux );         /* y0 z1 */
+    const float c10 = __builtin_fmaf( (float)( t.b1 & 0xFFFFu ), wx, (float)( t.b0 & 0xFFFFu ) * ux ); /* y1 z0 */
+    const float c11 = __builtin_fmaf( (float)( t.b1 >> 16 ), wx, (float)( t.b0 >> 16 ) * ux );         /* y1 z1 */
+    const float c0 = __builtin_fmaf( c10, wy, c00 * uy );
+    const float c1 = __builtin_fmaf( c11, wy, c01 * uy );
+    return __builtin_fmaf( c1, wz, c0 * uz );
+}
+
+/* the two gathers of a sample at byte offsets of the lane's packed slot.  TB = 2: 4-byte loads at 2-byte-aligned
+ * addresses; TB = 4: 8-byte loads at 4-byte-aligned addresses (multi-dword loads need dword alignment only).  On the
+ * device the pointer is typed as global memory, so the compiler emits global_load_dword / _dwordx2. */
+VRC_HD vrc_pk_taps< 2 > vrc_packed_load( const vrc_pk_taps< 2 >*, const uint8_t* slot, uint32_t byteOffset, uint32_t byteOffsetY1 )
 {
 #if defined( VRC_PACKED_ABLATE ) && VRC_PACKED_ABLATE == 3 /* timing experiment only: 4-byte-aligned (wrong) addresses */
     byteOffset &= ~2u;
@@ -1556,19 +1586,39 @@ VRC_HD vrc_texel_pair vrc_packed_load( const uint8_t* slot, uint32_t byteOffset,
 #if defined( __HIP_DEVICE_COMPILE__ )
     typedef uint32_t u32_a2 __attribute__( ( aligned( 2 ) ) );
     typedef __attribute__( ( address_space( 1 ) ) ) const u32_a2 g_t;
-    return vrc_texel_pair{ *reinterpret_cast< g_t* >( (uintptr_t)( slot + byteOffset ) ),
-                           *reinterpret_cast< g_t* >( (uintptr_t)( slot + byteOffsetY1 ) ) };
+    return vrc_pk_taps< 2 >{ *reinterpret_cast< g_t* >( (uintptr_t)( slot + byteOffset ) ),
+                          *reinterpret_cast< g_t* >( (uintptr_t)( slot + byteOffsetY1 ) ) };
 #else
-    vrc_texel_pair t;
+    vrc_pk_taps< 2 > t;
     memcpy( &t.t0, slot + byteOffset, 4 );
     memcpy( &t.t1, slot + byteOffsetY1, 4 );
     return t;
 #endif
 }
+VRC_HD vrc_pk_taps< 4 > vrc_packed_load( const vrc_pk_taps< 4 >*, const uint8_t* slot, uint32_t byteOffset, uint32_t byteOffsetY1 )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+    typedef uint32_t u32x2_a4 __attribute__( ( ext_vector_type( 2 ), aligned( 4 ) ) );
+    typedef __attribute__( ( address_space( 1 ) ) ) const u32x2_a4 g_t;
+    const u32x2_a4 a = *reinterpret_cast< g_t* >( (uintptr_t)( slot + byteOffset ) );
+    const u32x2_a4 b = *reinterpret_cast< g_t* >( (uintptr_t)( slot + byteOffsetY1 ) );
+    return vrc_pk_taps< 4 >{ a.x, a.y, b.x, b.y };
+#else
+    vrc_pk_taps< 4 > t;
+    memcpy( &t.a0, slot + byteOffset, 8 );
+    memcpy( &t.b0, slot + byteOffsetY1, 8 );
+    return t;
+#endif
+}
+/* (timing experiments only) */
+VRC_HD vrc_pk_taps< 2 > vrc_pk_taps_fake( const vrc_pk_taps< 2 >*, uint32_t off ) { return vrc_pk_taps< 2 >{ off * 0x01010101u, off * 0x00010101u }; }
+VRC_HD vrc_pk_taps< 4 > vrc_pk_taps_fake( const vrc_pk_taps< 4 >*, uint32_t off ) { return vrc_pk_taps< 4 >{ off * 0x01010101u, off * 0x00010101u, off, ~off }; }
+VRC_HD uint32_t vrc_pk_taps_mix( const vrc_pk_taps< 2 >& t ) { return t.t0 ^ t.t1; }
+VRC_HD uint32_t vrc_pk_taps_mix( const vrc_pk_taps< 4 >& t ) { return t.a0 ^ t.a1 ^ t.b0 ^ t.b1; }
 
 /* byte offsets (slot-local + bias) of the texel pairs of the next N samples; p advances by N steps.  Device: the per-axis
- * parts from the tables in LDS (filled by the kernel with VRC_PK_TEXEL * vrc_pk_x / y / z). */
-template < int N >
+ * parts from the tables in LDS (filled by the kernel with TB * vrc_pk_x / y / z). */
+template < int N, int TB >
 VRC_HD void vrc_packed_offsets( const vrc_sampler& s, vrc_fixpos& p, uint32_t bias, uint32_t* off, uint32_t* offY1 )
 {
 #if defined( __HIP_DEVICE_COMPILE__ ) && defined( VRC_ADDR_TABLES )
@@ -1593,8 +1643,8 @@ VRC_HD void vrc_packed_offsets( const vrc_sampler& s, vrc_fixpos& p, uint32_t bi
 #pragma unroll
     for( int k = 0; k < N; ++k )
     {
-        off[k] = bias + VRC_PK_TEXEL * vrc_packed_local_index( p.x >> 24, p.y >> 24, p.z >> 24, sbx, sby );
-        offY1[k] = bias + VRC_PK_TEXEL * vrc_packed_local_index( p.x >> 24, ( ( p.y >> 24 ) + 1u ) & 255u, p.z >> 24, sbx, sby );
+        off[k] = bias + (uint32_t)TB * vrc_packed_local_index( p.x >> 24, p.y >> 24, p.z >> 24, sbx, sby );
+        offY1[k] = bias + (uint32_t)TB * vrc_packed_local_index( p.x >> 24, ( ( p.y >> 24 ) + 1u ) & 255u, p.z >> 24, sbx, sby );
         p.x += p.dx;
         p.y += p.dy;
         p.z += p.dz;
@@ -1605,15 +1655,18 @@ VRC_HD void vrc_packed_offsets( const vrc_sampler& s, vrc_fixpos& p, uint32_t bi
 #ifndef VRC_PGROUP
 #define VRC_PGROUP 12 /* (4 ... 24 measured: the fetches in flight per wave decide; 12 at three waves per SIMD) */
 #endif
+#ifndef VRC_PGROUP16
+#define VRC_PGROUP16 8 /* 16-bit voxels: four registers of taps per sample in flight */
+#endif
 
 
 /* March one brick segment through the packed atlas (Renderer.cu:206-223 with the trilinear fetch).  Organised as
  * vrc_march_segment_as: whole groups without per-sample tests while more than GROUP steps remain, the early-exit
  * test once per group with an exact replay, a general tail.  tab: vrc_cls8_entry table.  E: vrc_f4, or vrc_f2
  * for a grey transfer function (vrc_raycast_args.greyTable). */
-template < bool COUNT, int GROUP, typename E, bool WIDE >
+template < bool COUNT, int GROUP, typename E, bool WIDE, int TB >
 VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n, vrc_segment s,
-                                      const uint32_t* __restrict__ packed, const vrc_f4* tab, const vrc_cls8& kc,
+                                      const void* __restrict__ packed, const vrc_f4* tab, const vrc_cls8& kc,
                                       E& color, uint32_t& nSamples, float levelStep )
 {
     const float stepSize = levelStep > 0.0f ? levelStep : f.stepSize;
@@ -1623,7 +1676,7 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
     const vrc_sampler sm = vrc_make_sampler( n, f );
     /* the lane's packed slot.  A packed atlas of at most 4 GiB: the atlas pointer (uniform: a scalar base) + a 32-bit
      * byte offset per lane, the slot's offset folded into it.  WIDE (a larger one): a 64-bit pointer per lane. */
-    const uint64_t slotBytes = vrc_packed_elems( n.slotBase ) * VRC_PK_TEXEL;
+    const uint64_t slotBytes = vrc_packed_elems( WIDE ? ( (uint64_t)n.slotBaseHi << 32 ) | n.slotBase : (uint64_t)n.slotBase ) * (uint32_t)TB;
     const uint8_t* const slot = reinterpret_cast< const uint8_t* >( packed ) + ( WIDE ? slotBytes : 0u );
     const uint32_t bias = WIDE ? 0u : (uint32_t)slotBytes;
     vrc_fixpos fp = vrc_fixpos_init( sm, s.pos, s.step );
@@ -1636,16 +1689,16 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
     while( travel > guard )
     {
         uint32_t off[GROUP], offY1[GROUP];
-        vrc_texel_pair t[GROUP];
+        vrc_pk_taps< TB > t[GROUP];
         vrc_fixpos q = fp; /* the group's first sample: the weights are taken again from here after the loads */
-        vrc_packed_offsets< GROUP >( sm, fp, bias, off, offY1 );
+        vrc_packed_offsets< GROUP, TB >( sm, fp, bias, off, offY1 );
 #pragma unroll
         for( int k = 0; k < GROUP; ++k )
         {
 #if defined( VRC_PACKED_ABLATE ) && VRC_PACKED_ABLATE == 1 /* timing experiment only: no fetch */
-            t[k] = vrc_texel_pair{ off[k] * 0x01010101u, off[k] * 0x00010101u };
+            t[k] = vrc_pk_taps_fake( (const vrc_pk_taps< TB >*)nullptr, off[k] );
 #else
-            t[k] = vrc_packed_load( slot, off[k], offY1[k] );
+            t[k] = vrc_packed_load( (const vrc_pk_taps< TB >*)nullptr, slot, off[k], offY1[k] );
 #endif
         }
 #pragma unroll
@@ -1657,13 +1710,13 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
         for( int k = 0; k < GROUP; ++k )
         {
             e[k] = E{};
-            e[k].w = (float)( ( t[k].t0 ^ t[k].t1 ) >> 31 ) * 1e-9f;
+            e[k].w = (float)( vrc_pk_taps_mix( t[k] ) >> 31 ) * 1e-9f;
         }
 #else
 #pragma unroll
         for( int k = 0; k < GROUP; ++k )
         {
-            e[k] = vrc_classify8( (const E*)nullptr, tab, vrc_trilerp_packed( t[k].t0, t[k].t1, q.x, q.y, q.z ), kc );
+            e[k] = vrc_classify8( (const E*)nullptr, tab, vrc_trilerp_packed( t[k], q.x, q.y, q.z ), kc );
             q.x += q.dx;
             q.y += q.dy;
             q.z += q.dz;
@@ -1696,9 +1749,9 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
     while( travel > 0.0f && !done )
     {
         uint32_t off[TAILG], offY1[TAILG], cnt = 0;
-        vrc_texel_pair t[TAILG];
+        vrc_pk_taps< TB > t[TAILG];
         vrc_fixpos q = fp;
-        vrc_packed_offsets< TAILG >( sm, fp, bias, off, offY1 );
+        vrc_packed_offsets< TAILG, TB >( sm, fp, bias, off, offY1 );
 #pragma unroll
         for( int k = 0; k < TAILG; ++k )
         {
@@ -1707,14 +1760,14 @@ VRC_HD bool vrc_march_segment_packed( const vrc_frame& f, const vrc_dev_node& n,
             /* a step the reference does not take reads the slot's first texels and blends nothing */
             off[k] = v ? off[k] : bias;
             offY1[k] = v ? offY1[k] : bias;
-            t[k] = vrc_packed_load( slot, off[k], offY1[k] );
+            t[k] = vrc_packed_load( (const vrc_pk_taps< TB >*)nullptr, slot, off[k], offY1[k] );
             travel -= stepSize;
         }
 #pragma unroll
         for( int k = 0; k < TAILG; ++k )
         {
             const E z = {};
-            const E c = vrc_classify8( (const E*)nullptr, tab, vrc_trilerp_packed( t[k].t0, t[k].t1, q.x, q.y, q.z ), kc );
+            const E c = vrc_classify8( (const E*)nullptr, tab, vrc_trilerp_packed( t[k], q.x, q.y, q.z ), kc );
             const bool active = ( (uint32_t)k < cnt ) && !done;
             vrc_composite( color, (uint32_t)k < cnt ? c : z, done );
             if( COUNT )
@@ -1757,19 +1810,21 @@ VRC_HD bool vrc_march_brick( const vrc_frame& f, const vrc_dev_node& n, const vr
 {
     if constexpr( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY )
     {
-        /* (BIG here: a packed atlas of more than 4 GiB -- 64-bit lane pointers; the byte atlas has < 2^32 voxels) */
-        static_assert( sizeof( ATLAS_T ) == 4 && !CLAMP, "the packed atlas: passed as 32-bit words, overlap >= 1" );
+        /* (BIG here: a packed atlas of more than 4 GiB, or of an atlas of more than 2^32 voxels -- 64-bit lane pointers.
+         * ATLAS_T is a tag: uint32_t = the packed form of 8-bit voxels, uint64_t = of 16-bit voxels) */
+        static_assert( ( sizeof( ATLAS_T ) == 4 || sizeof( ATLAS_T ) == 8 ) && !CLAMP, "the packed atlas: overlap >= 1" );
+        constexpr int TB = sizeof( ATLAS_T ) == 8 ? 4 : 2;
         const vrc_cls8 kc = vrc_make_cls8( cls );
         if constexpr( MODE == VRC_MODE_PACKED_GREY )
         {
             vrc_f2 c = { color.x, color.w };
-            const bool done = vrc_march_segment_packed< COUNT, GROUP, vrc_f2, BIG >( f, n, s, atlas, lut, kc, c, nSamples, levelStep );
+            const bool done = vrc_march_segment_packed< COUNT, GROUP, vrc_f2, BIG, TB >( f, n, s, atlas, lut, kc, c, nSamples, levelStep );
             color.x = color.y = color.z = c.x;
             color.w = c.w;
             return done;
         }
         else
-            return vrc_march_segment_packed< COUNT, GROUP, vrc_f4, BIG >( f, n, s, atlas, lut, kc, color, nSamples, levelStep );
+            return vrc_march_segment_packed< COUNT, GROUP, vrc_f4, BIG, TB >( f, n, s, atlas, lut, kc, color, nSamples, levelStep );
     }
     else if( BIG )
     {

@@ -73,10 +73,11 @@ hipError_t vrc_launch_repack_brick( const void* srcRowMajor, void* slot, uint32_
                                     const uint32_t size[3], const uint32_t slotDim[3],
                                     hipStream_t stream );
 
-/* byte atlas -> tap-packed atlas (vrc_core.h): the packed texels of elements [firstElem, firstElem + nElems) of the
- * byte atlas (whole slots; the packed atlas holds vrc_packed_elems( atlas elements ) texels of 4 bytes) */
+/* atlas -> tap-packed atlas (vrc_core.h): the packed texels of elements [firstElem, firstElem + nElems) of the atlas of
+ * 8- or 16-bit voxels (whole slots; the packed atlas holds vrc_packed_elems( atlas elements ) texels of
+ * VRC_PK_TEXEL( elemBytes ) bytes) */
 hipError_t vrc_launch_pack_slots( const void* atlas, void* packed, uint64_t firstElem, uint64_t nElems,
-                                  const uint32_t slotDim[3], hipStream_t stream );
+                                  const uint32_t slotDim[3], uint32_t elemBytes, hipStream_t stream );
 
 /* inverse, for tests: logical atlas region -> row-major */
 hipError_t vrc_launch_read_region( const void* atlas, void* dstRowMajor, uint32_t elemBytes,
@@ -116,7 +117,8 @@ struct vrc_raycast_args
                         * only for the table-driven point-sampling walk kernel and frames below 65536 pixels a side */
     uint32_t* rayList; /* counts[VRC_MAX_ERT_PARTS] | two lists of width * height packed pixels */
     bool packed;     /* trilinear through the tap-packed atlas: atlas = the pool's packed atlas (vrc_march_segment_packed) */
-    bool packedWide; /* ... of more than 4 GiB: 64-bit lane pointers instead of scalar base + 32-bit offset (BIG instances) */
+    bool packedWide; /* ... of more than 4 GiB, or of an atlas of more than 2^32 voxels: 64-bit lane pointers instead of
+                      * scalar base + 32-bit offset (BIG instances) */
     bool depthSplit; /* two waves per tile, near / far half of every ray (vrc_k_raycast_split): set by the host
                       * only when early ray termination cannot occur in this frame and the frame is cleared */
 };

@@ -284,19 +284,20 @@ hipError_t vrc_launch_read_region( const void* atlas, void* dst, uint32_t elemBy
 
 /* ------------------------------------------------------------------------------------------
  * tap-packed atlas (vrc_core.h, "tap-packed form of the trilinear filter"): texel (x,y,z) of a slot =
- * v[x,y,z] | v[x,y,z+1] << 8 of the byte slot, in blocks of 64 rows of 9 texels (vrc_packed_decode; the ninth column
+ * v[x,y,z] | v[x,y,z+1] << 8 (<< 16 for 16-bit voxels) of the atlas's slot, in blocks of 64 rows of 9 texels (vrc_packed_decode; the ninth column
  * repeats the next block's first; the z neighbour and the copy clamped at the slot's last voxel: never read with a
  * weight, a sample's lower tap is at most slotDim - 2 with overlap >= 1).  One thread per packed texel, coalesced
  * 2-byte stores; the byte reads hit L1/L2.
  * ---------------------------------------------------------------------------------------- */
-__global__ __launch_bounds__( 256 ) void vrc_k_pack_slots( const uint8_t* __restrict__ atlas, uint16_t* __restrict__ packed,
+template < typename V, typename T >
+__global__ __launch_bounds__( 256 ) void vrc_k_pack_slots( const V* __restrict__ atlas, T* __restrict__ packed,
                                                            uint64_t firstSlot, uint32_t slotBlocks, uint32_t sdx, uint32_t sdy,
                                                            uint32_t sdz, uint32_t sbx, uint32_t sby )
 {
     /* blockIdx.y = the slot (64-bit only in its base), x strides over the slot's packed texels in 32 bits */
     const uint64_t slotIndex = firstSlot + blockIdx.y;
-    const uint8_t* const slot = atlas + slotIndex * ( (uint64_t)slotBlocks * VRC_MB_VOXELS );
-    uint16_t* const out = packed + slotIndex * ( (uint64_t)slotBlocks * VRC_PK_BLOCK );
+    const V* const slot = atlas + slotIndex * ( (uint64_t)slotBlocks * VRC_MB_VOXELS );
+    T* const out = packed + slotIndex * ( (uint64_t)slotBlocks * VRC_PK_BLOCK );
     const uint32_t n = slotBlocks * VRC_PK_BLOCK;
     (void)sdy;
     for( uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x )
@@ -308,15 +309,17 @@ __global__ __launch_bounds__( 256 ) void vrc_k_pack_slots( const uint8_t* __rest
         const uint32_t y = ( ( b / sbx ) % sby ) * 8u + iy, z = ( b / ( sbx * sby ) ) * 8u + iz;
         x = x < sdx ? x : sdx - 1u;
         const uint32_t z1 = z + 1u < sdz ? z + 1u : z;
-        out[i] = vrc_pack_taps( slot[vrc_slot_local_index( x, y, z, sbx, sby )], slot[vrc_slot_local_index( x, y, z1, sbx, sby )] );
+        out[i] = vrc_pack_taps< T >( slot[vrc_slot_local_index( x, y, z, sbx, sby )], slot[vrc_slot_local_index( x, y, z1, sbx, sby )] );
     }
 }
 
 hipError_t vrc_launch_pack_slots( const void* atlas, void* packed, uint64_t firstElem, uint64_t nElems,
-                                  const uint32_t slotDim[3], hipStream_t stream )
+                                  const uint32_t slotDim[3], uint32_t elemBytes, hipStream_t stream )
 {
     if( nElems == 0 )
         return hipSuccess;
+    if( elemBytes != 1u && elemBytes != 2u )
+        return hipErrorInvalidValue;
     const uint32_t slotBlocks = ( slotDim[0] >> VRC_MB_SHIFT ) * ( slotDim[1] >> VRC_MB_SHIFT ) * ( slotDim[2] >> VRC_MB_SHIFT );
     const uint64_t slotElems = (uint64_t)slotBlocks * VRC_MB_VOXELS;
     const uint64_t firstSlot = firstElem / slotElems, nSlots = nElems / slotElems;
@@ -325,9 +328,15 @@ hipError_t vrc_launch_pack_slots( const void* atlas, void* packed, uint64_t firs
     for( uint64_t s0 = 0; s0 < nSlots; s0 += 65535u )
     {
         const uint32_t ns = (uint32_t)std::min< uint64_t >( nSlots - s0, 65535u );
-        hipLaunchKernelGGL( vrc_k_pack_slots, dim3( nSlots > 64u ? std::min( gx, 64u ) : gx, ns ), dim3( 256 ), 0, stream,
-                            (const uint8_t*)atlas, (uint16_t*)packed, firstSlot + s0, slotBlocks, slotDim[0], slotDim[1], slotDim[2],
-                            slotDim[0] >> VRC_MB_SHIFT, slotDim[1] >> VRC_MB_SHIFT );
+        const dim3 grid( nSlots > 64u ? std::min( gx, 64u ) : gx, ns );
+        if( elemBytes == 1u )
+            hipLaunchKernelGGL( ( vrc_k_pack_slots< uint8_t, uint16_t > ), grid, dim3( 256 ), 0, stream, (const uint8_t*)atlas,
+                                (uint16_t*)packed, firstSlot + s0, slotBlocks, slotDim[0], slotDim[1], slotDim[2],
+                                slotDim[0] >> VRC_MB_SHIFT, slotDim[1] >> VRC_MB_SHIFT );
+        else
+            hipLaunchKernelGGL( ( vrc_k_pack_slots< uint16_t, uint32_t > ), grid, dim3( 256 ), 0, stream, (const uint16_t*)atlas,
+                                (uint32_t*)packed, firstSlot + s0, slotBlocks, slotDim[0], slotDim[1], slotDim[2],
+                                slotDim[0] >> VRC_MB_SHIFT, slotDim[1] >> VRC_MB_SHIFT );
     }
     return hipGetLastError();
 }
@@ -588,9 +597,10 @@ __global__ __launch_bounds__( VRC_WG_THREADS ) __attribute__( ( amdgpu_waves_per
         /* per-axis BYTE offsets of the packed atlas's texels (vrc_core.h: vrc_pk_x / y / z) */
         for( uint32_t u = tid; u < 256u; u += VRC_WG_THREADS )
         {
-            vrc_addr_tab[u] = VRC_PK_TEXEL * vrc_pk_x( u );
-            vrc_addr_tab[256u + u] = VRC_PK_TEXEL * vrc_pk_y( u, f.sbx );
-            vrc_addr_tab[512u + u] = VRC_PK_TEXEL * vrc_pk_z( u, f.sbx, f.sby );
+            constexpr uint32_t TB = sizeof( ATLAS_T ) == 8 ? 4u : 2u; /* bytes per texel (ATLAS_T: the packed mode's tag) */
+            vrc_addr_tab[u] = TB * vrc_pk_x( u );
+            vrc_addr_tab[256u + u] = TB * vrc_pk_y( u, f.sbx );
+            vrc_addr_tab[512u + u] = TB * vrc_pk_z( u, f.sbx, f.sby );
         }
     }
     else if( FIXED )
@@ -706,7 +716,7 @@ static hipError_t launch_variant( const vrc_raycast_args& a, hipStream_t stream 
         return hipSuccess;
     vrc_internal_note_kernel( "vrc_k_raycast<%s,%s,%s,%s,%d,%s,%d,%s>", DDA ? "true" : "false", CLAMP ? "true" : "false",
                               COUNT ? "true" : "false", FIXED ? "true" : "false", (int)MODE,
-                              sizeof( ATLAS_T ) == 1 ? "unsigned char" : ( sizeof( ATLAS_T ) == 2 ? "unsigned short" : "unsigned int" ),
+                              sizeof( ATLAS_T ) == 1 ? "unsigned char" : ( sizeof( ATLAS_T ) == 2 ? "unsigned short" : ( sizeof( ATLAS_T ) == 4 ? "unsigned int" : "unsigned long" ) ),
                               (int)GROUP, BIG ? "true" : "false" );
     vrc_internal_note_kernel_fn( (const void*)&vrc_k_raycast< DDA, CLAMP, COUNT, FIXED, MODE, ATLAS_T, GROUP, BIG >,
                                  (int)VRC_WG_THREADS, 0 );
@@ -1054,16 +1064,25 @@ static hipError_t launch_big( const vrc_raycast_args& a, bool count, hipStream_t
 }
 
 /* trilinear through the tap-packed atlas (a.atlas = the packed atlas; the host offers it for 8-bit bricks with
- * overlap >= 1, slots of at most 248 voxels a side, atlases of at most 2^32 voxels, VRC_OPT_TF_FRAC_BITS = 8);
- * WIDE: a packed atlas of more than 4 GiB */
-template < int MODE, bool WIDE >
+ * or 16-bit bricks with overlap >= 1, slots of at most 248 voxels a side, VRC_OPT_TF_FRAC_BITS = 8);
+ * WIDE: a packed atlas of more than 4 GiB or of an atlas of more than 2^32 voxels */
+template < int MODE, bool WIDE, typename TAG >
 static hipError_t launch_packed( const vrc_raycast_args& a, bool count, hipStream_t stream )
 {
+    /* TAG: uint32_t = the packed atlas of 8-bit voxels (16-bit texels, groups of VRC_PGROUP), uint64_t = of 16-bit
+     * voxels (32-bit texels: twice the registers per sample in flight, groups of VRC_PGROUP16) */
+    constexpr int G = sizeof( TAG ) == 8 ? VRC_PGROUP16 : VRC_PGROUP;
     if( a.gridDda )
-        return count ? launch_variant< true, false, true, true, MODE, uint32_t, VRC_PGROUP, WIDE >( a, stream )
-                     : launch_variant< true, false, false, true, MODE, uint32_t, VRC_PGROUP, WIDE >( a, stream );
-    return count ? launch_variant< false, false, true, true, MODE, uint32_t, VRC_PGROUP, WIDE >( a, stream )
-                 : launch_variant< false, false, false, true, MODE, uint32_t, VRC_PGROUP, WIDE >( a, stream );
+        return count ? launch_variant< true, false, true, true, MODE, TAG, G, WIDE >( a, stream )
+                     : launch_variant< true, false, false, true, MODE, TAG, G, WIDE >( a, stream );
+    return count ? launch_variant< false, false, true, true, MODE, TAG, G, WIDE >( a, stream )
+                 : launch_variant< false, false, false, true, MODE, TAG, G, WIDE >( a, stream );
+}
+template < bool WIDE, typename TAG >
+static hipError_t launch_packed( const vrc_raycast_args& a, bool count, hipStream_t stream )
+{
+    return a.greyTable ? launch_packed< VRC_MODE_PACKED_GREY, WIDE, TAG >( a, count, stream )
+                       : launch_packed< VRC_MODE_PACKED, WIDE, TAG >( a, count, stream );
 }
 
 hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
@@ -1071,13 +1090,11 @@ hipError_t vrc_launch_raycast( const vrc_raycast_args& a, hipStream_t stream )
     const bool count = a.sampleCounter != nullptr;
     if( a.packed )
     {
-        if( !a.linear || a.elemBytes != 1 || a.bigAtlas || a.clamp )
+        if( !a.linear || ( a.elemBytes != 1 && a.elemBytes != 2 ) || a.clamp || ( a.bigAtlas && !a.packedWide ) )
             return hipErrorInvalidValue;
-        if( a.packedWide )
-            return a.greyTable ? launch_packed< VRC_MODE_PACKED_GREY, true >( a, count, stream )
-                               : launch_packed< VRC_MODE_PACKED, true >( a, count, stream );
-        return a.greyTable ? launch_packed< VRC_MODE_PACKED_GREY, false >( a, count, stream )
-                           : launch_packed< VRC_MODE_PACKED, false >( a, count, stream );
+        if( a.elemBytes == 2 )
+            return a.packedWide ? launch_packed< true, uint64_t >( a, count, stream ) : launch_packed< false, uint64_t >( a, count, stream );
+        return a.packedWide ? launch_packed< true, uint32_t >( a, count, stream ) : launch_packed< false, uint32_t >( a, count, stream );
     }
     if( a.bigAtlas )
     {

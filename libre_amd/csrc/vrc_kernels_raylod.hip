@@ -61,9 +61,10 @@ __global__ __launch_bounds__( VRC_RL_THREADS, VRC_RL_MIN_BLOCKS ) void vrc_k_ray
     {
         for( uint32_t u = tid; u < 256u; u += VRC_RL_THREADS )
         {
-            vrc_addr_tab[u] = VRC_PK_TEXEL * vrc_pk_x( u );
-            vrc_addr_tab[256u + u] = VRC_PK_TEXEL * vrc_pk_y( u, f.sbx );
-            vrc_addr_tab[512u + u] = VRC_PK_TEXEL * vrc_pk_z( u, f.sbx, f.sby );
+            constexpr uint32_t TB = sizeof( ATLAS_T ) == 8 ? 4u : 2u; /* bytes per texel (ATLAS_T: the packed mode's tag) */
+            vrc_addr_tab[u] = TB * vrc_pk_x( u );
+            vrc_addr_tab[256u + u] = TB * vrc_pk_y( u, f.sbx );
+            vrc_addr_tab[512u + u] = TB * vrc_pk_z( u, f.sbx, f.sby );
         }
     }
     else if( FIXED )
@@ -95,7 +96,10 @@ __global__ __launch_bounds__( VRC_RL_THREADS, VRC_RL_MIN_BLOCKS ) void vrc_k_ray
     uint32_t nSamples = 0;
     if( px < f.width && py < f.height )
         vrc_pixel_ray_lod< CLAMP, COUNT, FIXED, MODE, ATLAS_T,
-                           ( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY ) ? VRC_PGROUP : VRC_GROUP, BIG >(
+                           ( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY )
+                               ? ( sizeof( ATLAS_T ) == 8 ? VRC_PGROUP16 : VRC_PGROUP )
+                               : VRC_GROUP,
+                           BIG >(
             f, nodes, levelTables, atlas, lutLevels, cls, pixelBuffer, px, py, nSamples );
     if( COUNT )
     {
@@ -120,7 +124,7 @@ static hipError_t launch_raylod( const vrc_raycast_args& a, hipStream_t stream )
                                     : ( ( MODE == VRC_MODE_PACKED || MODE == VRC_MODE_PACKED_GREY ) ? VRC_CLS8_ENTRIES : VRC_TFP_ENTRIES );
     vrc_internal_note_kernel( "vrc_k_raycast_raylod<%s,%s,%s,%d,%s,%s>", CLAMP ? "true" : "false", COUNT ? "true" : "false",
                               FIXED ? "true" : "false", (int)MODE,
-                              sizeof( ATLAS_T ) == 1 ? "unsigned char" : ( sizeof( ATLAS_T ) == 2 ? "unsigned short" : "unsigned int" ),
+                              sizeof( ATLAS_T ) == 1 ? "unsigned char" : ( sizeof( ATLAS_T ) == 2 ? "unsigned short" : ( sizeof( ATLAS_T ) == 4 ? "unsigned int" : "unsigned long" ) ),
                               BIG ? "true" : "false" );
     hipLaunchKernelGGL( ( vrc_k_raycast_raylod< CLAMP, COUNT, FIXED, MODE, ATLAS_T, BIG > ),
                         dim3( ( vrc_schedule_slots( tilesX, tilesY ) + VRC_RL_WAVES - 1u ) / VRC_RL_WAVES ),
@@ -155,21 +159,18 @@ hipError_t vrc_launch_raycast_raylod( const vrc_raycast_args& a, hipStream_t str
     if( a.packed )
     {
         /* the trilinear filter through the tap-packed atlas (a.atlas), the hierarchy walk around it */
-        if( !a.linear || a.elemBytes != 1 || a.bigAtlas || a.clamp )
+        if( !a.linear || ( a.elemBytes != 1 && a.elemBytes != 2 ) || a.clamp || ( a.bigAtlas && !a.packedWide ) )
             return hipErrorInvalidValue;
-        if( a.packedWide ) /* a packed atlas of more than 4 GiB: 64-bit lane pointers */
-        {
-            if( a.greyTable )
-                return count ? launch_raylod< false, true, true, VRC_MODE_PACKED_GREY, uint32_t, true >( a, stream )
-                             : launch_raylod< false, false, true, VRC_MODE_PACKED_GREY, uint32_t, true >( a, stream );
-            return count ? launch_raylod< false, true, true, VRC_MODE_PACKED, uint32_t, true >( a, stream )
-                         : launch_raylod< false, false, true, VRC_MODE_PACKED, uint32_t, true >( a, stream );
-        }
-        if( a.greyTable )
-            return count ? launch_raylod< false, true, true, VRC_MODE_PACKED_GREY, uint32_t >( a, stream )
-                         : launch_raylod< false, false, true, VRC_MODE_PACKED_GREY, uint32_t >( a, stream );
-        return count ? launch_raylod< false, true, true, VRC_MODE_PACKED, uint32_t >( a, stream )
-                     : launch_raylod< false, false, true, VRC_MODE_PACKED, uint32_t >( a, stream );
+        /* (tags: uint32_t = the packed atlas of 8-bit voxels, uint64_t = of 16-bit voxels; ...,true>: 64-bit lane pointers) */
+#define VRC_RL_PACKED( TAG, WIDE )                                                                                       \
+    ( a.greyTable ? ( count ? launch_raylod< false, true, true, VRC_MODE_PACKED_GREY, TAG, WIDE >( a, stream )           \
+                            : launch_raylod< false, false, true, VRC_MODE_PACKED_GREY, TAG, WIDE >( a, stream ) )        \
+                  : ( count ? launch_raylod< false, true, true, VRC_MODE_PACKED, TAG, WIDE >( a, stream )                \
+                            : launch_raylod< false, false, true, VRC_MODE_PACKED, TAG, WIDE >( a, stream ) ) )
+        if( a.elemBytes == 2 )
+            return a.packedWide ? VRC_RL_PACKED( uint64_t, true ) : VRC_RL_PACKED( uint64_t, false );
+        return a.packedWide ? VRC_RL_PACKED( uint32_t, true ) : VRC_RL_PACKED( uint32_t, false );
+#undef VRC_RL_PACKED
     }
     if( a.bigAtlas )
     {

@@ -101,15 +101,16 @@ static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3]
     /* kernel: 1 reference order, 2 grid DDA, 3/4 the same with fixed-point stepping (u8 only),
      * 5/6 the same with the trilinear filter, 7/8 point sampling with per-sample
      * classification (the only point-sampling form for 16-bit voxels), 9/10 the trilinear filter through the
-     * tap-packed atlas (u8, overlap >= 1, fracBits 8), 11/12 the same with the (grey, alpha) colours of a grey
+     * tap-packed atlas (u8 or u16, overlap >= 1, fracBits 8), 11/12 the same with the (grey, alpha) colours of a grey
      * transfer function */
     const bool dda = !rayLod && ( kernel == 2 || kernel == 4 || kernel == 6 || kernel == 8 || kernel == 10 || kernel == 12 );
     const bool packedKernel = kernel >= 9 && kernel <= 12;
-    if( packedKernel && ( voxelBytes != 1 || t.clamp || fracBits != 8 ) )
+    if( packedKernel && ( ( voxelBytes != 1 && voxelBytes != 2 ) || t.clamp || fracBits != 8 ) )
         return 5;
-    /* the tap-packed atlas as vrc_k_pack_slots writes it (vrc_core.h): 16-bit texels in rows of 9, the z neighbour and
-     * the ninth column's copy clamped at the slot's last voxel (+ 2 words: a pair is read as 4 bytes) */
-    std::vector< uint32_t > packed( packedKernel ? (size_t)( vrc_packed_elems( nVoxels ) * VRC_PK_TEXEL / 4u + 2u ) : 0 );
+    /* the tap-packed atlas as vrc_k_pack_slots writes it (vrc_core.h): texels of twice the voxel's bytes in rows of 9, the
+     * z neighbour and the ninth column's copy clamped at the slot's last voxel (+ 2 words: a pair is read as 4 / 8 bytes) */
+    const uint32_t texelBytes = VRC_PK_TEXEL( (uint32_t)voxelBytes );
+    std::vector< uint32_t > packed( packedKernel ? (size_t)( vrc_packed_elems( nVoxels ) * texelBytes / 4u + 2u ) : 0 );
     if( packedKernel )
     {
         const uint32_t sbx = slotDim[0] / 8u, sby = slotDim[1] / 8u;
@@ -117,9 +118,7 @@ static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3]
             for( uint32_t j = 0; j < geom.slots[1]; ++j )
                 for( uint32_t i = 0; i < geom.slots[0]; ++i )
                 {
-                    const uint64_t base = vrc_slot_base( lay, i, j, k ); /* of the byte slot */
-                    const uint8_t* const slot = atlas.data() + base;
-                    uint16_t* const out = reinterpret_cast< uint16_t* >( packed.data() ) + vrc_packed_elems( base );
+                    const uint64_t base = vrc_slot_base( lay, i, j, k ); /* of the atlas's slot */
                     for( uint32_t z = 0; z < slotDim[2]; ++z )
                         for( uint32_t y = 0; y < slotDim[1]; ++y )
                             for( uint32_t bx = 0; bx < sbx; ++bx )
@@ -128,8 +127,13 @@ static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3]
                                     uint32_t x = bx * 8u + ix;
                                     x = x < slotDim[0] ? x : slotDim[0] - 1u;
                                     const uint32_t z1 = z + 1u < slotDim[2] ? z + 1u : z;
-                                    out[vrc_packed_local_index( bx * 8u, y, z, sbx, sby ) + ix] =
-                                        vrc_pack_taps( slot[vrc_slot_local_index( x, y, z, sbx, sby )], slot[vrc_slot_local_index( x, y, z1, sbx, sby )] );
+                                    const uint64_t e0 = base + vrc_slot_local_index( x, y, z, sbx, sby ),
+                                                   e1 = base + vrc_slot_local_index( x, y, z1, sbx, sby );
+                                    const uint64_t o = vrc_packed_elems( base ) + vrc_packed_local_index( bx * 8u, y, z, sbx, sby ) + ix;
+                                    if( voxelBytes == 1 )
+                                        reinterpret_cast< uint16_t* >( packed.data() )[o] = vrc_pack_taps< uint16_t >( atlas[e0], atlas[e1] );
+                                    else
+                                        packed[o] = vrc_pack_taps< uint32_t >( atlas16[e0], atlas16[e1] );
                                 }
                 }
     }
@@ -138,7 +142,7 @@ static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3]
     const bool fixed = ( kernel == 3 || kernel == 4 ) && !t.clamp;
     if( dda && !t.gridOk )
         return 2;
-    if( voxelBytes == 2 && mode == VRC_MODE_TABLE )
+    if( voxelBytes == 2 && mode == VRC_MODE_TABLE && !packedKernel )
         return 4; /* the classified table indexes 8-bit voxels only */
     const vrc_classifier cls = vrc_make_classifier( lp );
     std::vector< vrc_f4 > tfp( VRC_TFP_ENTRIES );
@@ -175,19 +179,24 @@ static int render_impl( const uint8_t* atlasRowMajor, const uint32_t atlasDim[3]
         if( t.clamp ) vrc_pixel_ray_lod< true, true, false, MODE, T >( ARGS_DDA( A ) );              \
         else vrc_pixel_ray_lod< false, true, FIXED, MODE, T >( ARGS_DDA( A ) );                      \
     }
-            if( packedKernel && rayLod )
+#define PACKED( TAG, G )                                                                                                                  \
+    {                                                                                                                                     \
+        const TAG* const pk = reinterpret_cast< const TAG* >( packed.data() );                                                            \
+        if( rayLod && kernel >= 11 ) vrc_pixel_ray_lod< false, true, true, VRC_MODE_PACKED_GREY, TAG, G >( ARGS_DDA( pk ) );              \
+        else if( rayLod ) vrc_pixel_ray_lod< false, true, true, VRC_MODE_PACKED, TAG, G >( ARGS_DDA( pk ) );                              \
+        else if( kernel == 9 ) vrc_pixel_reference_order< false, true, true, VRC_MODE_PACKED, TAG, G >( ARGS_REF( pk ) );                 \
+        else if( kernel == 10 ) vrc_pixel_grid_dda< false, true, true, VRC_MODE_PACKED, TAG, G >( ARGS_DDA( pk ) );                       \
+        else if( kernel == 11 ) vrc_pixel_reference_order< false, true, true, VRC_MODE_PACKED_GREY, TAG, G >( ARGS_REF( pk ) );           \
+        else vrc_pixel_grid_dda< false, true, true, VRC_MODE_PACKED_GREY, TAG, G >( ARGS_DDA( pk ) );                                     \
+    }
+            if( packedKernel )
             {
-                /* per-ray LOD around the tap-packed march (kernel 9; 11: grey colours) */
-                if( kernel >= 11 ) vrc_pixel_ray_lod< false, true, true, VRC_MODE_PACKED_GREY, uint32_t, VRC_PGROUP >( ARGS_DDA( packed.data() ) );
-                else vrc_pixel_ray_lod< false, true, true, VRC_MODE_PACKED, uint32_t, VRC_PGROUP >( ARGS_DDA( packed.data() ) );
+                /* the tap-packed march (9 / 10: reference order / grid walk; 11 / 12: grey colours; per-ray LOD around it:
+                 * 9 or 11); the tag says which packed atlas: uint32_t of 8-bit voxels, uint64_t of 16-bit voxels */
+                if( voxelBytes == 1 ) PACKED( uint32_t, VRC_PGROUP )
+                else PACKED( uint64_t, VRC_PGROUP16 )
             }
-            else if( packedKernel )
-            {
-                if( kernel == 9 ) vrc_pixel_reference_order< false, true, true, VRC_MODE_PACKED, uint32_t, VRC_PGROUP >( ARGS_REF( packed.data() ) );
-                else if( kernel == 10 ) vrc_pixel_grid_dda< false, true, true, VRC_MODE_PACKED, uint32_t, VRC_PGROUP >( ARGS_DDA( packed.data() ) );
-                else if( kernel == 11 ) vrc_pixel_reference_order< false, true, true, VRC_MODE_PACKED_GREY, uint32_t, VRC_PGROUP >( ARGS_REF( packed.data() ) );
-                else vrc_pixel_grid_dda< false, true, true, VRC_MODE_PACKED_GREY, uint32_t, VRC_PGROUP >( ARGS_DDA( packed.data() ) );
-            }
+#undef PACKED
             else if( rayLod )
             {
                 if( mode == VRC_MODE_TRILINEAR && voxelBytes == 1 ) RAYLOD( false, VRC_MODE_TRILINEAR, uint8_t, atlas.data() )

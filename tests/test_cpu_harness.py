@@ -225,7 +225,7 @@ def test_trilinear_extension_matches_oracle(name):
 @pytest.mark.parametrize("name", sorted(scenes.SCENES))
 def test_tap_packed_trilinear_matches_oracle(name):
     # the trilinear filter through the tap-packed atlas (VRC_KERNEL_PACKED; vrc_core.h: vrc_march_segment_packed):
-    # 32-bit texels holding the 2x2 neighbourhood, two reads per sample -- against the oracle's fetch_trilinear, for
+    # 16-bit texels holding a voxel and its z neighbour, two 4-byte reads per sample -- against the oracle's fetch_trilinear, for
     # both brick enumerations and with the (grey, alpha) colours of a grey transfer function
     s = scenes.get(name)
     if min(s.vi.overlap[a] for a in range(3)) < 1 or s.atlas.dtype.itemsize != 1:
@@ -286,6 +286,19 @@ def test_uint16_extension_matches_oracle(name):
         got, n_got, _ = orc.harness_render(s, kernel=kernel)
         scenes.assert_parity(got, want_lin, "%s k%d" % (name, kernel))
         assert abs(n_got - n_lin) <= 2e-4 * n_lin + 8
+    # the trilinear filter through the tap-packed atlas of 16-bit voxels (32-bit texels, two 8-byte reads per sample):
+    # reference order / grid walk, and the same bits with the two-float colours of a grey transfer function
+    if min(s.vi.overlap[a] for a in range(3)) >= 1:
+        frames = {}
+        for kernel in (9, 10):
+            got, n_got, _ = orc.harness_render(s, kernel=kernel)
+            scenes.assert_parity(got, want_lin, "%s packed k%d" % (name, kernel))
+            assert abs(n_got - n_lin) <= 2e-4 * n_lin + 8
+            frames[kernel] = got
+        if (s.tf[:, 0] == s.tf[:, 1]).all() and (s.tf[:, 0] == s.tf[:, 2]).all():
+            for kernel in (11, 12):
+                got, _, _ = orc.harness_render(s, kernel=kernel)
+                assert (got == frames[kernel - 2]).all(), "%s k%d: grey form differs" % (name, kernel)
 
 
 def test_per_sample_classification_equals_the_classified_table():

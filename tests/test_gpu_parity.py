@@ -288,8 +288,15 @@ def test_lds_staged_trilinear_uint16(vrc, case):
         assert st.kernel_variant == vrc.KERNEL_LDS and g.L.vrc_last_kernel().decode().endswith(",false,unsigned short,false>")
         gat, n_gat, st = g.render(kernel=vrc.KERNEL_GRID_DDA, filter_mode=vrc.FILTER_TRILINEAR)
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
+        # AUTO: the tap-packed atlas of 16-bit voxels (32-bit texels, two 8-byte gathers per sample) -- the staged form's
+        # positions, weights and arithmetic: the same frame, bit for bit
+        packed, n_packed, st = g.render(filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_PACKED and ",unsigned long," in g.L.vrc_last_kernel().decode(), g.L.vrc_last_kernel()
+        assert n_packed == n_lin and (packed == lin).all()
         vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_GREY_TABLE, 0))
         four, n_four, _ = g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
+        packed4, n_packed4, st = g.render(kernel=vrc.KERNEL_PACKED, filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_PACKED and n_packed4 == n_lin and (packed4 == lin).all()
     scenes.assert_parity(lin, want_lin, "u16 staged trilinear, " + case)
     scenes.assert_parity(gat, want_lin, "u16 gathered trilinear, " + case)
     assert abs(n_lin - n_want_lin) <= 2e-4 * n_want_lin + 8
@@ -319,13 +326,17 @@ def test_uint16_extension_parity(vrc, name):
             assert abs(n_got - n_lin) <= 2e-4 * n_lin + 8
         with pytest.raises(Exception):
             g.render(kernel=vrc.KERNEL_LDS)  # point sampling through LDS reads the classified table: 8-bit only
-        # the trilinear filter is staged through LDS for 16-bit voxels too (what AUTO picks)
+        # the trilinear filter is staged through LDS for 16-bit voxels too; AUTO takes the tap-packed atlas (same bits)
         staged, n_got, st = g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
         assert st.kernel_variant == vrc.KERNEL_LDS and g.L.vrc_last_kernel().decode().endswith(",false,unsigned short,false>")
         scenes.assert_parity(staged, want_lin, name + " trilinear, staged")
         assert abs(n_got - n_lin) <= 2e-4 * n_lin + 8
         auto, _, st = g.render(filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_PACKED and (auto == staged).all()
+        vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_PACKED_ATLAS, 0))
+        auto, _, st = g.render(filter_mode=vrc.FILTER_TRILINEAR)
         assert st.kernel_variant == vrc.KERNEL_LDS and (auto == staged).all()
+        vrc.check(g.L, g.L.vrc_set_option(g.ctx, vrc.OPT_PACKED_ATLAS, 1))
         uncounted, _, _ = g.render(filter_mode=vrc.FILTER_TRILINEAR, count=False)
         assert (uncounted == staged).all()
 
@@ -688,6 +699,10 @@ def test_random_views_uint16_and_multipass(vrc, seed):
         got, _, st = g.render(kernel=vrc.KERNEL_LDS, filter_mode=vrc.FILTER_TRILINEAR)
         assert st.kernel_variant == vrc.KERNEL_LDS
         _fuzz_parity(got, want16_lin, "seed %d u16 trilinear staged %r" % (seed, kw))
+        if min(s16.vi.overlap[a] for a in range(3)) >= 1:
+            got, _, st = g.render(kernel=vrc.KERNEL_PACKED, filter_mode=vrc.FILTER_TRILINEAR)
+            assert st.kernel_variant == vrc.KERNEL_PACKED
+            _fuzz_parity(got, want16_lin, "seed %d u16 trilinear tap-packed %r" % (seed, kw))
     s = orc.build_scene(**kw)
     want, n_want = orc.oracle_render(s, threads=8)
     cuts = sorted(set(int(c) for c in rng.integers(1, max(2, s.n_nodes), size=3)) | {0, s.n_nodes})
@@ -963,11 +978,11 @@ def test_ray_lod_trilinear_staged_through_lds(vrc, sse, tf):
     lod = (sse, orc.world_space_per_pixel(s))
     want, n_want = orc.oracle_render(s, ray_lod=lod, filter_mode=1)
     with _gpu(s) as g:
-        # AUTO: the tap-packed atlas for 8-bit bricks (round 4), the staged form for 16-bit ones
+        # AUTO: the tap-packed atlas (round 4; tag unsigned int: of 8-bit voxels, unsigned long: of 16-bit voxels)
+        tag = ",unsigned int," if voxel == "unsigned char" else ",unsigned long,"
         auto, n_auto, st = g.render(ray_lod=lod, filter_mode=1)
         assert st.kernel_variant == vrc.KERNEL_RAY_LOD
-        if voxel == "unsigned char":
-            assert _ran(g).startswith("vrc_k_raycast_raylod<") and ",unsigned int," in _ran(g), _ran(g)
+        assert _ran(g).startswith("vrc_k_raycast_raylod<") and tag in _ran(g), _ran(g)
         staged, n_staged, st = g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_LDS)
         assert st.kernel_variant == vrc.KERNEL_RAY_LOD
         assert _ran(g).startswith("vrc_k_raycast_lds<true,true,") and _ran(g).endswith(",true,%s,false>" % voxel), _ran(g)
@@ -979,15 +994,11 @@ def test_ray_lod_trilinear_staged_through_lds(vrc, sse, tf):
         assert (uncounted == auto).all()
         with pytest.raises(Exception):
             g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_REFERENCE_ORDER)
-        if voxel == "unsigned char":
-            # ... and through the tap-packed atlas (round 4): the staged form's positions, weights and arithmetic
-            packed, n_packed, st = g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_PACKED)
-            assert st.kernel_variant == vrc.KERNEL_RAY_LOD and _ran(g).startswith("vrc_k_raycast_raylod<") and ",unsigned int," in _ran(g), _ran(g)
-            assert n_packed == n_staged
-            scenes.assert_same_frame(packed, staged, "per-ray LOD, tap-packed atlas vs LDS-staged", tol=1e-6)
-        else:
-            with pytest.raises(vrc.VrcError):
-                g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_PACKED)
+        # ... and through the tap-packed atlas asked for by name: the staged form's positions, weights and arithmetic
+        packed, n_packed, st = g.render(ray_lod=lod, filter_mode=1, kernel=vrc.KERNEL_PACKED)
+        assert st.kernel_variant == vrc.KERNEL_RAY_LOD and _ran(g).startswith("vrc_k_raycast_raylod<") and tag in _ran(g), _ran(g)
+        assert n_packed == n_staged
+        scenes.assert_same_frame(packed, staged, "per-ray LOD, tap-packed atlas vs LDS-staged", tol=1e-6)
     _lod_parity(staged, want, "staged sse %g" % sse)
     _lod_parity(gathered, want, "gathers sse %g" % sse)
     assert abs(n_staged - n_want) <= 3e-4 * n_want + 16
@@ -1166,7 +1177,12 @@ def test_atlas_of_more_than_2_pow_32_voxels(vrc):
         got, st = frame(vrc.KERNEL_GRID_DDA, vrc.FILTER_TRILINEAR)  # the gather form
         assert st.kernel_variant == vrc.KERNEL_GRID_DDA
         assert np.abs(got - want_lin).max() <= 1e-6
-        # the trilinear filter is staged through LDS here too (64-bit slot bases): the frame of the small pool, bit for bit
+        # AUTO takes the tap-packed atlas here too (64-bit lane pointers: the ...,true> instance) and, without it, stages
+        # the voxels through LDS (64-bit slot bases): the staged frame of the small pool, bit for bit, both times
+        got, st = frame(vrc.KERNEL_AUTO, vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_PACKED and L.vrc_last_kernel().decode().endswith(",unsigned int,12,true>"), L.vrc_last_kernel()
+        assert (got == want_lds).all() and st.samples == n_lds
+        vrc.check(L, L.vrc_set_option(ctx, vrc.OPT_PACKED_ATLAS, 0))
         got, st = frame(vrc.KERNEL_AUTO, vrc.FILTER_TRILINEAR)
         assert st.kernel_variant == vrc.KERNEL_LDS and L.vrc_last_kernel().decode().endswith(",false,unsigned char,true>")
         assert (got == want_lds).all() and st.samples == n_lds
@@ -1252,11 +1268,16 @@ def test_ray_lod_in_an_atlas_of_more_than_2_pow_32_voxels(vrc):
         want, n_want, st = g.render(kernel=vrc.KERNEL_GRID_DDA, stepping=0, ray_lod=lod)
         assert st.kernel_variant == vrc.KERNEL_RAY_LOD
         want_lin, n_lin, _ = g.render(kernel=vrc.KERNEL_GRID_DDA, filter_mode=vrc.FILTER_TRILINEAR, ray_lod=lod)
+        want_pk, n_pk, _ = g.render(kernel=vrc.KERNEL_PACKED, filter_mode=vrc.FILTER_TRILINEAR, ray_lod=lod)
+    # ... and the tap-packed atlas of such a pool (13.5 GB here): 64-bit lane pointers, the small pool's packed frame
     got = _frames_in_a_large_pool(vrc, s, 6 * 1000 ** 3, 2 ** 32,
-                                  [({vrc.OPT_FILTER: vrc.FILTER_NEAREST}, lod), ({vrc.OPT_FILTER: vrc.FILTER_TRILINEAR}, lod)])
-    for (fb, n, variant, name), frame_want, n_w in zip(got, (want, want_lin), (n_want, n_lin)):
+                                  [({vrc.OPT_FILTER: vrc.FILTER_NEAREST}, lod),
+                                   ({vrc.OPT_FILTER: vrc.FILTER_TRILINEAR, vrc.OPT_PACKED_ATLAS: 0}, lod),
+                                   ({vrc.OPT_FILTER: vrc.FILTER_TRILINEAR, vrc.OPT_PACKED_ATLAS: 1}, lod)])
+    for (fb, n, variant, name), frame_want, n_w in zip(got, (want, want_lin, want_pk), (n_want, n_lin, n_pk)):
         assert variant == vrc.KERNEL_RAY_LOD and name.endswith(",true>"), name
         assert n == n_w and (fb == frame_want).all(), name
+    assert ",unsigned int," in got[2][3] and ",unsigned int," not in got[1][3], (got[1][3], got[2][3])
 
 
 def test_tap_packed_atlas_of_more_than_4_gib(vrc):

@@ -39,7 +39,8 @@ def test_harness_matches_oracle(sse, kernel):
     assert abs(n_got - n_want) <= 3e-4 * n_want + 16
 
 
-@pytest.mark.parametrize("kernel,filter_mode,dtype", [(5, 1, "u8"), (7, 0, "u8"), (5, 1, "u16"), (7, 0, "u16")])
+@pytest.mark.parametrize("kernel,filter_mode,dtype", [(5, 1, "u8"), (7, 0, "u8"), (5, 1, "u16"), (7, 0, "u16"),
+                                                      (9, 1, "u8"), (9, 1, "u16"), (11, 1, "u16")])  # 9 / 11: tap-packed atlas
 def test_per_sample_classification_modes(kernel, filter_mode, dtype):
     s = _hierarchy(viewport=(40, 32), volume="hash", spin=(-0.7, 0.2), dtype=dtype, alpha=0.3)
     lod = (1.6, orc.world_space_per_pixel(s))
