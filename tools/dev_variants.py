@@ -32,10 +32,11 @@ def main():
     ap.add_argument("--no-tile-order", action="store_true", help="row-major tile order instead of heaviest-first")
     ap.add_argument("--kernel", type=int, default=vrc.KERNEL_GRID_DDA, help="VRC_KERNEL_* code")
     ap.add_argument("--filter", type=int, default=0, help="0 nearest, 1 trilinear")
+    ap.add_argument("--dtype", default="u8", help="u8 | u16")
     a = ap.parse_args()
     t0 = time.time()
     s = orc.build_scene(voxels=(a.voxels,) * 3, block=a.block, viewport=(a.viewport,) * 2,
-                        volume=a.volume, spin=tuple(a.spin), alpha=a.alpha)
+                        volume=a.volume, spin=tuple(a.spin), alpha=a.alpha, dtype=a.dtype)
     print("scene %s built in %.1fs: %d nodes spr %d" % (a.volume, time.time() - t0, s.n_nodes,
           s.render.samplesPerRay), flush=True)
     view = C.cast(C.byref(s.view), C.POINTER(vrc.ViewData))
