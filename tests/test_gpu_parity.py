@@ -168,8 +168,8 @@ def test_the_judged_kernel_runs_five_workgroups_per_cu(vrc):
 
 @pytest.mark.parametrize("name", sorted(scenes.SCENES))
 def test_tap_packed_trilinear_parity(vrc, name):
-    # VRC_KERNEL_PACKED: the trilinear filter through the pool's tap-packed atlas (32-bit texels holding the 2x2
-    # neighbourhood, two gathers per sample; vrc_core.h: vrc_march_segment_packed) against the oracle's
+    # VRC_KERNEL_PACKED: the trilinear filter through the pool's tap-packed atlas (16-bit texels holding a voxel and its
+    # z neighbour, two 4-byte gathers per sample; vrc_core.h: vrc_march_segment_packed) against the oracle's
     # fetch_trilinear and against the LDS-staged form, whose positions, weights and arithmetic it shares
     s = scenes.get(name)
     L = None
