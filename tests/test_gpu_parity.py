@@ -711,6 +711,14 @@ def test_random_views_uint16_and_multipass(vrc, seed):
         for k in (vrc.KERNEL_REFERENCE_ORDER, vrc.KERNEL_GRID_DDA, vrc.KERNEL_LDS):
             got, n_got, _ = g.render(kernel=k, passes=passes)
             _fuzz_parity(got, want, "seed %d multipass %r k%d %r" % (seed, passes, k, kw))
+        if min(s.vi.overlap[a] for a in range(3)) >= 1:
+            # the tap-packed march over the same passes (the grey form on the first pass only: later passes start from
+            # the pixel's colour so far) and in one pass
+            want_lin, n_lin = orc.oracle_render(s, threads=8, filter_mode=1)
+            one, n_one, _ = g.render(kernel=vrc.KERNEL_PACKED, filter_mode=vrc.FILTER_TRILINEAR)
+            got, n_got, _ = g.render(kernel=vrc.KERNEL_PACKED, filter_mode=vrc.FILTER_TRILINEAR, passes=passes)
+            _fuzz_parity(got, want_lin, "seed %d multipass %r tap-packed %r" % (seed, passes, kw))
+            assert n_got == n_one and np.abs(got - one).max() <= 1e-6
 
 
 def test_c1_config_parity(vrc):
