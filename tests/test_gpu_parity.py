@@ -1213,7 +1213,7 @@ def _frames_in_a_large_pool(vrc, s, pool_bytes, line_voxels, cases):
     out = []
     try:
         mb = [s.vi.maximumBlockSize[a] for a in range(3)]
-        vrc.check(L, L.vrc_pool_create(ctx, 1, 0, 0, 1, vrc.u32x3(*mb), pool_bytes, C.byref(pool)))
+        vrc.check(L, L.vrc_pool_create(ctx, s.atlas.dtype.itemsize, 0, 0, 1, vrc.u32x3(*mb), pool_bytes, C.byref(pool)))
         sb, ab, fs = C.c_size_t(), C.c_size_t(), C.c_uint32()
         ad, sl = vrc.u32x3(), vrc.u32x3()
         vrc.check(L, L.vrc_pool_info(pool, C.byref(sb), ad, C.byref(ab), sl, C.byref(fs)))
@@ -1308,6 +1308,15 @@ def test_tap_packed_atlas_of_more_than_4_gib(vrc):
     for (fb, n, variant, name), frame_want, n_w, v in zip(got, (want_lod, want), (n_lod, n_want), (vrc.KERNEL_RAY_LOD, vrc.KERNEL_PACKED)):
         assert variant == v and ",unsigned int," in name and name.endswith(",true>"), name
         assert n == n_w and (fb == frame_want).all(), name
+    # the same for 16-bit voxels (32-bit texels: the 4 GiB line lies at 2^32 / 4.5 voxels)
+    s16 = orc.build_scene(voxels=(64, 64, 64), block=16, viewport=(96, 80), volume="hash", spin=(0.5, 0.35),
+                          ids=orc.all_level_ids(vi), dtype="u16")
+    with _gpu(s16) as g:
+        want16, n16, st = g.render(kernel=vrc.KERNEL_PACKED, filter_mode=vrc.FILTER_TRILINEAR)
+        assert st.kernel_variant == vrc.KERNEL_PACKED and _ran(g).endswith(",unsigned long,12,false>"), _ran(g)
+    (fb, n, variant, name), = _frames_in_a_large_pool(vrc, s16, 6 * 1000 ** 3, (2 ** 32) * 2 // 9, [(opts, None)])
+    assert variant == vrc.KERNEL_PACKED and name.endswith(",unsigned long,12,true>"), name
+    assert n == n16 and (fb == want16).all(), name
 
 
 def test_slot_longer_than_255_voxels_marches_with_float_positions(vrc):
