@@ -495,9 +495,17 @@ int vrc_pool_create( vrc_ctx* c, size_t bytesPerVoxel, int isSigned, int isFloat
                                          (float)k / (float)p->slots[2], 0.0f } );
 
     e = hipMalloc( &p->dAtlas, p->atlasBytes );
-    if( e == hipSuccess ) e = hipMemset( p->dAtlas, 0, p->atlasBytes );
     if( e == hipSuccess ) e = hipStreamCreateWithFlags( &p->uploadStream, hipStreamNonBlocking );
+    /* the clear goes on the upload stream, where every write to the atlas is queued: a hipMemset on the null stream is
+     * not ordered with a non-blocking stream, and the first uploads of a large pool could be overtaken by it (seen once:
+     * a 6 GB pool of 16-bit voxels, round 4) */
+    if( e == hipSuccess ) e = hipMemsetAsync( p->dAtlas, 0, p->atlasBytes, p->uploadStream );
     if( e == hipSuccess ) e = hipEventCreateWithFlags( &p->lastUpload, hipEventDisableTiming );
+    if( e == hipSuccess )
+    {
+        e = hipEventRecord( p->lastUpload, p->uploadStream ); /* a render before any upload waits for the clear too */
+        p->hasUpload = true;
+    }
     for( int k = 0; k < 2 && e == hipSuccess; ++k )
         e = hipStreamCreateWithFlags( &p->copyStream[k], hipStreamNonBlocking );
     for( int s = 0; s < kStagingSlots && e == hipSuccess; ++s )
