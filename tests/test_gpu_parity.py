@@ -1319,6 +1319,48 @@ def test_tap_packed_atlas_of_more_than_4_gib(vrc):
     assert n == n16 and (fb == want16).all(), name
 
 
+def test_first_uploads_into_a_fresh_large_pool_survive_its_clear(vrc):
+    # a new atlas is cleared; the clear is queued on the upload stream, BEFORE the first uploads (round 4: it was a
+    # hipMemset on the null stream, which a non-blocking stream does not wait for -- in one cold run of four the clear of
+    # a 6 GB pool overtook the first bricks written into it).  Several fresh 6 GB pools, bricks uploaded at once from
+    # four threads, every brick read back
+    import threading
+    L = vrc.load_library()
+    rng = np.random.default_rng(11)
+    bricks = [rng.integers(1, 256, size=(24, 24, 24), dtype=np.uint8) for _ in range(32)]
+    ctx = C.c_void_p()
+    vrc.check(L, L.vrc_ctx_create(0, C.byref(ctx)))
+    try:
+        for _ in range(4):
+            pool = C.c_void_p()
+            vrc.check(L, L.vrc_pool_create(ctx, 1, 0, 0, 1, vrc.u32x3(24, 24, 24), 6 * 1000 ** 3, C.byref(pool)))
+            try:
+                slots = [None] * len(bricks)
+
+                def up(t):
+                    for i in range(t, len(bricks), 4):
+                        slot = vrc.f32x3()
+                        vrc.check(L, L.vrc_pool_copy_to_slot(pool, bricks[i].ctypes.data, vrc.u32x3(24, 24, 24), slot))
+                        slots[i] = (slot[0], slot[1], slot[2])
+                ths = [threading.Thread(target=up, args=(t,)) for t in range(4)]
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+                sb, ab, fs = C.c_size_t(), C.c_size_t(), C.c_uint32()
+                ad, sl = vrc.u32x3(), vrc.u32x3()
+                vrc.check(L, L.vrc_pool_info(pool, C.byref(sb), ad, C.byref(ab), sl, C.byref(fs)))
+                for i, b in enumerate(bricks):
+                    origin = [int(round(slots[i][a] * sl[a])) * (ad[a] // sl[a]) for a in range(3)]
+                    out = np.zeros_like(b)
+                    vrc.check(L, L.vrc_pool_read_region(pool, vrc.u32x3(*origin), vrc.u32x3(24, 24, 24), out.ctypes.data))
+                    assert (out == b).all(), "brick %d of a fresh pool" % i
+            finally:
+                L.vrc_pool_destroy(pool)
+    finally:
+        L.vrc_ctx_destroy(ctx)
+
+
 def test_slot_longer_than_255_voxels_marches_with_float_positions(vrc):
     # pool creation bounds a slot's volume (2^24 voxels), not its edges: a 300 x 16 x 16 brick (overlap 1) has slot-local
     # coordinates that do not fit the 8.24 fixed-point positions of VRC_OPT_STEPPING = 1, the address tables and the LDS
